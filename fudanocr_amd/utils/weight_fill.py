@@ -1,0 +1,89 @@
+"""Name-keyed deterministic parameter fill.
+
+Every tensor of a ``state_dict`` is filled from a generator seeded by the CRC32 of its
+key, so the reference model (in the authoring container), the CPU oracle and the HIP
+product model all get bit-identical weights from the key names alone -- weights never
+have to travel as fixtures.
+
+Rules (chosen so that every layer is numerically "alive"):
+  * ``*.num_batches_tracked``, ``tps.*`` buffers, ``stn_head.stn_fc2.bias`` : untouched
+    (the fc2 bias is the control-point frame, reference stn_head.py:69-86).
+  * BatchNorm (a key that has a sibling ``running_mean``): weight U[0.5,1.5],
+    bias U[-0.1,0.1], running_mean U[-0.1,0.1], running_var U[0.5,1.5].
+  * LayerNorm ``a_2`` U[0.5,1.5], ``b_2`` U[-0.1,0.1]  (reference tbsrn.py:23-36).
+  * PReLU slope (shape [1] weight): U[0.1,0.4].
+  * dim >= 2: U[-1/sqrt(fan_in), +1/sqrt(fan_in)], fan_in = numel / shape[0];
+    ``stn_head.stn_fc2.weight`` additionally scaled by 0.2 (keeps the warp mild).
+  * remaining 1-D tensors (biases): U[-0.1, 0.1].
+"""
+import math
+import zlib
+
+import torch
+
+
+def _u(shape, lo, hi, key):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(zlib.crc32(key.encode("utf-8")))
+    return torch.rand(shape, generator=g, dtype=torch.float32) * (hi - lo) + lo
+
+
+def fill_value(key, shape, siblings):
+    """Return the fp32 CPU tensor for `key`, or None when the entry is left untouched."""
+    leaf = key.rsplit(".", 1)[-1]
+    prefix = key[: -len(leaf)]
+    if leaf == "num_batches_tracked" or key.startswith("tps."):
+        return None
+    if key == "stn_head.stn_fc2.bias":
+        return None
+    is_bn = (prefix + "running_mean") in siblings
+    if is_bn:
+        if leaf == "weight":
+            return _u(shape, 0.5, 1.5, key)
+        if leaf == "bias":
+            return _u(shape, -0.1, 0.1, key)
+        if leaf == "running_mean":
+            return _u(shape, -0.1, 0.1, key)
+        if leaf == "running_var":
+            return _u(shape, 0.5, 1.5, key)
+        return None
+    if leaf == "a_2":
+        return _u(shape, 0.5, 1.5, key)
+    if leaf == "b_2":
+        return _u(shape, -0.1, 0.1, key)
+    if len(shape) >= 2:
+        numel = 1
+        for s in shape:
+            numel *= s
+        fan_in = max(1, numel // shape[0])
+        b = 1.0 / math.sqrt(fan_in)
+        t = _u(shape, -b, b, key)
+        if key == "stn_head.stn_fc2.weight":
+            t = t * 0.2
+        return t
+    if leaf == "weight" and tuple(shape) == (1,):
+        return _u(shape, 0.1, 0.4, key)
+    return _u(shape, -0.1, 0.1, key)
+
+
+@torch.no_grad()
+def fill_module_(module):
+    """Fill every entry of ``module.state_dict()`` in place; returns the module."""
+    sd = module.state_dict()
+    keys = set(sd.keys())
+    for k in sorted(sd.keys()):
+        v = fill_value(k, tuple(sd[k].shape), keys)
+        if v is not None:
+            sd[k].copy_(v.to(sd[k].device))
+    return module
+
+
+@torch.no_grad()
+def fill_dict_(params):
+    """Same rule for a plain ``{key: tensor}`` dict (used by the functional oracle)."""
+    keys = set(params.keys())
+    for k in sorted(params.keys()):
+        v = fill_value(k, tuple(params[k].shape), keys)
+        if v is not None:
+            params[k].copy_(v)
+    return params
