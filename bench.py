@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training images/sec of the SR + CTC optimisation step on synthetic
+16x64 -> 32x128 crops (BASELINE.json metric), one process per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = forward (TBSRN, STN on, dropout on) -> MSE + frozen-CRNN CTC -> (loss*100).backward()
+-> [RCCL all-reduce of the flat gradient buffer] -> clip 0.25 -> Adam, on a device-resident
+synthetic batch of 128 images per GPU (BASELINE configs[2]/[3]; weak scaling).  Prints ONE JSON
+line on rank 0 with `roofline` (dominant kernel, measured with on-stream events in the timed
+region) and `cpu_baseline` (the CPU oracle timed on this box's host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA = vector f32 peak
+FLOP_PER_IMG = 18.131e9           # TBSRN fwd+bwd 15.311 + frozen CRNN 2.820
+
+
+def cpu_baseline(batch=4, steps=3):
+    """Oracle (CPU restatement of the reference maths, kind 'port') on the host cores."""
+    from fudanocr_amd.utils.synth import make_batch
+    from fudanocr_amd.utils.weight_fill import fill_dict_
+    from oracle import sr_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    P = O.make_params(O.schema_sr("tbsrn"))
+    fill_dict_({k: v.data for k, v in P.items()})
+    C = O.make_params(O.schema_crnn(), requires_grad=False)
+    fill_dict_(C)
+    opt = O.AdamState([v for v in P.values() if v.requires_grad])
+    lr, hr, labels = make_batch(batch, 1234)
+    tgt, tlen = O.encode_labels(labels)
+    O.train_step(P, opt, "tbsrn", lr, hr, C, tgt, tlen, dropout_p=0.1)          # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        O.train_step(P, opt, "tbsrn", lr, hr, C, tgt, tlen, dropout_p=0.1)
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * steps / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d timed steps of batch %d (TBSRN+CRNN-CTC step, fp32, torch CPU oracle)" % (steps, batch)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
+    ap.add_argument("--arch", default="tbsrn")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from fudanocr_amd import _lib
+    from fudanocr_amd.engine import TrainStep
+    from fudanocr_amd.smoke import build_models
+    from fudanocr_amd.utils.synth import make_batch
+    _lib.load()
+    net, rec, crit = build_models(dev, args.arch)
+    step = TrainStep(net, crit, dropout=True)
+    lr, hr, labels = make_batch(args.batch, 1234 + rank)
+    lr, hr = lr.to(dev), hr.to(dev)
+    enc = crit.encode(labels, dev)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(lr, hr, encoded=enc)
+    timed = ["focr_attention_fwd", "focr_attention_bwd"]
+    sync()
+    _lib.start_timing(timed)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(lr, hr, encoded=enc)
+    sync()
+    dt = time.perf_counter() - t0
+    kt = _lib.stop_timing()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    loss = out["loss"].item()
+    if rank == 0:
+        imgs = args.batch * world * args.steps
+        value = imgs / dt
+        # dominant kernel: fused attention forward (one launch per SRB): 4*B*H*N^2*d flops
+        fwd_ms = sum(kt["focr_attention_fwd"]) / max(1, len(kt["focr_attention_fwd"]))
+        flops_launch = 4.0 * args.batch * 4 * 1024 * 1024 * 32
+        ach = flops_launch / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
+        res = {
+            "metric": "training images/sec (16x64->32x128 SR+CTC step)", "value": round(value, 2),
+            "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "TBSRN + frozen CRNN-CTC train step (BASELINE configs[2]), STN on, "
+                                   "dropout on, 16x64->32x128", "per_gpu_batch": args.batch,
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "arch": args.arch},
+            "roofline": {"bound": "mfma", "kernel": "attn_fwd_kernel (fused QK^T-softmax-dropout-PV, f32 MFMA)",
+                         "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": round(fwd_ms, 4),
+                         "step_frac_of_peak": round(value * FLOP_PER_IMG / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+            "final_loss": round(loss, 5),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,112 @@
+"""ctypes loader for the C-ABI library libfocr_hip.so (include/focr.h).
+
+There is NO fallback: if the library is missing or a symbol is absent, importing the ops
+raises.  The product never routes through the CPU oracle.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfocr_hip.so")
+
+P, I, L, F, U = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_uint64
+
+# name -> argument types (every entry point returns int and takes the stream last)
+SIGNATURES = {
+    "focr_conv2d_fwd": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, I, P],
+    "focr_conv2d_wgrad": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "focr_weight_flip_transpose": [P, P, I, I, I, I, P],
+    "focr_colsum": [P, P, L, I, I, P],
+    "focr_attention_fwd": [P, P, P, P, P, I, I, I, I, F, F, U, P],
+    "focr_attention_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, U, P],
+    "focr_bn_train_fwd": [P, P, P, P, P, P, P, P, P, P, P, L, I, F, F, I, P],
+    "focr_bn_eval_fwd": [P, P, P, P, P, P, P, P, L, I, F, I, P],
+    "focr_bn_bwd": [P, P, P, P, P, P, P, P, P, P, L, I, I, I, P],
+    "focr_layernorm_fwd": [P, P, P, P, P, P, P, L, I, F, P],
+    "focr_layernorm_bwd": [P, P, P, P, P, P, P, P, P, L, I, F, P],
+    "focr_prelu_fwd": [P, P, P, L, P],
+    "focr_prelu_bwd": [P, P, P, P, P, L, P],
+    "focr_pixelshuffle_mish_fwd": [P, P, I, I, I, I, P],
+    "focr_pixelshuffle_mish_bwd": [P, P, P, I, I, I, I, P],
+    "focr_nchw_to_nhwc": [P, P, I, I, I, P],
+    "focr_nhwc_to_nchw": [P, P, I, I, I, I, P],
+    "focr_tanh_bwd_to_nhwc": [P, P, P, I, I, I, P],
+    "focr_concat_pe": [P, P, P, L, I, I, I, P],
+    "focr_slice_cols": [P, P, P, L, I, I, I, P],
+    "focr_dropout": [P, P, L, F, U, P],
+    "focr_mse_fwd": [P, P, P, L, P],
+    "focr_mse_bwd": [P, P, P, P, L, P],
+    "focr_axpy": [P, P, P, L, F, P],
+    "focr_relu_bwd": [P, P, P, L, P],
+    "focr_maxpool_fwd": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "focr_maxpool_bwd": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "focr_tps_fwd": [P, P, P, P, P, P, I, I, I, I, I, P],
+    "focr_tps_bwd": [P, P, P, P, P, P, I, I, I, I, I, P],
+    "focr_bicubic_gray_fwd": [P, P, I, I, I, I, I, P],
+    "focr_bicubic_gray_bwd": [P, P, I, I, I, I, I, P],
+    "focr_lstm_bidir_fwd": [P, P, P, P, P, P, I, I, I, I, I, P],
+    "focr_lstm_bidir_bwd": [P, P, P, P, P, P, I, I, I, I, I, P],
+    "focr_ctc_fwd": [P, P, P, P, P, P, P, I, I, I, P],
+    "focr_scale_dev": [P, P, P, L, P],
+    "focr_grad_sumsq": [P, P, L, F, P],
+    "focr_clip_adam": [P, P, P, P, P, L, F, F, F, F, I, F, F, P],
+}
+
+_lib = None
+
+
+def load():
+    """Load the library and bind every symbol declared in include/focr.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "fudanocr_amd: %s is missing -- build it with `python __graft_entry__.py` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.argtypes = args
+        fn.restype = ctypes.c_int
+    lib.focr_last_error.restype = ctypes.c_char_p
+    lib.focr_last_error.argtypes = []
+    lib.focr_version.restype = ctypes.c_int
+    lib.focr_version.argtypes = []
+    _lib = lib
+    return lib
+
+
+# optional on-stream timing of selected entry points (bench.py's roofline leg): name -> list of
+# (start_event, end_event) recorded on the stream the kernel is launched on.
+_timed = None
+
+
+def start_timing(names):
+    global _timed
+    _timed = {n: [] for n in names}
+
+
+def stop_timing():
+    """Returns {name: [ms, ...]} (synchronises)."""
+    global _timed
+    import torch
+    torch.cuda.synchronize()
+    out = {n: [a.elapsed_time(b) for a, b in ev] for n, ev in (_timed or {}).items()}
+    _timed = None
+    return out
+
+
+def call(name, *args):
+    lib = load()
+    if _timed is not None and name in _timed:
+        import torch
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = getattr(lib, name)(*args)
+        b.record()
+        _timed[name].append((a, b))
+    else:
+        rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (name, rc, lib.focr_last_error().decode()))

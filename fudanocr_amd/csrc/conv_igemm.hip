@@ -1,0 +1,453 @@
+// Implicit-GEMM NHWC convolution / linear layer on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// Replaces the reference's torch ops nn.Conv2d / nn.Linear (SURVEY.md section 2.3 K1-K3,
+// K6, K9-K12, K15; call sites model/tsrn.py:26-43,80-94,101-114, model/tbsrn.py:103-129,
+// 153-163, model/stn_head.py:13-49, model/crnn/crnn.py:31-63) with ONE kernel family:
+//
+//   forward : Y[p][co] = act(alpha * sum_k A[p][k] * W[co][k] + bias[co] + R[p][co])
+//             p = (n,oy,ox)  k = (kh,kw,ci)  A[p][k] = X[n,oy+kh-ph,ox+kw-pw,ci] (0 outside)
+//   dgrad   : the same kernel on flipped/transposed weights (focr_weight_flip_transpose)
+//   wgrad   : dW[co][k] = sum_p dY[p][co] * A[p][k]   (split over p, fp32 atomics)
+//
+// No im2col buffer exists: the A operand is gathered straight from the NHWC tensor into
+// an LDS tile (rows = pixels, 32 consecutive k per chunk), the re-reads across the KHxKW
+// taps are served by L2.  Precision: exact fp32 (the f32-input MFMA is a k-ordered fmaf
+// chain), which is what the 1e-3 parity gate against the fp32 reference needs; roofline =
+// 157.3 TFLOP/s (MI355X_MICROARCH.md).
+//
+// Tile: 128 pixels x (32*NT) channels per 256-thread block, 4 waves stacked along pixels,
+// each wave 32 pixels x 32*NT channels = NT accumulators of 16 VGPRs.  LDS pitch 36 floats:
+// the ds_read_b128 fragment reads (16-lane groups, 64 banks) are conflict-free.
+#include "focr_common.h"
+
+#define BM 128
+#define BK 32
+#define LDP 36   // LDS row pitch in floats (BK + 4)
+
+struct ConvGeom {
+  int N, H, W, Cin;       // input  NHWC
+  int OH, OW, Cout;       // output NHWC
+  int KH, KW, padH, padW;
+  int Ktot;               // KH*KW*Cin
+  int M;                  // N*OH*OW
+  int ldy;                // output row pitch (floats) >= Cout
+  int ldr;                // residual row pitch
+};
+
+// ---------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------
+template <int NT, bool VEC>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__ X,
+                                                       const float* __restrict__ Wt,
+                                                       const float* __restrict__ bias,
+                                                       const float* __restrict__ R,
+                                                       float* __restrict__ Y, ConvGeom g,
+                                                       float alpha, int relu) {
+  constexpr int BN = 32 * NT;
+  __shared__ __attribute__((aligned(16))) float As[BM * LDP];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * LDP];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int nchunks = (g.Ktot + BK - 1) / BK;
+
+  // ---- per-thread staging coordinates -------------------------------------------------
+  // VEC: thread owns float4 column c4 = tid&7 of rows (tid>>3) + 32*i, i<4
+  // SCALAR: thread owns column kk = tid&31 of rows (tid>>5) + 8*i, i<16
+  constexpr int AROWS = VEC ? 4 : 16;
+  int rbase[AROWS];     // element offset of pixel (n, oy-ph, ox-pw, 0), only used if valid
+  int riy[AROWS], rix[AROWS];
+#pragma unroll
+  for (int i = 0; i < AROWS; ++i) {
+    int row = VEC ? (tid >> 3) + 32 * i : (tid >> 5) + 8 * i;
+    int p = m0 + row;
+    if (p < g.M) {
+      int n = p / (g.OH * g.OW);
+      int rem = p - n * (g.OH * g.OW);
+      int oy = rem / g.OW, ox = rem - oy * g.OW;
+      riy[i] = oy - g.padH;
+      rix[i] = ox - g.padW;
+      rbase[i] = n * g.H * g.W;
+    } else {
+      riy[i] = -100000;   // never in bounds
+      rix[i] = 0;
+      rbase[i] = 0;
+    }
+  }
+
+  float4 areg[VEC ? 4 : 1];
+  float asc[VEC ? 1 : 16];
+  constexpr int BV = VEC ? (BN * BK / 4) / 256 : (BN * BK) / 256;   // per-thread B loads
+  float4 breg[VEC ? BV : 1];
+  float bsc[VEC ? 1 : BV];
+
+  auto load_chunk = [&](int c) {
+    const int k0 = c * BK;
+    if constexpr (VEC) {
+      // chunk lies inside one tap (Cin % BK == 0)
+      int tap = k0 / g.Cin;
+      int ci0 = k0 - tap * g.Cin + (tid & 7) * 4;
+      int kh = tap / g.KW, kw = tap - kh * g.KW;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int iy = riy[i] + kh, ix = rix[i] + kw;
+        bool ok = (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v = *reinterpret_cast<const float4*>(X + ((size_t)(rbase[i] + iy * g.W + ix) * g.Cin + ci0));
+        areg[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < BV; ++i) {
+        int idx = tid + 256 * i;
+        int row = idx >> 3, c4 = idx & 7;
+        int co = n0 + row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (co < g.Cout) v = *reinterpret_cast<const float4*>(Wt + (size_t)co * g.Ktot + k0 + c4 * 4);
+        breg[i] = v;
+      }
+    } else {
+      int k = k0 + (tid & 31);
+      bool kok = k < g.Ktot;
+      int tap = k / g.Cin;
+      int ci = k - tap * g.Cin;
+      int kh = tap / g.KW, kw = tap - kh * g.KW;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        int iy = riy[i] + kh, ix = rix[i] + kw;
+        bool ok = kok && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+        asc[i] = ok ? X[(size_t)(rbase[i] + iy * g.W + ix) * g.Cin + ci] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < BV; ++i) {
+        int row = (tid >> 5) + 8 * i;
+        int co = n0 + row;
+        bsc[i] = (kok && co < g.Cout) ? Wt[(size_t)co * g.Ktot + k] : 0.f;
+      }
+    }
+  };
+  auto store_chunk = [&]() {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<float4*>(&As[((tid >> 3) + 32 * i) * LDP + (tid & 7) * 4]) = areg[i];
+#pragma unroll
+      for (int i = 0; i < BV; ++i) {
+        int idx = tid + 256 * i;
+        *reinterpret_cast<float4*>(&Bs[(idx >> 3) * LDP + (idx & 7) * 4]) = breg[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) As[((tid >> 5) + 8 * i) * LDP + (tid & 31)] = asc[i];
+#pragma unroll
+      for (int i = 0; i < BV; ++i) Bs[((tid >> 5) + 8 * i) * LDP + (tid & 31)] = bsc[i];
+    }
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int li = lane & 31, lh = lane >> 5;
+  const float* aptr = &As[(wave * 32 + li) * LDP + 4 * lh];
+  const float* bptr = &Bs[li * LDP + 4 * lh];
+
+  load_chunk(0);
+  for (int c = 0; c < nchunks; ++c) {
+    store_chunk();
+    __syncthreads();
+    if (c + 1 < nchunks) load_chunk(c + 1);
+    float4 af[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) af[t] = *reinterpret_cast<const float4*>(aptr + 8 * t);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float4 bf[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) bf[t] = *reinterpret_cast<const float4*>(bptr + nt * 32 * LDP + 8 * t);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t].x, bf[t].x, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t].y, bf[t].y, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t].z, bf[t].z, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t].w, bf[t].w, acc[nt], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds channel n0 + nt*32 + li for 16 pixel rows --------------------
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int co = n0 + nt * 32 + li;
+    if (co >= g.Cout) continue;
+    float b = bias ? bias[co] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int p = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (p < g.M) {
+        float v = alpha * acc[nt][r] + b;
+        if (R) v += R[(size_t)p * g.ldr + co];
+        if (relu) v = fmaxf(v, 0.f);
+        Y[(size_t)p * g.ldy + co] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// wgrad:  dW[co][k] += sum_{p in split} dY[p][co] * A[p][k]
+// block tile 64 co x 64 k, 4 waves as 2x2 of 32x32; reduction chunk = 32 pixels.
+// ---------------------------------------------------------------------------------------
+#define WP 68   // LDS pitch for the [32 pixel][64] tiles
+template <bool VEC>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ X,
+                                                         const float* __restrict__ dY,
+                                                         float* __restrict__ dW, ConvGeom g,
+                                                         int ldd, int pix_per_split) {
+  __shared__ __attribute__((aligned(16))) float Ds[32 * WP];   // dY tile  [pixel][co]
+  __shared__ __attribute__((aligned(16))) float Xs[32 * WP];   // A tile   [pixel][k]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int k0 = blockIdx.x * 64;
+  const int co0 = blockIdx.y * 64;
+  const int pbeg = blockIdx.z * pix_per_split;
+  const int pend = min(g.M, pbeg + pix_per_split);
+  if (pbeg >= pend) return;
+
+  // staging: 32 pixels x 64 columns = 2048 floats = 512 float4 -> 2 per thread (VEC)
+  // VEC : thread -> pixel rows (tid>>4) + 16*i, float4 column (tid&15)
+  // SCALAR: thread -> column tid&63, pixel rows (tid>>6) + 4*i, i<8
+  int tapkh = 0, tapkw = 0, ci0 = 0;
+  bool kok = true;
+  if constexpr (VEC) {
+    int tap = k0 / g.Cin;                 // 64-wide k tile inside one tap (Cin % 64 == 0)
+    ci0 = k0 - tap * g.Cin + (tid & 15) * 4;
+    tapkh = tap / g.KW;
+    tapkw = tap - tapkh * g.KW;
+  } else {
+    int k = k0 + (tid & 63);
+    kok = k < g.Ktot;
+    int tap = k / g.Cin;
+    ci0 = k - tap * g.Cin;
+    tapkh = tap / g.KW;
+    tapkw = tap - tapkh * g.KW;
+  }
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int wi = wave >> 1, wj = wave & 1;     // wave tile: co rows wi*32.., k cols wj*32..
+  const int li = lane & 31, lh = lane >> 5;
+
+  for (int pc = pbeg; pc < pend; pc += 32) {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int row = (tid >> 4) + 16 * i;
+        int p = pc + row;
+        float4 dv = make_float4(0.f, 0.f, 0.f, 0.f), xv = dv;
+        if (p < pend) {
+          int co = co0 + (tid & 15) * 4;
+          if (co + 3 < g.Cout) {
+            dv = *reinterpret_cast<const float4*>(dY + (size_t)p * ldd + co);
+          } else {
+            float t[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int e = 0; e < 4; ++e)
+              if (co + e < g.Cout) t[e] = dY[(size_t)p * ldd + co + e];
+            dv = make_float4(t[0], t[1], t[2], t[3]);
+          }
+          int n = p / (g.OH * g.OW);
+          int rem = p - n * (g.OH * g.OW);
+          int oy = rem / g.OW, ox = rem - oy * g.OW;
+          int iy = oy - g.padH + tapkh, ix = ox - g.padW + tapkw;
+          if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
+            xv = *reinterpret_cast<const float4*>(X + ((size_t)((n * g.H + iy) * g.W + ix) * g.Cin + ci0));
+        }
+        *reinterpret_cast<float4*>(&Ds[row * WP + (tid & 15) * 4]) = dv;
+        *reinterpret_cast<float4*>(&Xs[row * WP + (tid & 15) * 4]) = xv;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        int row = (tid >> 6) + 4 * i;
+        int p = pc + row;
+        float dv = 0.f, xv = 0.f;
+        if (p < pend) {
+          int co = co0 + (tid & 63);
+          if (co < g.Cout) dv = dY[(size_t)p * ldd + co];
+          if (kok) {
+            int n = p / (g.OH * g.OW);
+            int rem = p - n * (g.OH * g.OW);
+            int oy = rem / g.OW, ox = rem - oy * g.OW;
+            int iy = oy - g.padH + tapkh, ix = ox - g.padW + tapkw;
+            if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
+              xv = X[(size_t)((n * g.H + iy) * g.W + ix) * g.Cin + ci0];
+          }
+        }
+        Ds[row * WP + (tid & 63)] = dv;
+        Xs[row * WP + (tid & 63)] = xv;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      float a = Ds[(2 * s + lh) * WP + wi * 32 + li];
+      float b = Xs[(2 * s + lh) * WP + wj * 32 + li];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // acc[r]: row (co) = (r&3)+8*(r>>2)+4*lh, col (k) = li
+  int k = k0 + wj * 32 + li;
+  if (k < g.Ktot) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int co = co0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (co < g.Cout) atomicAdd(&dW[(size_t)co * g.Ktot + k], acc[r]);
+    }
+  }
+}
+
+// W[co][kh][kw][ci] -> Wd[ci][KH-1-kh][KW-1-kw][co]   (weights of the dgrad convolution)
+__global__ void weight_flip_transpose_kernel(const float* __restrict__ W, float* __restrict__ Wd,
+                                             int Cout, int KH, int KW, int Cin) {
+  int total = Cout * KH * KW * Cin;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    // i indexes Wd: [ci][kh'][kw'][co]
+    int co = i % Cout;
+    int t = i / Cout;
+    int kw = t % KW;
+    t /= KW;
+    int kh = t % KH;
+    int ci = t / KH;
+    Wd[i] = W[((size_t)(co * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)) * Cin + ci];
+  }
+}
+
+// column sums of a [rows][C] matrix (row pitch ld): out[c] = sum_r x[r][c]  (bias grads)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                     long rows, int C, int ld) {
+  // block handles 64 columns x a slab of rows; threads: 64 columns x 4 row lanes
+  __shared__ float red[4][64];
+  int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  int rl = threadIdx.x >> 6;
+  long rows_per = (rows + gridDim.y - 1) / gridDim.y;
+  long r0 = (long)blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  float s = 0.f;
+  if (c < C)
+    for (long r = r0 + rl; r < r1; r += 4) s += x[r * ld + c];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+static int fill_geom(ConvGeom& g, int N, int H, int W, int Cin, int Cout, int KH, int KW, int padH,
+                     int padW) {
+  g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.KH = KH; g.KW = KW;
+  g.padH = padH; g.padW = padW;
+  g.OH = H + 2 * padH - KH + 1;
+  g.OW = W + 2 * padW - KW + 1;
+  g.Ktot = KH * KW * Cin;
+  long M = (long)N * g.OH * g.OW;
+  if (g.OH <= 0 || g.OW <= 0 || M <= 0 || M > 0x7fffffffL) return -1;
+  if ((long)N * H * W * Cin > 0x7fffffffL * 4L) return -1;
+  g.M = (int)M;
+  g.ldy = Cout; g.ldr = Cout;
+  return 0;
+}
+
+extern "C" int focr_conv2d_fwd(const float* x, const float* w, const float* bias,
+                               const float* residual, float* y, int N, int H, int W, int Cin,
+                               int Cout, int KH, int KW, int padH, int padW, float alpha, int relu,
+                               int ldy, int ldr, hipStream_t stream) {
+  ConvGeom g;
+  FOCR_CHECK_ARG(x && w && y, "null pointer");
+  FOCR_CHECK_ARG(fill_geom(g, N, H, W, Cin, Cout, KH, KW, padH, padW) == 0, "bad geometry");
+  if (ldy > 0) g.ldy = ldy;
+  if (ldr > 0) g.ldr = ldr;
+  FOCR_CHECK_ARG(g.ldy >= Cout && g.ldr >= Cout, "row pitch smaller than Cout");
+  bool vec = (Cin % BK == 0);
+  bool wide = Cout > 32;
+  dim3 grid(cdiv(g.M, BM), cdiv(Cout, wide ? 64 : 32));
+  if (vec && wide)
+    hipLaunchKernelGGL((conv_fwd_kernel<2, true>), grid, 256, 0, stream, x, w, bias, residual, y, g, alpha, relu);
+  else if (vec)
+    hipLaunchKernelGGL((conv_fwd_kernel<1, true>), grid, 256, 0, stream, x, w, bias, residual, y, g, alpha, relu);
+  else if (wide)
+    hipLaunchKernelGGL((conv_fwd_kernel<2, false>), grid, 256, 0, stream, x, w, bias, residual, y, g, alpha, relu);
+  else
+    hipLaunchKernelGGL((conv_fwd_kernel<1, false>), grid, 256, 0, stream, x, w, bias, residual, y, g, alpha, relu);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+
+// dw must hold Cout*KH*KW*Cin floats, dbias (nullable) Cout floats; both are overwritten.
+extern "C" int focr_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N,
+                                 int H, int W, int Cin, int Cout, int KH, int KW, int padH,
+                                 int padW, int ldd, hipStream_t stream) {
+  ConvGeom g;
+  FOCR_CHECK_ARG(x && dy && dw, "null pointer");
+  FOCR_CHECK_ARG(fill_geom(g, N, H, W, Cin, Cout, KH, KW, padH, padW) == 0, "bad geometry");
+  if (ldd <= 0) ldd = Cout;
+  FOCR_CHECK_ARG(ldd >= Cout, "row pitch smaller than Cout");
+  if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cout * g.Ktot, stream) != hipSuccess) {
+    focr_set_error("focr_conv2d_wgrad: memset failed");
+    return FOCR_EHIP;
+  }
+  bool vec = (Cin % 64 == 0) && (ldd % 4 == 0);
+  int tiles = cdiv(g.Ktot, 64) * cdiv(Cout, 64);
+  int splits = 2048 / tiles;
+  int maxsplits = cdiv(g.M, 128);
+  if (splits > maxsplits) splits = maxsplits;
+  if (splits < 1) splits = 1;
+  int pps = cdiv(cdiv(g.M, splits), 32) * 32;
+  splits = cdiv(g.M, pps);
+  dim3 grid(cdiv(g.Ktot, 64), cdiv(Cout, 64), splits);
+  if (vec)
+    hipLaunchKernelGGL((conv_wgrad_kernel<true>), grid, 256, 0, stream, x, dy, dw, g, ldd, pps);
+  else
+    hipLaunchKernelGGL((conv_wgrad_kernel<false>), grid, 256, 0, stream, x, dy, dw, g, ldd, pps);
+  FOCR_LAUNCH_CHECK();
+  if (dbias) {
+    if (hipMemsetAsync(dbias, 0, sizeof(float) * Cout, stream) != hipSuccess) {
+      focr_set_error("focr_conv2d_wgrad: memset failed");
+      return FOCR_EHIP;
+    }
+    int ry = cdiv(g.M, 512);
+    if (ry > 256) ry = 256;
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(Cout, 64), ry), 256, 0, stream, dy, dbias, (long)g.M, Cout, ldd);
+    FOCR_LAUNCH_CHECK();
+  }
+  return FOCR_OK;
+}
+
+extern "C" int focr_weight_flip_transpose(const float* w, float* wd, int Cout, int KH, int KW,
+                                          int Cin, hipStream_t stream) {
+  FOCR_CHECK_ARG(w && wd, "null pointer");
+  int total = Cout * KH * KW * Cin;
+  hipLaunchKernelGGL(weight_flip_transpose_kernel, dim3(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)), 256, 0,
+                     stream, w, wd, Cout, KH, KW, Cin);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+
+extern "C" int focr_colsum(const float* x, float* out, long rows, int C, int ld, hipStream_t stream) {
+  FOCR_CHECK_ARG(x && out && rows > 0 && C > 0, "bad argument");
+  if (ld <= 0) ld = C;
+  if (hipMemsetAsync(out, 0, sizeof(float) * C, stream) != hipSuccess) {
+    focr_set_error("focr_colsum: memset failed");
+    return FOCR_EHIP;
+  }
+  int ry = cdiv(rows, 512);
+  if (ry > 256) ry = 256;
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64), ry), 256, 0, stream, x, out, rows, C, ld);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}

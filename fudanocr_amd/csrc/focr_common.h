@@ -1,0 +1,69 @@
+// Shared helpers for the libfocr_hip C-ABI kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define FOCR_OK 0
+#define FOCR_EINVAL (-1)
+#define FOCR_EUNSUPPORTED (-2)
+#define FOCR_EHIP (-3)
+
+extern "C" void focr_set_error(const char* fmt, ...);
+
+#define FOCR_CHECK_ARG(cond, msg)                          \
+  do {                                                     \
+    if (!(cond)) {                                         \
+      focr_set_error("%s: %s", __func__, msg);             \
+      return FOCR_EINVAL;                                  \
+    }                                                      \
+  } while (0)
+
+#define FOCR_LAUNCH_CHECK()                                              \
+  do {                                                                   \
+    hipError_t e_ = hipGetLastError();                                   \
+    if (e_ != hipSuccess) {                                              \
+      focr_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e_)); \
+      return FOCR_EHIP;                                                  \
+    }                                                                    \
+  } while (0)
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// mish(x) = x * tanh(softplus(x)), softplus threshold 20 (reference tsrn.py:117-125)
+__device__ __forceinline__ float mish_f(float x) {
+  float sp = x > 20.f ? x : log1pf(expf(x));
+  return x * tanhf(sp);
+}
+// d mish / dx
+__device__ __forceinline__ float mish_grad_f(float x) {
+  float sp = x > 20.f ? x : log1pf(expf(x));
+  float t = tanhf(sp);
+  float sg = x > 20.f ? 1.f : 1.f / (1.f + expf(-x));   // d softplus / dx
+  return t + x * (1.f - t * t) * sg;
+}
+
+// counter-based RNG for dropout masks: one 32-bit draw per (seed, index); the same
+// function regenerates the mask in the backward kernels.
+__device__ __forceinline__ uint32_t rng_hash(uint64_t seed, uint64_t idx) {
+  uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}

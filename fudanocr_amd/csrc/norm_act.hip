@@ -1,0 +1,684 @@
+// Memory-bound kernels of the SR trunk: BatchNorm (train / eval, fwd / bwd, fused activation
+// and residual), the reference's own LayerNorm, PReLU, pixel-shuffle + mish, tanh + layout,
+// positional-encoding concat, dropout, MSE.  All tensors fp32, channel-last (NHWC); every
+// kernel is HBM-bound and uses 16-byte accesses where the layout allows.
+//
+// Reference semantics (scene-text-telescope/):
+//   BatchNorm2d/1d  torch semantics, SURVEY.md Appendix C   (model/tsrn.py:81-86, stn_head.py:17-21)
+//   LayerNorm       unbiased std, eps added to std          (model/tbsrn.py:23-36)
+//   mish            x*tanh(softplus(x)), threshold 20       (model/tsrn.py:117-125)
+//   PReLU           single learnable slope                  (model/tsrn.py:28)
+//   PixelShuffle(2) out[n,c,2h+i,2w+j] = in[n,4c+2i+j,h,w]  (model/tsrn.py:101-114)
+#include "focr_common.h"
+
+#define ACT_NONE 0
+#define ACT_RELU 1
+#define ACT_MISH 4
+
+__device__ __forceinline__ float act_fwd(float x, int act) {
+  if (act == ACT_RELU) return fmaxf(x, 0.f);
+  if (act == ACT_MISH) return mish_f(x);
+  return x;
+}
+__device__ __forceinline__ float act_grad(float x, int act) {
+  if (act == ACT_RELU) return x > 0.f ? 1.f : 0.f;
+  if (act == ACT_MISH) return mish_grad_f(x);
+  return 1.f;
+}
+
+// ---------------------------------------------------------------------------------------
+// column reductions over [rows][C] (C % 4 == 0 not required): block = 64 columns x 4 row lanes
+// mode 0: sum x          mode 1: sum (x - mean)^2, mean = sum0[c]/rows
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_colstat_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ sum0,
+                                                         float* __restrict__ out, long rows, int C,
+                                                         int mode) {
+  __shared__ float red[4][64];
+  int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  int rl = threadIdx.x >> 6;
+  long rows_per = (rows + gridDim.y - 1) / gridDim.y;
+  long r0 = (long)blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  float s = 0.f;
+  if (c < C) {
+    float mean = mode ? sum0[c] / (float)rows : 0.f;
+    for (long r = r0 + rl; r < r1; r += 4) {
+      float v = x[r * C + c] - mean;
+      s += mode ? v * v : v;
+    }
+  }
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    int t = threadIdx.x;
+    atomicAdd(&out[c], red[0][t] + red[1][t] + red[2][t] + red[3][t]);
+  }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sq,
+                                   float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                   float* __restrict__ rmean, float* __restrict__ rvar,
+                                   long long* nbt, long rows, int C, float momentum, float eps) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    float mean = sum[c] / (float)rows;
+    float var = sq[c] / (float)rows;
+    save_mean[c] = mean;
+    save_invstd[c] = rsqrtf(var + eps);
+    if (rmean) {
+      float unb = rows > 1 ? var * ((float)rows / (float)(rows - 1)) : var;
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+    }
+  }
+  if (c == 0 && nbt) *nbt += 1;
+}
+
+// y = act(gamma * (x - mean) * invstd + beta) + residual       (total = rows*C elements)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd,
+                                                       const float* __restrict__ res,
+                                                       float* __restrict__ y, long total4, int C,
+                                                       int act) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (long)gridDim.x * blockDim.x) {
+    int c = (int)((i * 4) % C);
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    float4 g = *reinterpret_cast<const float4*>(gamma + c);
+    float4 b = *reinterpret_cast<const float4*>(beta + c);
+    float4 mu = *reinterpret_cast<const float4*>(mean + c);
+    float4 is = *reinterpret_cast<const float4*>(invstd + c);
+    float4 o;
+    o.x = act_fwd(g.x * (v.x - mu.x) * is.x + b.x, act);
+    o.y = act_fwd(g.y * (v.y - mu.y) * is.y + b.y, act);
+    o.z = act_fwd(g.z * (v.z - mu.z) * is.z + b.z, act);
+    o.w = act_fwd(g.w * (v.w - mu.w) * is.w + b.w, act);
+    if (res) {
+      float4 r = reinterpret_cast<const float4*>(res)[i];
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    reinterpret_cast<float4*>(y)[i] = o;
+  }
+}
+
+// backward pass 1: sums[c] = sum g, sums[C + c] = sum g * xhat, g = dz * act'(gamma*xhat+beta)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ invstd,
+    float* __restrict__ sums, long rows, int C, int act) {
+  __shared__ float red[2][4][64];
+  int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  int rl = threadIdx.x >> 6;
+  long rows_per = (rows + gridDim.y - 1) / gridDim.y;
+  long r0 = (long)blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C) {
+    float g_ = gamma[c], b_ = beta[c], mu = mean[c], is = invstd[c];
+    for (long r = r0 + rl; r < r1; r += 4) {
+      float xh = (x[r * C + c] - mu) * is;
+      float g = dz[r * C + c] * act_grad(g_ * xh + b_, act);
+      s0 += g;
+      s1 += g * xh;
+    }
+  }
+  red[0][rl][threadIdx.x & 63] = s0;
+  red[1][rl][threadIdx.x & 63] = s1;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    int t = threadIdx.x;
+    atomicAdd(&sums[c], red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t]);
+    atomicAdd(&sums[C + c], red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t]);
+  }
+}
+
+// backward pass 2 (train): dx = gamma*invstd*(g - sum_g/rows - xhat*sum_gx/rows)
+//          (eval, sums == nullptr): dx = gamma*invstd*g
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ sums, float* __restrict__ dx, long total4, long rows, int C, int act) {
+  const float inv_rows = 1.f / (float)rows;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (long)gridDim.x * blockDim.x) {
+    int c = (int)((i * 4) % C);
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    float4 d = reinterpret_cast<const float4*>(dz)[i];
+    float vv[4] = {v.x, v.y, v.z, v.w}, dd[4] = {d.x, d.y, d.z, d.w}, oo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float g_ = gamma[c + e], is = invstd[c + e];
+      float xh = (vv[e] - mean[c + e]) * is;
+      float g = dd[e] * act_grad(g_ * xh + beta[c + e], act);
+      if (sums) g = g - sums[c + e] * inv_rows - xh * sums[C + c + e] * inv_rows;
+      oo[e] = g_ * is * g;
+    }
+    reinterpret_cast<float4*>(dx)[i] = make_float4(oo[0], oo[1], oo[2], oo[3]);
+  }
+}
+
+__global__ void bn_eval_prep_kernel(const float* __restrict__ rvar, float* __restrict__ invstd, int C,
+                                    float eps) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) invstd[c] = rsqrtf(rvar[c] + eps);
+}
+
+// ---------------------------------------------------------------------------------------
+// LayerNorm of the reference (unbiased std, eps on the std), D = 128, one wave per row
+// ---------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x,
+                                                     const float* __restrict__ res,
+                                                     const float* __restrict__ a,
+                                                     const float* __restrict__ b, float* __restrict__ y,
+                                                     float* __restrict__ save_mean,
+                                                     float* __restrict__ save_rinv, long rows, float eps) {
+  constexpr int E = D / 64;
+  const int lane = threadIdx.x & 63;
+  long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v[E];
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    v[e] = x[row * D + e * 64 + lane];
+    if (res) v[e] += res[row * D + e * 64 + lane];
+    s += v[e];
+  }
+  float mean = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    v[e] -= mean;
+    q += v[e] * v[e];
+  }
+  float sd = sqrtf(wave_sum(q) / (D - 1));
+  float rinv = 1.f / (sd + eps);
+#pragma unroll
+  for (int e = 0; e < E; ++e)
+    y[row * D + e * 64 + lane] = a[e * 64 + lane] * v[e] * rinv + b[e * 64 + lane];
+  if (lane == 0) {
+    save_mean[row] = mean;
+    save_rinv[row] = rinv;
+  }
+}
+
+// xin = x (+res) is recomputed from the same inputs.  dx is also the gradient of `res`.
+template <int D>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy,
+                                                     const float* __restrict__ x,
+                                                     const float* __restrict__ res,
+                                                     const float* __restrict__ a,
+                                                     const float* __restrict__ save_mean,
+                                                     const float* __restrict__ save_rinv,
+                                                     float* __restrict__ dx, float* __restrict__ da,
+                                                     float* __restrict__ db, long rows, float eps) {
+  constexpr int E = D / 64;
+  __shared__ float red[2][4][D];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float pa[E], pb[E], av[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) { pa[e] = 0.f; pb[e] = 0.f; av[e] = a[e * 64 + lane]; }
+  for (long row = (long)blockIdx.x * 4 + wv; row < rows; row += (long)gridDim.x * 4) {
+    float mean = save_mean[row], rinv = save_rinv[row];
+    float sd = 1.f / rinv - eps;
+    float u[E], dn[E];
+    float s_dn = 0.f, s_dnu = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      float xv = x[row * D + e * 64 + lane];
+      if (res) xv += res[row * D + e * 64 + lane];
+      u[e] = xv - mean;
+      float g = dy[row * D + e * 64 + lane];
+      pa[e] += g * u[e] * rinv;
+      pb[e] += g;
+      dn[e] = g * av[e];
+      s_dn += dn[e];
+      s_dnu += dn[e] * u[e];
+    }
+    s_dn = wave_sum(s_dn);
+    s_dnu = wave_sum(s_dnu);
+    float k = rinv * rinv * s_dnu / ((D - 1) * sd);
+    float mdn = rinv * s_dn / D;
+#pragma unroll
+    for (int e = 0; e < E; ++e) dx[row * D + e * 64 + lane] = dn[e] * rinv - k * u[e] - mdn;
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    red[0][wv][e * 64 + lane] = pa[e];
+    red[1][wv][e * 64 + lane] = pb[e];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < D; i += 256) {
+    atomicAdd(&da[i], red[0][0][i] + red[0][1][i] + red[0][2][i] + red[0][3][i]);
+    atomicAdd(&db[i], red[1][0][i] + red[1][1][i] + red[1][2][i] + red[1][3][i]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// PReLU with one shared slope
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prelu_fwd_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ slope,
+                                                        float* __restrict__ y, long n4) {
+  const float a = slope[0];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    v.x = v.x >= 0.f ? v.x : a * v.x;
+    v.y = v.y >= 0.f ? v.y : a * v.y;
+    v.z = v.z >= 0.f ? v.z : a * v.z;
+    v.w = v.w >= 0.f ? v.w : a * v.w;
+    reinterpret_cast<float4*>(y)[i] = v;
+  }
+}
+__global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict__ dy,
+                                                        const float* __restrict__ x,
+                                                        const float* __restrict__ slope,
+                                                        float* __restrict__ dx, float* __restrict__ dslope,
+                                                        long n4) {
+  __shared__ float red[4];
+  const float a = slope[0];
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    float4 d = reinterpret_cast<const float4*>(dy)[i];
+    float4 o;
+    o.x = v.x >= 0.f ? d.x : a * d.x;  acc += v.x >= 0.f ? 0.f : d.x * v.x;
+    o.y = v.y >= 0.f ? d.y : a * d.y;  acc += v.y >= 0.f ? 0.f : d.y * v.y;
+    o.z = v.z >= 0.f ? d.z : a * d.z;  acc += v.z >= 0.f ? 0.f : d.z * v.z;
+    o.w = v.w >= 0.f ? d.w : a * d.w;  acc += v.w >= 0.f ? 0.f : d.w * v.w;
+    reinterpret_cast<float4*>(dx)[i] = o;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(dslope, red[0] + red[1] + red[2] + red[3]);
+}
+
+// ---------------------------------------------------------------------------------------
+// pixel-shuffle(2) + mish:  pre [N,H,W,4C] -> z [N,2H,2W,C];  thread = (n,h,w,c)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pshuf_mish_fwd_kernel(const float* __restrict__ pre,
+                                                             float* __restrict__ z, long total, int H,
+                                                             int W, int C) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    long p = i / C;
+    int w = (int)(p % W);
+    long t = p / W;
+    int h = (int)(t % H);
+    long n = t / H;
+    float4 v = reinterpret_cast<const float4*>(pre)[i];
+    size_t o = (((size_t)n * 2 * H + 2 * h) * 2 * W + 2 * w) * C + c;
+    z[o] = mish_f(v.x);
+    z[o + C] = mish_f(v.y);
+    z[o + (size_t)2 * W * C] = mish_f(v.z);
+    z[o + (size_t)2 * W * C + C] = mish_f(v.w);
+  }
+}
+__global__ __launch_bounds__(256) void pshuf_mish_bwd_kernel(const float* __restrict__ dz,
+                                                             const float* __restrict__ pre,
+                                                             float* __restrict__ dpre, long total, int H,
+                                                             int W, int C) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    long p = i / C;
+    int w = (int)(p % W);
+    long t = p / W;
+    int h = (int)(t % H);
+    long n = t / H;
+    float4 v = reinterpret_cast<const float4*>(pre)[i];
+    size_t o = (((size_t)n * 2 * H + 2 * h) * 2 * W + 2 * w) * C + c;
+    float4 g;
+    g.x = dz[o] * mish_grad_f(v.x);
+    g.y = dz[o + C] * mish_grad_f(v.y);
+    g.z = dz[o + (size_t)2 * W * C] * mish_grad_f(v.z);
+    g.w = dz[o + (size_t)2 * W * C + C] * mish_grad_f(v.w);
+    reinterpret_cast<float4*>(dpre)[i] = g;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// layout / small elementwise
+// ---------------------------------------------------------------------------------------
+// y_nhwc[n,p,c] = x_nchw[n,c,p]
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, long total, int C,
+                                    int HW) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    long t = i / C;
+    int p = (int)(t % HW);
+    long n = t / HW;
+    y[i] = x[((size_t)n * C + c) * HW + p];
+  }
+}
+// y_nchw[n,c,p] = f(x_nhwc[n,p,c]),  f = tanh if do_tanh
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, long total, int C,
+                                    int HW, int do_tanh) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int p = (int)(i % HW);
+    long t = i / HW;
+    int c = (int)(t % C);
+    long n = t / C;
+    float v = x[((size_t)n * HW + p) * C + c];
+    y[i] = do_tanh ? tanhf(v) : v;
+  }
+}
+// dx_nhwc[n,p,c] = dy_nchw[n,c,p] * (1 - y_nchw^2)
+__global__ void tanh_bwd_to_nhwc_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                        float* __restrict__ dx, long total, int C, int HW) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    long t = i / C;
+    int p = (int)(t % HW);
+    long n = t / HW;
+    size_t j = ((size_t)n * C + c) * HW + p;
+    float yy = y[j];
+    dx[i] = dy[j] * (1.f - yy * yy);
+  }
+}
+
+// tok[r, 0:Cf] = feat[r,:], tok[r, Cf:Cf+Cp] = pe[r % T, :]      (float4 granularity)
+__global__ __launch_bounds__(256) void concat_pe_kernel(const float* __restrict__ feat,
+                                                        const float* __restrict__ pe,
+                                                        float* __restrict__ tok, long total4, int Cf,
+                                                        int Cp, int T) {
+  const int D4 = (Cf + Cp) / 4, Cf4 = Cf / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    int c4 = (int)(i % D4);
+    long r = i / D4;
+    float4 v;
+    if (c4 < Cf4) v = reinterpret_cast<const float4*>(feat)[r * Cf4 + c4];
+    else v = reinterpret_cast<const float4*>(pe)[(r % T) * (Cp / 4) + (c4 - Cf4)];
+    reinterpret_cast<float4*>(tok)[i] = v;
+  }
+}
+// out[r, 0:w] = x[r, c0:c0+w]  (+ add[r,0:w] if add)      all multiples of 4
+__global__ __launch_bounds__(256) void slice_cols_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ add,
+                                                         float* __restrict__ out, long total4, int ld,
+                                                         int c0, int w) {
+  const int w4 = w / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    int c4 = (int)(i % w4);
+    long r = i / w4;
+    float4 v = *reinterpret_cast<const float4*>(x + r * ld + c0 + c4 * 4);
+    if (add) {
+      float4 a = reinterpret_cast<const float4*>(add)[i];
+      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = v;
+  }
+}
+
+// y = keep ? x / (1-p) : 0, mask from rng_hash(seed, element index)
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                      long n, float p, uint64_t seed) {
+  const uint32_t thr = (uint32_t)(p * 4294967296.0);
+  const float ik = 1.f / (1.f - p);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = rng_hash(seed, (uint64_t)i) >= thr ? x[i] * ik : 0.f;
+}
+
+// out[0] += scale * sum (a-b)^2
+__global__ __launch_bounds__(256) void mse_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      float* __restrict__ out, long n, float scale) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float d = a[i] - b[i];
+    acc += d * d;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1] + red[2] + red[3]) * scale);
+}
+// da = upstream[0] * 2 (a-b) / n
+__global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      const float* __restrict__ upstream,
+                                                      float* __restrict__ da, long n) {
+  const float k = upstream[0] * 2.f / (float)n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    da[i] = k * (a[i] - b[i]);
+}
+// y = alpha * x + (add ? add : 0)   (generic axpby used for small glue)
+__global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ x, const float* __restrict__ add,
+                                                   float* __restrict__ y, long n, float alpha) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = alpha * x[i] + (add ? add[i] : 0.f);
+}
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+static inline int ew_grid(long n) {
+  long g = (n + 255) / 256;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+static inline int row_slabs(long rows) {
+  long s = (rows + 255) / 256;
+  if (s > 512) s = 512;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+#define MEMSET0(ptr, bytes)                                                   \
+  do {                                                                        \
+    if (hipMemsetAsync((ptr), 0, (bytes), stream) != hipSuccess) {            \
+      focr_set_error("%s: memset failed", __func__);                          \
+      return FOCR_EHIP;                                                       \
+    }                                                                         \
+  } while (0)
+
+// ws: 2*C floats of scratch.  running_mean/var/nbt may be null (no running update).
+extern "C" int focr_bn_train_fwd(const float* x, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, long long* nbt,
+                                 const float* residual, float* y, float* save_mean,
+                                 float* save_invstd, float* ws, long rows, int C, float momentum,
+                                 float eps, int act, hipStream_t stream) {
+  FOCR_CHECK_ARG(x && gamma && beta && y && save_mean && save_invstd && ws, "null pointer");
+  FOCR_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0, "need C % 4 == 0");
+  MEMSET0(ws, sizeof(float) * 2 * C);
+  dim3 g(cdiv(C, 64), row_slabs(rows));
+  hipLaunchKernelGGL(bn_colstat_kernel, g, 256, 0, stream, x, (const float*)nullptr, ws, rows, C, 0);
+  hipLaunchKernelGGL(bn_colstat_kernel, g, 256, 0, stream, x, (const float*)ws, ws + C, rows, C, 1);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), 64, 0, stream, (const float*)ws,
+                     (const float*)(ws + C), save_mean, save_invstd, running_mean, running_var, nbt, rows, C,
+                     momentum, eps);
+  long total4 = rows * C / 4;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total4)), 256, 0, stream, x, gamma, beta,
+                     (const float*)save_mean, (const float*)save_invstd, residual, y, total4, C, act);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+
+// eval: normalise with running stats; invstd_out: C floats (kept for the backward)
+extern "C" int focr_bn_eval_fwd(const float* x, const float* gamma, const float* beta,
+                                const float* running_mean, const float* running_var,
+                                const float* residual, float* y, float* invstd_out, long rows, int C,
+                                float eps, int act, hipStream_t stream) {
+  FOCR_CHECK_ARG(x && gamma && beta && running_mean && running_var && y && invstd_out, "null pointer");
+  FOCR_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0, "need C % 4 == 0");
+  hipLaunchKernelGGL(bn_eval_prep_kernel, dim3(cdiv(C, 64)), 64, 0, stream, running_var, invstd_out, C, eps);
+  long total4 = rows * C / 4;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total4)), 256, 0, stream, x, gamma, beta, running_mean,
+                     (const float*)invstd_out, residual, y, total4, C, act);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+
+// train-mode backward.  dgamma/dbeta: C floats each (overwritten); ws: 2*C floats.
+// train == 0: eval-mode backward (mean = running_mean, no batch-statistics terms, no dgamma).
+extern "C" int focr_bn_bwd(const float* dz, const float* x, const float* gamma, const float* beta,
+                           const float* mean, const float* invstd, float* dx, float* dgamma,
+                           float* dbeta, float* ws, long rows, int C, int act, int train,
+                           hipStream_t stream) {
+  FOCR_CHECK_ARG(dz && x && gamma && beta && mean && invstd && dx, "null pointer");
+  FOCR_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0, "need C % 4 == 0");
+  long total4 = rows * C / 4;
+  if (train) {
+    FOCR_CHECK_ARG(ws && dgamma && dbeta, "null pointer");
+    MEMSET0(ws, sizeof(float) * 2 * C);
+    dim3 g(cdiv(C, 64), row_slabs(rows));
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, g, 256, 0, stream, dz, x, gamma, beta, mean, invstd, ws, rows, C, act);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), 256, 0, stream, dz, x, gamma, beta, mean,
+                       invstd, (const float*)ws, dx, total4, rows, C, act);
+    if (hipMemcpyAsync(dbeta, ws, sizeof(float) * C, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
+        hipMemcpyAsync(dgamma, ws + C, sizeof(float) * C, hipMemcpyDeviceToDevice, stream) != hipSuccess) {
+      focr_set_error("focr_bn_bwd: memcpy failed");
+      return FOCR_EHIP;
+    }
+  } else {
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), 256, 0, stream, dz, x, gamma, beta, mean,
+                       invstd, (const float*)nullptr, dx, total4, rows, C, act);
+  }
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+
+extern "C" int focr_layernorm_fwd(const float* x, const float* residual, const float* a,
+                                  const float* b, float* y, float* save_mean, float* save_rinv,
+                                  long rows, int D, float eps, hipStream_t stream) {
+  FOCR_CHECK_ARG(x && a && b && y && save_mean && save_rinv, "null pointer");
+  FOCR_CHECK_ARG(D == 128 && rows > 0, "only D == 128 is built");
+  hipLaunchKernelGGL((ln_fwd_kernel<128>), dim3(cdiv(rows, 4)), 256, 0, stream, x, residual, a, b, y,
+                     save_mean, save_rinv, rows, eps);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+
+extern "C" int focr_layernorm_bwd(const float* dy, const float* x, const float* residual,
+                                  const float* a, const float* save_mean, const float* save_rinv,
+                                  float* dx, float* da, float* db, long rows, int D, float eps,
+                                  hipStream_t stream) {
+  FOCR_CHECK_ARG(dy && x && a && save_mean && save_rinv && dx && da && db, "null pointer");
+  FOCR_CHECK_ARG(D == 128 && rows > 0, "only D == 128 is built");
+  MEMSET0(da, sizeof(float) * D);
+  MEMSET0(db, sizeof(float) * D);
+  long g = cdiv(rows, 4);
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL((ln_bwd_kernel<128>), dim3((int)g), 256, 0, stream, dy, x, residual, a, save_mean,
+                     save_rinv, dx, da, db, rows, eps);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+
+extern "C" int focr_prelu_fwd(const float* x, const float* slope, float* y, long n, hipStream_t stream) {
+  FOCR_CHECK_ARG(x && slope && y && n > 0 && n % 4 == 0, "need n % 4 == 0");
+  hipLaunchKernelGGL(prelu_fwd_kernel, dim3(ew_grid(n / 4)), 256, 0, stream, x, slope, y, n / 4);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+extern "C" int focr_prelu_bwd(const float* dy, const float* x, const float* slope, float* dx,
+                              float* dslope, long n, hipStream_t stream) {
+  FOCR_CHECK_ARG(dy && x && slope && dx && dslope && n > 0 && n % 4 == 0, "need n % 4 == 0");
+  MEMSET0(dslope, sizeof(float));
+  hipLaunchKernelGGL(prelu_bwd_kernel, dim3(ew_grid(n / 4)), 256, 0, stream, dy, x, slope, dx, dslope, n / 4);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+
+// pre [N,H,W,4C] -> z [N,2H,2W,C]
+extern "C" int focr_pixelshuffle_mish_fwd(const float* pre, float* z, int N, int H, int W, int C,
+                                          hipStream_t stream) {
+  FOCR_CHECK_ARG(pre && z && N > 0 && H > 0 && W > 0 && C > 0, "bad argument");
+  long total = (long)N * H * W * C;
+  hipLaunchKernelGGL(pshuf_mish_fwd_kernel, dim3(ew_grid(total)), 256, 0, stream, pre, z, total, H, W, C);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+extern "C" int focr_pixelshuffle_mish_bwd(const float* dz, const float* pre, float* dpre, int N, int H,
+                                          int W, int C, hipStream_t stream) {
+  FOCR_CHECK_ARG(dz && pre && dpre && N > 0 && H > 0 && W > 0 && C > 0, "bad argument");
+  long total = (long)N * H * W * C;
+  hipLaunchKernelGGL(pshuf_mish_bwd_kernel, dim3(ew_grid(total)), 256, 0, stream, dz, pre, dpre, total, H, W, C);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+
+extern "C" int focr_nchw_to_nhwc(const float* x, float* y, int N, int C, int HW, hipStream_t stream) {
+  FOCR_CHECK_ARG(x && y && N > 0 && C > 0 && HW > 0, "bad argument");
+  long total = (long)N * C * HW;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_grid(total)), 256, 0, stream, x, y, total, C, HW);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+extern "C" int focr_nhwc_to_nchw(const float* x, float* y, int N, int C, int HW, int do_tanh,
+                                 hipStream_t stream) {
+  FOCR_CHECK_ARG(x && y && N > 0 && C > 0 && HW > 0, "bad argument");
+  long total = (long)N * C * HW;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_grid(total)), 256, 0, stream, x, y, total, C, HW, do_tanh);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+extern "C" int focr_tanh_bwd_to_nhwc(const float* dy_nchw, const float* y_nchw, float* dx_nhwc, int N,
+                                     int C, int HW, hipStream_t stream) {
+  FOCR_CHECK_ARG(dy_nchw && y_nchw && dx_nhwc && N > 0 && C > 0 && HW > 0, "bad argument");
+  long total = (long)N * C * HW;
+  hipLaunchKernelGGL(tanh_bwd_to_nhwc_kernel, dim3(ew_grid(total)), 256, 0, stream, dy_nchw, y_nchw, dx_nhwc,
+                     total, C, HW);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+
+extern "C" int focr_concat_pe(const float* feat, const float* pe, float* tok, long rows, int Cf, int Cp,
+                              int T, hipStream_t stream) {
+  FOCR_CHECK_ARG(feat && pe && tok && rows > 0 && Cf % 4 == 0 && Cp % 4 == 0 && T > 0, "bad argument");
+  long total4 = rows * (Cf + Cp) / 4;
+  hipLaunchKernelGGL(concat_pe_kernel, dim3(ew_grid(total4)), 256, 0, stream, feat, pe, tok, total4, Cf, Cp, T);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+extern "C" int focr_slice_cols(const float* x, const float* add, float* out, long rows, int ld, int c0,
+                               int w, hipStream_t stream) {
+  FOCR_CHECK_ARG(x && out && rows > 0 && ld % 4 == 0 && c0 % 4 == 0 && w % 4 == 0 && c0 + w <= ld, "bad argument");
+  long total4 = rows * w / 4;
+  hipLaunchKernelGGL(slice_cols_kernel, dim3(ew_grid(total4)), 256, 0, stream, x, add, out, total4, ld, c0, w);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+extern "C" int focr_dropout(const float* x, float* y, long n, float p, uint64_t seed, hipStream_t stream) {
+  FOCR_CHECK_ARG(x && y && n > 0 && p >= 0.f && p < 1.f, "bad argument");
+  hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n)), 256, 0, stream, x, y, n, p, seed);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+// out (1 float, overwritten) = mean (a-b)^2
+extern "C" int focr_mse_fwd(const float* a, const float* b, float* out, long n, hipStream_t stream) {
+  FOCR_CHECK_ARG(a && b && out && n > 0, "bad argument");
+  MEMSET0(out, sizeof(float));
+  hipLaunchKernelGGL(mse_fwd_kernel, dim3(ew_grid(n) > 256 ? 256 : ew_grid(n)), 256, 0, stream, a, b, out, n,
+                     1.f / (float)n);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+extern "C" int focr_mse_bwd(const float* a, const float* b, const float* upstream, float* da, long n,
+                            hipStream_t stream) {
+  FOCR_CHECK_ARG(a && b && upstream && da && n > 0, "bad argument");
+  hipLaunchKernelGGL(mse_bwd_kernel, dim3(ew_grid(n)), 256, 0, stream, a, b, upstream, da, n);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+extern "C" int focr_axpy(const float* x, const float* add, float* y, long n, float alpha, hipStream_t stream) {
+  FOCR_CHECK_ARG(x && y && n > 0, "bad argument");
+  hipLaunchKernelGGL(axpy_kernel, dim3(ew_grid(n)), 256, 0, stream, x, add, y, n, alpha);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+
+// dx = dy * (y > 0)      (backward of a ReLU fused into a GEMM/conv epilogue)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                       float* __restrict__ dx, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+extern "C" int focr_relu_bwd(const float* dy, const float* y, float* dx, long n, hipStream_t stream) {
+  FOCR_CHECK_ARG(dy && y && dx && n > 0, "bad argument");
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n)), 256, 0, stream, dy, y, dx, n);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}

@@ -1,0 +1,75 @@
+// Fused optimiser tail of the training step (interfaces/super_resolution.py:83-84,
+// interfaces/base.py:194-198): torch.nn.utils.clip_grad_norm_(params, 0.25) followed by
+// Adam(lr, betas=(beta1, 0.999), eps 1e-8, bias-corrected) on ONE flat fp32 buffer (the same
+// buffer the data-parallel all-reduce runs on).  The clip coefficient is computed on the device
+// from the squared-norm accumulator: no host synchronisation anywhere in the step.
+// HBM-bound: reads g,p,m,v, writes p,m,v = 28 B per parameter.
+#include "focr_common.h"
+
+// out[0] += sum (gscale*g)^2     (gscale = 1/world for data-parallel gradient averaging)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, float* __restrict__ out, long n4,
+                                                    long n, float gscale) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 v = reinterpret_cast<const float4*>(g)[i];
+    acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0)
+    for (long i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) acc += g[i] * g[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1] + red[2] + red[3]) * gscale * gscale);
+}
+
+__global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v,
+                                                        const float* __restrict__ sumsq, long n, float lr,
+                                                        float b1, float b2, float eps, float c1, float c2s,
+                                                        float max_norm, float gscale) {
+  // clip_grad_norm_: coef = max_norm / (norm + 1e-6), applied only when < 1
+  float norm = sqrtf(sumsq[0]);
+  float coef = max_norm > 0.f ? fminf(max_norm / (norm + 1e-6f), 1.f) : 1.f;
+  const float k = coef * gscale;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i] * k;
+    float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    // torch: denom = sqrt(v)/sqrt(1-b2^t) + eps ; p -= lr/(1-b1^t) * m/denom
+    p[i] -= (lr / c1) * mi / (sqrtf(vi) / c2s + eps);
+  }
+}
+
+// sumsq: 1 float of workspace, overwritten with the squared (averaged) gradient norm.
+extern "C" int focr_grad_sumsq(const float* g, float* sumsq, long n, float gscale, hipStream_t stream) {
+  FOCR_CHECK_ARG(g && sumsq && n > 0, "bad argument");
+  if (hipMemsetAsync(sumsq, 0, sizeof(float), stream) != hipSuccess) {
+    focr_set_error("focr_grad_sumsq: memset failed");
+    return FOCR_EHIP;
+  }
+  long n4 = n / 4;
+  long gsz = (n4 + 255) / 256;
+  if (gsz > 1024) gsz = 1024;
+  if (gsz < 1) gsz = 1;
+  hipLaunchKernelGGL(sumsq_kernel, dim3((int)gsz), 256, 0, stream, g, sumsq, n4, n, gscale);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+
+// step: 1-based Adam step count.  max_norm <= 0 disables clipping.
+extern "C" int focr_clip_adam(float* p, const float* g, float* m, float* v, const float* sumsq, long n,
+                              float lr, float beta1, float beta2, float eps, int step, float max_norm,
+                              float gscale, hipStream_t stream) {
+  FOCR_CHECK_ARG(p && g && m && v && sumsq && n > 0 && step >= 1, "bad argument");
+  float c1 = 1.f - powf(beta1, (float)step);
+  float c2s = sqrtf(1.f - powf(beta2, (float)step));
+  long gsz = (n + 255) / 256;
+  if (gsz > 2048) gsz = 2048;
+  hipLaunchKernelGGL(clip_adam_kernel, dim3((int)gsz), 256, 0, stream, p, g, m, v, sumsq, n, lr, beta1, beta2, eps,
+                     c1, c2s, max_norm, gscale);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}

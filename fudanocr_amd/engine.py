@@ -1,0 +1,119 @@
+"""Optimisation-step engine: the reference's train-step tail
+(interfaces/super_resolution.py:79-84: loss*100 -> backward -> clip_grad_norm_(0.25) -> Adam)
+restated for one process per GPU.
+
+* All trainable parameters live in ONE flat fp32 buffer (parameters become strided views of it,
+  keeping their state_dict shapes), their gradients in a second one.  Dead parameters
+   simply keep a zero gradient: with zero first/second moments Adam leaves
+  them untouched, exactly like torch skipping `grad is None`.
+* Data parallel (replaces nn.DataParallel, base.py:178-179): the flat gradient buffer is
+  all-reduced (RCCL via torch.distributed, SUM) in a few large buckets; the 1/world averaging is
+  folded into the fused norm / clip+Adam kernels.  BatchNorm statistics stay per shard, as in
+  DataParallel.  No parameter broadcast per step: replicas apply identical averaged gradients.
+* clip + Adam: two HIP kernels over the flat buffers, clip coefficient computed on the device,
+  no host synchronisation in the step.
+"""
+import torch
+import torch.distributed as dist
+
+from . import kernels as K
+
+
+def _physical(p):
+    """(shape, permutation) such that p.permute(perm) is contiguous (dense tensors only)."""
+    order = sorted(range(p.dim()), key=lambda d: (-p.stride(d), d))
+    return [p.shape[d] for d in order], order
+
+
+class FlatBuffers:
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        dev = self.params[0].device
+        self.offsets, total = [], 0
+        for p in self.params:
+            self.offsets.append(total)
+            total += (p.numel() + 3) // 4 * 4              # keep every slice 16-byte aligned
+        self.numel = total
+        self.flat_param = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.flat_grad = torch.zeros(total, device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            for p, off in zip(self.params, self.offsets):
+                shape, order = _physical(p)
+                inv = [order.index(d) for d in range(p.dim())]
+                view = self.flat_param[off:off + p.numel()].view(shape).permute(inv) if p.dim() else \
+                    self.flat_param[off:off + 1].view(())
+                view.copy_(p.data)
+                p.data = view
+                g = self.flat_grad[off:off + p.numel()].view(shape).permute(inv) if p.dim() else \
+                    self.flat_grad[off:off + 1].view(())
+                p.grad = g
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+        for p, off in zip(self.params, self.offsets):      # re-attach if something reset .grad
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
+                shape, order = _physical(p)
+                inv = [order.index(d) for d in range(p.dim())]
+                p.grad = self.flat_grad[off:off + p.numel()].view(shape).permute(inv) if p.dim() else \
+                    self.flat_grad[off:off + 1].view(())
+
+
+class FusedClipAdam:
+    """clip_grad_norm_(max_norm) + Adam on flat buffers (HIP on CUDA tensors).  `world` folds the
+    data-parallel averaging into the kernels."""
+
+    def __init__(self, flat, lr=1e-4, betas=(0.5, 0.999), eps=1e-8, max_norm=0.25):
+        self.flat, self.lr, self.betas, self.eps, self.max_norm = flat, lr, betas, eps, max_norm
+        self.m = torch.zeros_like(flat.flat_param)
+        self.v = torch.zeros_like(flat.flat_param)
+        self.sumsq = torch.zeros(1, device=flat.flat_param.device)
+        self.t = 0
+
+    def step(self, world=1):
+        self.t += 1
+        g = 1.0 / world
+        K.grad_sumsq(self.flat.flat_grad, self.sumsq, g)
+        K.clip_adam(self.flat.flat_param, self.flat.flat_grad, self.m, self.v, self.sumsq, self.lr,
+                    self.betas[0], self.betas[1], self.eps, self.t, self.max_norm, g)
+
+    def grad_norm(self):
+        return self.sumsq.sqrt()
+
+
+class TrainStep:
+    """model: SR net (TBSRN/TSRN); crit: CTCFocusLoss.  One call = one optimisation step."""
+
+    def __init__(self, model, crit, lr=1e-4, betas=(0.5, 0.999), max_norm=0.25, process_group=None,
+                 n_buckets=4, dropout=True):
+        self.model, self.crit = model, crit
+        self.dropout = dropout        # False: nn.Dropout slots stay in eval (parity runs)
+        self.flat = FlatBuffers(list(model.parameters()))
+        self.opt = FusedClipAdam(self.flat, lr, betas, 1e-8, max_norm)
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        n = self.flat.numel
+        edges = [n * i // n_buckets // 4 * 4 for i in range(n_buckets)] + [n]
+        self.buckets = [(edges[i], edges[i + 1]) for i in range(n_buckets) if edges[i + 1] > edges[i]]
+
+    def allreduce_grads(self):
+        if self.world == 1:
+            return
+        works = [dist.all_reduce(self.flat.flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                 for a, b in self.buckets]
+        for w in works:
+            w.wait()
+
+    def __call__(self, images_lr, images_hr, label_strs=None, encoded=None):
+        self.model.train()
+        if not self.dropout:
+            for m in self.model.modules():
+                if isinstance(m, torch.nn.Dropout):
+                    m.eval()
+        self.flat.zero_grad()
+        sr = self.model(images_lr)
+        loss, mse, _, ctc = self.crit(sr, images_hr, label_strs, encoded)
+        (loss * 100).backward()
+        self.allreduce_grads()
+        self.opt.step(self.world)
+        return {"loss": loss.detach(), "mse": mse.detach(),
+                "ctc": ctc.detach() if torch.is_tensor(ctc) else None, "sr": sr.detach()}

@@ -1,0 +1,604 @@
+"""torch.autograd.Function wrappers over the C-ABI HIP library (include/focr.h).
+
+PyTorch is plumbing here: it owns device memory (caching allocator), the stream and the
+autograd tape; every arithmetic op of the path runs in a hand-written gfx950 kernel.
+Internal activation layout is channel-last: [N,H,W,C] / [rows,C], fp32, contiguous.
+Convolution weights are `[Cout,Cin,KH,KW]` tensors held in channels_last memory format,
+i.e. physically [Cout][KH][KW][Cin] -- exactly the K-contiguous operand the implicit-GEMM
+kernel wants, with the reference's state_dict shapes unchanged.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_MISH = 0, 1, 4
+_NULL = ctypes.c_void_p(0)
+
+
+def _p(t):
+    return _NULL if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError("fudanocr_amd kernel needs a contiguous fp32 CUDA tensor, got %s %s %s"
+                               % (t.device, t.dtype, tuple(t.stride())))
+
+
+def _ohwi(w):
+    """[Cout,Cin,KH,KW] parameter -> physically-OHWI flat storage (no copy when the parameter
+    is already channels_last)."""
+    if w.dim() == 2:
+        return w if w.is_contiguous() else w.contiguous()
+    v = w.permute(0, 2, 3, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+def _new_seed():
+    return int(torch.randint(0, 2 ** 62, (1,), device="cpu").item())
+
+
+# ----------------------------------------------------------------------------------------
+# convolution / linear
+# ----------------------------------------------------------------------------------------
+def _conv_fwd_raw(x4, w_ohwi, bias, residual, cout, kh, kw, ph, pw, alpha, relu):
+    n, h, w, cin = x4.shape
+    oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
+    y = torch.empty((n, oh, ow, cout), device=x4.device, dtype=torch.float32)
+    _lib.call("focr_conv2d_fwd", _p(x4), _p(w_ohwi), _p(bias), _p(residual), _p(y), n, h, w, cin, cout,
+              kh, kw, ph, pw, float(alpha), int(relu), 0, 0, _stream())
+    return y
+
+
+class _Conv2d(torch.autograd.Function):
+    """y = [relu](alpha * conv(x, w) + bias [+ residual]); x,y NHWC.  Reference: nn.Conv2d /
+    nn.Linear call sites listed in csrc/conv_igemm.hip."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, pad, alpha, relu):
+        cout = weight.shape[0]
+        if weight.dim() == 2:
+            kh = kw = 1
+            ph = pw = 0
+        else:
+            kh, kw = weight.shape[2], weight.shape[3]
+            ph, pw = pad
+        ctx.x_shape = tuple(x.shape)
+        lead = x.shape[:-1]
+        x4 = x if x.dim() == 4 else x.reshape(-1, 1, 1, x.shape[-1])
+        res4 = None if residual is None else residual.reshape(-1, cout)
+        wk = _ohwi(weight)
+        _chk(x4, wk, bias, res4)
+        y = _conv_fwd_raw(x4, wk, bias, res4, cout, kh, kw, ph, pw, alpha, relu)
+        ctx.geom = (kh, kw, ph, pw, float(alpha), bool(relu), bias is not None, residual is not None)
+        ctx.save_for_backward(x4, weight, y if relu else None)
+        return y if x.dim() == 4 else y.reshape(*lead, cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x4, weight, y = ctx.saved_tensors
+        kh, kw, ph, pw, alpha, relu, has_bias, has_res = ctx.geom
+        n, h, w, cin = x4.shape
+        cout = weight.shape[0]
+        oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
+        dy4 = dy.contiguous().reshape(n, oh, ow, cout)
+        if relu:
+            g = torch.empty_like(dy4)
+            _lib.call("focr_relu_bwd", _p(dy4), _p(y), _p(g), dy4.numel(), _stream())
+            dy4 = g
+        dres = dy4.reshape(dy.shape) if has_res else None
+        wk = _ohwi(weight)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wd = torch.empty(wk.numel(), device=dy.device, dtype=torch.float32)
+            _lib.call("focr_weight_flip_transpose", _p(wk), _p(wd), cout, kh, kw, cin, _stream())
+            dx4 = _conv_fwd_raw(dy4, wd, None, None, cin, kh, kw, kh - 1 - ph, kw - 1 - pw, alpha, False)
+            dx = dx4 if len(ctx.x_shape) == 4 else dx4.reshape(ctx.x_shape)
+        if ctx.needs_input_grad[1]:
+            if weight.dim() == 2:
+                dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+            else:   # logical [Cout,Cin,KH,KW] view of the physically-OHWI buffer the kernel fills
+                dw = torch.empty((cout, kh, kw, cin), device=dy.device).permute(0, 3, 1, 2)
+            need_db = has_bias and ctx.needs_input_grad[2]
+            if need_db:
+                db = torch.empty(cout, device=dy.device, dtype=torch.float32)
+            _lib.call("focr_conv2d_wgrad", _p(x4), _p(dy4), _p(dw), _p(db), n, h, w, cin, cout, kh, kw, ph,
+                      pw, 0, _stream())
+            if alpha != 1.0:
+                _lib.call("focr_axpy", _p(dw), _NULL, _p(dw), dw.numel(), alpha, _stream())
+        elif has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(cout, device=dy.device, dtype=torch.float32)
+            _lib.call("focr_colsum", _p(dy4), _p(db), dy4.numel() // cout, cout, cout, _stream())
+        return dx, dw, db, dres, None, None, None
+
+
+def conv2d(x, weight, bias=None, pad=(0, 0), residual=None, alpha=1.0, relu=False):
+    return _Conv2d.apply(x, weight, bias, residual, pad, alpha, relu)
+
+
+def linear(x, weight, bias=None, residual=None, alpha=1.0, relu=False):
+    """x [..., In] @ weight[Out, In]^T (+bias) (+residual) -- the same implicit-GEMM kernel."""
+    return _Conv2d.apply(x, weight, bias, residual, (0, 0), alpha, relu)
+
+
+# ----------------------------------------------------------------------------------------
+# batch norm (+activation, +residual)
+# ----------------------------------------------------------------------------------------
+class _BatchNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, nbt, residual, training, act, momentum, eps):
+        c = x.shape[-1]
+        rows = x.numel() // c
+        _chk(x, gamma, beta, rmean, rvar, residual)
+        y = torch.empty_like(x)
+        if training:
+            mean = torch.empty(c, device=x.device)
+            invstd = torch.empty(c, device=x.device)
+            ws = torch.empty(2 * c, device=x.device)
+            _lib.call("focr_bn_train_fwd", _p(x), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(nbt),
+                      _p(residual), _p(y), _p(mean), _p(invstd), _p(ws), rows, c, float(momentum), float(eps),
+                      act, _stream())
+        else:
+            mean = rmean
+            invstd = torch.empty(c, device=x.device)
+            _lib.call("focr_bn_eval_fwd", _p(x), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(residual), _p(y),
+                      _p(invstd), rows, c, float(eps), act, _stream())
+        ctx.cfg = (rows, c, act, bool(training), residual is not None)
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        rows, c, act, training, has_res = ctx.cfg
+        dz = dz.contiguous()
+        dx = torch.empty_like(x)
+        dg = db = None
+        if training:
+            dg = torch.empty(c, device=x.device)
+            db = torch.empty(c, device=x.device)
+            ws = torch.empty(2 * c, device=x.device)
+            _lib.call("focr_bn_bwd", _p(dz), _p(x), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(dx), _p(dg),
+                      _p(db), _p(ws), rows, c, act, 1, _stream())
+        else:
+            _lib.call("focr_bn_bwd", _p(dz), _p(x), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(dx), _NULL,
+                      _NULL, _NULL, rows, c, act, 0, _stream())
+        return dx, dg, db, None, None, None, (dz if has_res else None), None, None, None, None
+
+
+def batchnorm_act(x, gamma, beta, rmean, rvar, nbt, training, act=ACT_NONE, residual=None,
+                  momentum=0.1, eps=1e-5):
+    return _BatchNormAct.apply(x, gamma, beta, rmean, rvar, nbt, residual, training, act, momentum, eps)
+
+
+# ----------------------------------------------------------------------------------------
+# the reference's LayerNorm (unbiased std, eps on std), fused residual add
+# ----------------------------------------------------------------------------------------
+class _LayerNormStd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, a, b, eps):
+        d = x.shape[-1]
+        rows = x.numel() // d
+        _chk(x, residual, a, b)
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, device=x.device)
+        rinv = torch.empty(rows, device=x.device)
+        _lib.call("focr_layernorm_fwd", _p(x), _p(residual), _p(a), _p(b), _p(y), _p(mean), _p(rinv), rows, d,
+                  float(eps), _stream())
+        ctx.cfg = (rows, d, float(eps), residual is not None)
+        ctx.save_for_backward(x, residual, a, mean, rinv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, residual, a, mean, rinv = ctx.saved_tensors
+        rows, d, eps, has_res = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        da = torch.empty(d, device=x.device)
+        db = torch.empty(d, device=x.device)
+        _lib.call("focr_layernorm_bwd", _p(dy), _p(x), _p(residual), _p(a), _p(mean), _p(rinv), _p(dx), _p(da),
+                  _p(db), rows, d, eps, _stream())
+        return dx, (dx if has_res else None), da, db, None
+
+
+def layernorm_std(x, a, b, residual=None, eps=1e-6):
+    return _LayerNormStd.apply(x, residual, a, b, eps)
+
+
+# ----------------------------------------------------------------------------------------
+# PReLU / pixel-shuffle+mish / layout + tanh
+# ----------------------------------------------------------------------------------------
+class _PReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, slope):
+        _chk(x, slope)
+        y = torch.empty_like(x)
+        _lib.call("focr_prelu_fwd", _p(x), _p(slope), _p(y), x.numel(), _stream())
+        ctx.save_for_backward(x, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, slope = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        ds = torch.empty(1, device=x.device)
+        _lib.call("focr_prelu_bwd", _p(dy), _p(x), _p(slope), _p(dx), _p(ds), x.numel(), _stream())
+        return dx, ds
+
+
+def prelu(x, slope):
+    return _PReLU.apply(x, slope)
+
+
+class _PixelShuffleMish(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pre):
+        n, h, w, c4 = pre.shape
+        _chk(pre)
+        z = torch.empty((n, 2 * h, 2 * w, c4 // 4), device=pre.device)
+        _lib.call("focr_pixelshuffle_mish_fwd", _p(pre), _p(z), n, h, w, c4 // 4, _stream())
+        ctx.save_for_backward(pre)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        (pre,) = ctx.saved_tensors
+        n, h, w, c4 = pre.shape
+        dz = dz.contiguous()
+        dpre = torch.empty_like(pre)
+        _lib.call("focr_pixelshuffle_mish_bwd", _p(dz), _p(pre), _p(dpre), n, h, w, c4 // 4, _stream())
+        return dpre
+
+
+def pixelshuffle_mish(pre):
+    return _PixelShuffleMish.apply(pre)
+
+
+class _ToNHWC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        n, c, h, w = x.shape
+        x = x.contiguous()
+        _chk(x)
+        y = torch.empty((n, h, w, c), device=x.device)
+        _lib.call("focr_nchw_to_nhwc", _p(x), _p(y), n, c, h * w, _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, h, w, c = dy.shape
+        dy = dy.contiguous()
+        dx = torch.empty((n, c, h, w), device=dy.device)
+        _lib.call("focr_nhwc_to_nchw", _p(dy), _p(dx), n, c, h * w, 0, _stream())
+        return dx
+
+
+def to_nhwc(x):
+    return _ToNHWC.apply(x)
+
+
+class _ToNCHW(torch.autograd.Function):
+    """NHWC -> NCHW, optionally through tanh (the SR network's output non-linearity)."""
+
+    @staticmethod
+    def forward(ctx, x, do_tanh):
+        n, h, w, c = x.shape
+        _chk(x)
+        y = torch.empty((n, c, h, w), device=x.device)
+        _lib.call("focr_nhwc_to_nchw", _p(x), _p(y), n, c, h * w, int(do_tanh), _stream())
+        ctx.do_tanh = bool(do_tanh)
+        if do_tanh:
+            ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c, h, w = dy.shape
+        dy = dy.contiguous()
+        dx = torch.empty((n, h, w, c), device=dy.device)
+        if ctx.do_tanh:
+            (y,) = ctx.saved_tensors
+            _lib.call("focr_tanh_bwd_to_nhwc", _p(dy), _p(y), _p(dx), n, c, h * w, _stream())
+        else:
+            _lib.call("focr_nchw_to_nhwc", _p(dy), _p(dx), n, c, h * w, _stream())
+        return dx, None
+
+
+def to_nchw(x, tanh=False):
+    return _ToNCHW.apply(x, tanh)
+
+
+# ----------------------------------------------------------------------------------------
+# FeatureEnhancer pieces
+# ----------------------------------------------------------------------------------------
+class _ConcatPE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, pe):
+        b, t, cf = feat.shape
+        cp = pe.shape[-1]
+        _chk(feat, pe)
+        tok = torch.empty((b, t, cf + cp), device=feat.device)
+        _lib.call("focr_concat_pe", _p(feat), _p(pe), _p(tok), b * t, cf, cp, t, _stream())
+        ctx.cfg = (b, t, cf, cp)
+        return tok
+
+    @staticmethod
+    def backward(ctx, dtok):
+        b, t, cf, cp = ctx.cfg
+        dtok = dtok.contiguous()
+        df = torch.empty((b, t, cf), device=dtok.device)
+        _lib.call("focr_slice_cols", _p(dtok), _NULL, _p(df), b * t, cf + cp, 0, cf, _stream())
+        return df, None
+
+
+def concat_pe(feat, pe):
+    return _ConcatPE.apply(feat, pe)
+
+
+class _Attention(torch.autograd.Function):
+    """softmax(q k^T / sqrt(32)) [dropout] v, 4 heads of 32 inside a [B,T,128] row layout."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, p_drop, seed):
+        b, t, d = q.shape
+        _chk(q, k, v)
+        o = torch.empty_like(q)
+        lse = torch.empty((b, heads, t), device=q.device)
+        scale = 1.0 / math.sqrt(d // heads)
+        _lib.call("focr_attention_fwd", _p(q), _p(k), _p(v), _p(o), _p(lse), b, heads, t, d, scale,
+                  float(p_drop), seed, _stream())
+        ctx.cfg = (b, heads, t, d, scale, float(p_drop), seed)
+        ctx.save_for_backward(q, k, v, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        b, heads, t, d, scale, p_drop, seed = ctx.cfg
+        do = do.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        work = torch.empty((b, heads, t), device=q.device)
+        _lib.call("focr_attention_bwd", _p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(dq), _p(dk), _p(dv),
+                  _p(work), b, heads, t, d, scale, p_drop, seed, _stream())
+        return dq, dk, dv, None, None, None
+
+
+def attention(q, k, v, heads=4, p_drop=0.0):
+    seed = _new_seed() if p_drop > 0 else 0
+    return _Attention.apply(q, k, v, heads, p_drop, seed)
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        _chk(x)
+        y = torch.empty_like(x)
+        _lib.call("focr_dropout", _p(x), _p(y), x.numel(), float(p), seed, _stream())
+        ctx.cfg = (float(p), seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        _lib.call("focr_dropout", _p(dy), _p(dx), dy.numel(), p, seed, _stream())
+        return dx, None, None
+
+
+def dropout(x, p, training):
+    if not training or p <= 0:
+        return x
+    return _Dropout.apply(x, p, _new_seed())
+
+
+# ----------------------------------------------------------------------------------------
+# losses
+# ----------------------------------------------------------------------------------------
+class _MSE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        _chk(a, b)
+        out = torch.empty(1, device=a.device)
+        _lib.call("focr_mse_fwd", _p(a), _p(b), _p(out), a.numel(), _stream())
+        ctx.save_for_backward(a, b)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous().reshape(1)
+        da = torch.empty_like(a)
+        _lib.call("focr_mse_bwd", _p(a), _p(b), _p(g), _p(da), a.numel(), _stream())
+        return da, None
+
+
+def mse_loss(a, b):
+    return _MSE.apply(a, b)
+
+
+class _CTC(torch.autograd.Function):
+    """log_softmax + CTC (blank 0, reduction 'mean', zero_infinity) on logits [T,B,C]."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, lengths, offsets):
+        t, b, c = logits.shape
+        logits = logits.contiguous()
+        _chk(logits)
+        loss = torch.empty(1, device=logits.device)
+        nll = torch.empty(b, device=logits.device)
+        grad = torch.empty_like(logits)
+        _lib.call("focr_ctc_fwd", _p(logits), _p(targets), _p(lengths), _p(offsets), _p(loss), _p(nll),
+                  _p(grad), t, b, c, _stream())
+        ctx.save_for_backward(grad)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        g = g.contiguous().reshape(1)
+        out = torch.empty_like(grad)
+        _lib.call("focr_scale_dev", _p(grad), _p(g), _p(out), grad.numel(), _stream())
+        return out, None, None, None
+
+
+def ctc_loss(logits, targets, lengths):
+    """targets: int32 [sum L] (device), lengths: int32 [B] (device)."""
+    offsets = (torch.cumsum(lengths, 0) - lengths).to(torch.int32)
+    return _CTC.apply(logits, targets.to(torch.int32).contiguous(), lengths.to(torch.int32).contiguous(),
+                      offsets.contiguous())
+
+
+# ----------------------------------------------------------------------------------------
+# pooling / resampling
+# ----------------------------------------------------------------------------------------
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kernel, stride, pad):
+        n, h, w, c = x.shape
+        _chk(x)
+        kh, kw = kernel
+        sh, sw = stride
+        ph, pw = pad
+        oh, ow = (h + 2 * ph - kh) // sh + 1, (w + 2 * pw - kw) // sw + 1
+        y = torch.empty((n, oh, ow, c), device=x.device)
+        idx = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.uint8)
+        _lib.call("focr_maxpool_fwd", _p(x), _p(y), ctypes.c_void_p(idx.data_ptr()), n, h, w, c, kh, kw, sh, sw,
+                  ph, pw, _stream())
+        ctx.cfg = (n, h, w, c, kh, kw, sh, sw, ph, pw)
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        n, h, w, c, kh, kw, sh, sw, ph, pw = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty((n, h, w, c), device=dy.device)
+        _lib.call("focr_maxpool_bwd", _p(dy), ctypes.c_void_p(idx.data_ptr()), _p(dx), n, h, w, c, kh, kw, sh,
+                  sw, ph, pw, _stream())
+        return dx, None, None, None
+
+
+def maxpool(x, kernel, stride=None, pad=(0, 0)):
+    return _MaxPool.apply(x, tuple(kernel), tuple(stride or kernel), tuple(pad))
+
+
+class _TPSWarp(torch.autograd.Function):
+    """TPS grid + bilinear sampling of an NHWC image; gradient flows to the control points only
+    (the warped tensor is the input image -- nothing trainable lies upstream of it)."""
+
+    @staticmethod
+    def forward(ctx, img, ctrl, inv_kernel, coord_repr):
+        b, h, w, c = img.shape
+        nc = ctrl.shape[1]
+        ctrl = ctrl.contiguous()
+        _chk(img, ctrl, inv_kernel, coord_repr)
+        out = torch.empty_like(img)
+        src = torch.empty((b, h * w, 2), device=img.device)
+        _lib.call("focr_tps_fwd", _p(img), _p(ctrl), _p(inv_kernel), _p(coord_repr), _p(out), _p(src), b, h, w,
+                  c, nc, _stream())
+        ctx.cfg = (b, h, w, c, nc)
+        ctx.save_for_backward(img, src, inv_kernel, coord_repr)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        img, src, inv_kernel, coord_repr = ctx.saved_tensors
+        b, h, w, c, nc = ctx.cfg
+        dout = dout.contiguous()
+        dctrl = torch.empty((b, nc, 2), device=dout.device)
+        _lib.call("focr_tps_bwd", _p(dout), _p(img), _p(src), _p(inv_kernel), _p(coord_repr), _p(dctrl), b, h,
+                  w, c, nc, _stream())
+        return None, dctrl, None, None
+
+
+def tps_warp(img, ctrl, inv_kernel, coord_repr):
+    return _TPSWarp.apply(img, ctrl, inv_kernel, coord_repr)
+
+
+class _BicubicGray(torch.autograd.Function):
+    """parse_crnn_data: NCHW [B,C>=3,H,IW] -> [B,1,H,OW] (bicubic along W, luma)."""
+
+    @staticmethod
+    def forward(ctx, x, ow):
+        b, c, h, iw = x.shape
+        x = x.contiguous()
+        _chk(x)
+        y = torch.empty((b, 1, h, ow), device=x.device)
+        _lib.call("focr_bicubic_gray_fwd", _p(x), _p(y), b, c, h, iw, ow, _stream())
+        ctx.cfg = (b, c, h, iw, ow)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        b, c, h, iw, ow = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty((b, c, h, iw), device=dy.device)
+        _lib.call("focr_bicubic_gray_bwd", _p(dy), _p(dx), b, c, h, iw, ow, _stream())
+        return dx, None
+
+
+def bicubic_gray(x, ow=100):
+    return _BicubicGray.apply(x, ow)
+
+
+# ----------------------------------------------------------------------------------------
+# bidirectional LSTM (recurrent part; the input projection is a `linear`)
+# ----------------------------------------------------------------------------------------
+class _LSTMRecur(torch.autograd.Function):
+    """gx: [rows, 2*4H] with row(t,b) = t*st_t + b*st_b;  returns hseq [T,B,2H].
+    Gradient flows to gx only (recurrent weights of the frozen recognizer get no gradient)."""
+
+    @staticmethod
+    def forward(ctx, gx, whh, bhh, t_len, batch, st_t, st_b):
+        hid = whh.shape[-1]
+        _chk(gx, whh, bhh)
+        hseq = torch.empty((t_len, batch, 2 * hid), device=gx.device)
+        gates = torch.empty((t_len, batch, 2, 4 * hid), device=gx.device)
+        cseq = torch.empty((t_len, batch, 2, hid), device=gx.device)
+        _lib.call("focr_lstm_bidir_fwd", _p(gx), _p(whh), _p(bhh), _p(hseq), _p(gates), _p(cseq), t_len, batch,
+                  hid, st_t, st_b, _stream())
+        ctx.cfg = (t_len, batch, hid, st_t, st_b, tuple(gx.shape))
+        ctx.save_for_backward(whh, gates, cseq)
+        return hseq
+
+    @staticmethod
+    def backward(ctx, dh):
+        whh, gates, cseq = ctx.saved_tensors
+        t_len, batch, hid, st_t, st_b, gshape = ctx.cfg
+        dh = dh.contiguous()
+        dgx = torch.empty(gshape, device=dh.device)
+        carry = torch.empty((2, batch, hid), device=dh.device)
+        _lib.call("focr_lstm_bidir_bwd", _p(dh), _p(whh), _p(gates), _p(cseq), _p(dgx), _p(carry), t_len, batch,
+                  hid, st_t, st_b, _stream())
+        return dgx, None, None, None, None, None, None
+
+
+def lstm_recurrence(gx, whh, bhh, t_len, batch, st_t, st_b):
+    return _LSTMRecur.apply(gx, whh, bhh, t_len, batch, st_t, st_b)
+
+
+# ----------------------------------------------------------------------------------------
+# optimiser tail
+# ----------------------------------------------------------------------------------------
+def grad_sumsq(flat_grad, out, gscale=1.0):
+    _lib.call("focr_grad_sumsq", _p(flat_grad), _p(out), flat_grad.numel(), float(gscale), _stream())
+
+
+def clip_adam(p, g, m, v, sumsq, lr, beta1, beta2, eps, step, max_norm, gscale=1.0):
+    _lib.call("focr_clip_adam", _p(p), _p(g), _p(m), _p(v), _p(sumsq), p.numel(), float(lr), float(beta1),
+              float(beta2), float(eps), int(step), float(max_norm), float(gscale), _stream())

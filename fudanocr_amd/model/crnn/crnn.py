@@ -1,0 +1,91 @@
+"""CRNN recognizer on HIP kernels; same classes / state_dict keys as the reference
+(scene-text-telescope/model/crnn/crnn.py:6-80).  Input NCHW [B, nc, 32, 100], output logits
+[T=26, B, nclass].  The recognizer is used frozen (eval-mode BN, no weight gradients) exactly as
+the reference uses it (interfaces/super_resolution.py:168-171); gradients flow to its input."""
+import torch
+from torch import nn
+
+from ... import kernels as K
+from .._layers import BatchNorm2d, Conv2d, Linear, MaxPool2d, ReLUTag
+
+
+class BidirectionalLSTM(nn.Module):
+    def __init__(self, nIn, nHidden, nOut):
+        super().__init__()
+        self.rnn = nn.LSTM(nIn, nHidden, bidirectional=True)      # parameter registry only
+        self.embedding = Linear(nHidden * 2, nOut)
+        self._packed = None
+
+    def _pack(self):
+        """[W_ih | W_ih_reverse], stacked W_hh / biases, rebuilt only when a parameter changed."""
+        r = self.rnn
+        ps = (r.weight_ih_l0, r.weight_ih_l0_reverse, r.weight_hh_l0, r.weight_hh_l0_reverse,
+              r.bias_ih_l0, r.bias_ih_l0_reverse, r.bias_hh_l0, r.bias_hh_l0_reverse)
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if self._packed is None or self._packed[0] != key:
+            with torch.no_grad():
+                wih = torch.cat([ps[0], ps[1]], 0).contiguous()
+                whh = torch.stack([ps[2], ps[3]], 0).contiguous()
+                bih = torch.cat([ps[4], ps[5]], 0).contiguous()
+                bhh = torch.stack([ps[6], ps[7]], 0).contiguous()
+            self._packed = (key, wih, whh, bih, bhh)
+        return self._packed[1:]
+
+    def forward(self, input, t_len=None, batch=None, st_t=None, st_b=None):
+        """input: rows x nIn with row(t,b) = t*st_t + b*st_b (defaults: sequence-first [T,B,nIn])."""
+        if input.dim() == 3:
+            t_len, batch = input.shape[0], input.shape[1]
+            st_t, st_b = batch, 1
+            input = input.reshape(t_len * batch, -1)
+        if any(p.requires_grad for p in self.rnn.parameters()):
+            raise RuntimeError("training the recognizer's LSTM weights is not built yet (frozen CRNN only)")
+        wih, whh, bih, bhh = self._pack()
+        gx = K.linear(input, wih, bih)
+        rec = K.lstm_recurrence(gx, whh, bhh, t_len, batch, st_t, st_b)     # [T,B,2H]
+        out = self.embedding(rec.view(t_len * batch, -1))
+        return out.view(t_len, batch, -1)
+
+
+class CRNN(nn.Module):
+    def __init__(self, imgH, nc, nclass, nh, n_rnn=2, leakyRelu=False):
+        super().__init__()
+        assert imgH % 16 == 0, "imgH has to be a multiple of 16"
+        assert not leakyRelu, "the path uses ReLU"
+        ks, ps = [3, 3, 3, 3, 3, 3, 2], [1, 1, 1, 1, 1, 1, 0]
+        nm = [64, 128, 256, 256, 512, 512, 512]
+        cnn = nn.Sequential()
+        for i in range(7):
+            cnn.add_module("conv%d" % i, Conv2d(nc if i == 0 else nm[i - 1], nm[i], ks[i], 1, ps[i]))
+            if i in (2, 4, 6):
+                cnn.add_module("batchnorm%d" % i, BatchNorm2d(nm[i]))
+            cnn.add_module("relu%d" % i, ReLUTag(True))
+            if i in (0, 1):
+                cnn.add_module("pooling%d" % i, MaxPool2d(2, 2))
+            elif i in (3, 5):
+                cnn.add_module("pooling%d" % (2 if i == 3 else 3), MaxPool2d((2, 2), (2, 1), (0, 1)))
+        self.cnn = cnn
+        self.rnn = nn.Sequential(BidirectionalLSTM(512, nh, nh), BidirectionalLSTM(nh, nh, nclass))
+
+    def forward(self, input):
+        x = K.to_nhwc(input) if input.shape[1] != 1 else input.reshape(input.shape[0], input.shape[2],
+                                                                       input.shape[3], 1)
+        mods = list(self.cnn.named_children())
+        i = 0
+        while i < len(mods):
+            name, m = mods[i]
+            if name.startswith("conv"):
+                bn = mods[i + 1][1] if mods[i + 1][0].startswith("batchnorm") else None
+                if bn is None:
+                    x = m(x, relu=True)
+                    i += 2                      # conv, relu
+                else:
+                    x = bn(m(x), act=K.ACT_RELU)
+                    i += 3                      # conv, batchnorm, relu
+            else:
+                x = m(x)
+                i += 1
+        b, h, w, c = x.shape
+        assert h == 1, "the height of conv must be 1"
+        # rows of x are (b, t): feed the LSTM through strides instead of transposing to [T,B,C]
+        out = self.rnn[0](x.view(b * w, c), t_len=w, batch=b, st_t=1, st_b=w)
+        return self.rnn[1](out)

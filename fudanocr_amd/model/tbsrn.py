@@ -1,0 +1,197 @@
+"""TBSRN (text-gestalt / scene-text-telescope transformer-based SR net) on HIP kernels.
+
+Same public classes, constructor signatures and state_dict keys as the reference
+(scene-text-telescope/model/tbsrn.py:23-305; text-gestalt/model/tbsrn.py is identical up to
+dead timing lines), including the parameters that never receive a gradient (`conv`, `bn`,
+`blockK.gru1/gru2`, `compress_attention_linear`) so reference checkpoints
+load.  I/O is NCHW at the module boundary, channel-last inside.
+"""
+import math
+
+import torch
+from torch import nn
+
+from .. import kernels as K
+from ._layers import BatchNorm2d, Conv2d, Linear, PReLU
+from .stn_head import STNHead
+from .tps_spatial_transformer import TPSSpatialTransformer
+
+
+def positionalencoding2d(d_model, height, width):
+    """Fixed 2-D sinusoid table [d_model, H, W] (reference tbsrn.py:39-61): the first half of the
+    channels encodes the column, the second half the row; sin on even, cos on odd channels."""
+    if d_model % 4 != 0:
+        raise ValueError("Cannot use sin/cos positional encoding with odd dimension (got dim=%d)" % d_model)
+    half = d_model // 2
+    freq = torch.exp(torch.arange(0.0, half, 2) * -(math.log(10000.0) / half))
+    col = torch.arange(0.0, width).unsqueeze(1) * freq
+    row = torch.arange(0.0, height).unsqueeze(1) * freq
+    pe = torch.zeros(d_model, height, width)
+    pe[0:half:2] = col.sin().t().unsqueeze(1)
+    pe[1:half:2] = col.cos().t().unsqueeze(1)
+    pe[half::2] = row.sin().t().unsqueeze(2)
+    pe[half + 1::2] = row.cos().t().unsqueeze(2)
+    return pe
+
+
+class LayerNorm(nn.Module):
+    """a_2 * (x - mean) / (std_unbiased + eps) + b_2   (reference tbsrn.py:23-36)."""
+
+    def __init__(self, features, eps=1e-6):
+        super().__init__()
+        self.a_2 = nn.Parameter(torch.ones(features))
+        self.b_2 = nn.Parameter(torch.zeros(features))
+        self.eps = eps
+
+    def forward(self, x, residual=None):
+        return K.layernorm_std(x, self.a_2, self.b_2, residual=residual, eps=self.eps)
+
+
+class MultiHeadedAttention(nn.Module):
+    def __init__(self, h, d_model, dropout=0.1, compress_attention=False):
+        super().__init__()
+        assert d_model % h == 0
+        self.d_k, self.h = d_model // h, h
+        self.linears = nn.ModuleList([Linear(d_model, d_model) for _ in range(4)])
+        self.attn = None
+        self.dropout = nn.Dropout(p=dropout)          # p and train/eval flag only
+        self.compress_attention = compress_attention
+        self.compress_attention_linear = nn.Linear(h, 1)   # dead in the reference too (tbsrn.py:107)
+
+    def forward(self, query, key, value, mask=None, align=None):
+        assert mask is None, "the SR nets never pass a mask"
+        q, k, v = (lin(x) for lin, x in zip(self.linears, (query, key, value)))
+        p = self.dropout.p if self.dropout.training else 0.0
+        ctx = K.attention(q, k, v, heads=self.h, p_drop=p)
+        return self.linears[3](ctx), None
+
+
+class PositionwiseFeedForward(nn.Module):
+    def __init__(self, d_model, d_ff, dropout=0.1):
+        super().__init__()
+        self.w_1 = Linear(d_model, d_ff)
+        self.w_2 = Linear(d_ff, d_model)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x):
+        h = self.w_1(x, relu=True)
+        h = K.dropout(h, self.dropout.p, self.dropout.training)
+        return self.w_2(h)
+
+
+class FeatureEnhancer(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.multihead = MultiHeadedAttention(h=4, d_model=128, dropout=0.1)
+        self.mul_layernorm1 = LayerNorm(features=128)
+        self.pff = PositionwiseFeedForward(128, 128)
+        self.mul_layernorm3 = LayerNorm(features=128)
+        self.linear = Linear(128, 64)
+        self._pe = None
+
+    def _pe_table(self, device):
+        # the reference rebuilds this on the host and copies it every call (tbsrn.py:83)
+        if self._pe is None or self._pe.device != device:
+            self._pe = positionalencoding2d(64, 16, 64).reshape(64, 1024).t().contiguous().to(device)
+        return self._pe
+
+    def forward(self, conv_feature, residual=None):
+        """conv_feature: [B, 1024, 64] tokens (channel-last) -> [B, 1024, 64] (+ residual)."""
+        tok = K.concat_pe(conv_feature, self._pe_table(conv_feature.device))
+        att, _ = self.multihead(tok, tok, tok, mask=None)
+        r = self.mul_layernorm1(att, residual=tok)
+        r = self.mul_layernorm3(self.pff(r), residual=r)
+        return self.linear(r, residual=residual)
+
+
+class mish(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.activated = True
+
+
+class GruBlock(nn.Module):
+    """Parameter holder only: TBSRN constructs but never calls it (tbsrn.py:234,239)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=1, padding=0)
+        self.gru = nn.GRU(out_channels, out_channels // 2, bidirectional=True, batch_first=True)
+
+
+class RecurrentResidualBlock(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.conv1 = Conv2d(channels, channels, kernel_size=3, padding=1)
+        self.bn1 = BatchNorm2d(channels)
+        self.gru1 = GruBlock(channels, channels)
+        self.prelu = mish()
+        self.conv2 = Conv2d(channels, channels, kernel_size=3, padding=1)
+        self.bn2 = BatchNorm2d(channels)
+        self.gru2 = GruBlock(channels, channels)
+        self.feature_enhancer = FeatureEnhancer()
+        for p in self.parameters():                      # tbsrn.py:242-244
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, x):
+        r = self.bn1(self.conv1(x), act=K.ACT_MISH)
+        r = self.bn2(self.conv2(r))
+        n, h, w, c = r.shape
+        out = self.feature_enhancer(r.view(n, h * w, c), residual=x.view(n, h * w, c))
+        return out.view(n, h, w, c)
+
+
+class UpsampleBLock(nn.Module):
+    def __init__(self, in_channels, up_scale):
+        super().__init__()
+        assert up_scale == 2
+        self.conv = Conv2d(in_channels, in_channels * up_scale ** 2, kernel_size=3, padding=1)
+        self.pixel_shuffle = nn.PixelShuffle(up_scale)
+        self.prelu = mish()
+
+    def forward(self, x):
+        return K.pixelshuffle_mish(self.conv(x))
+
+
+class TBSRN(nn.Module):
+    def __init__(self, scale_factor=2, width=128, height=32, STN=True, srb_nums=5, mask=False,
+                 hidden_units=32, input_channel=3):
+        super().__init__()
+        self.conv = nn.Conv2d(input_channel, 3, 3, 1, 1)        # dead (tbsrn.py:170-172)
+        self.bn = nn.BatchNorm2d(3)
+        self.relu = nn.ReLU()
+        in_planes = 4 if mask else 3
+        assert math.log(scale_factor, 2) % 1 == 0
+        upsample_block_num = int(math.log(scale_factor, 2))
+        c = 2 * hidden_units
+        self.block1 = nn.Sequential(Conv2d(in_planes, c, kernel_size=9, padding=4), PReLU())
+        self.srb_nums = srb_nums
+        for i in range(srb_nums):
+            setattr(self, "block%d" % (i + 2), RecurrentResidualBlock(c))
+        setattr(self, "block%d" % (srb_nums + 2),
+                nn.Sequential(Conv2d(c, c, kernel_size=3, padding=1), BatchNorm2d(c)))
+        tail = [UpsampleBLock(c, 2) for _ in range(upsample_block_num)]
+        tail.append(Conv2d(c, in_planes, kernel_size=9, padding=4))
+        setattr(self, "block%d" % (srb_nums + 3), nn.Sequential(*tail))
+        self.tps_inputsize = [height // scale_factor, width // scale_factor]
+        self.stn = STN
+        if self.stn:
+            self.tps = TPSSpatialTransformer(output_image_size=tuple(self.tps_inputsize),
+                                             num_control_points=20, margins=(0.05, 0.05))
+            self.stn_head = STNHead(in_planes=in_planes, num_ctrlpoints=20, activation="none")
+
+    def forward(self, x):
+        """x: [B, Cin, 16, 64] NCHW in [0,1] -> SR image [B, Cin, 32, 128] NCHW in (-1,1)."""
+        x = K.to_nhwc(x)
+        if self.stn and self.training:
+            _, ctrl = self.stn_head(x)
+            x, _ = self.tps(x, ctrl)
+        b1 = self.block1(x)
+        h = b1
+        for i in range(self.srb_nums):
+            h = getattr(self, "block%d" % (i + 2))(h)
+        tail7 = getattr(self, "block%d" % (self.srb_nums + 2))
+        h = tail7[1](tail7[0](h), residual=b1)                 # block1 + block7
+        h = getattr(self, "block%d" % (self.srb_nums + 3))(h)
+        return K.to_nchw(h, tanh=True)

@@ -1,0 +1,408 @@
+"""GPU parity tests, kernel level: every HIP kernel (called through the C ABI via
+fudanocr_amd.kernels) against a plain PyTorch CPU float64 reference of the same op.
+Tolerance: fp32 kernels, so 2e-5 * (1 + max|ref|) on values (accumulation-order noise only);
+the end-to-end 1e-3 gate of north_star is checked in test_gpu_models.py."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def K():
+    from fudanocr_amd import kernels
+    return kernels
+
+
+def dev(t):
+    return t.detach().float().cuda().contiguous()
+
+
+def close(got, ref, tol=2e-5, what=""):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = (got - ref).abs().max().item()
+    lim = tol * (1 + ref.abs().max().item())
+    assert err <= lim, "%s: max abs err %.3e > %.3e (ref max %.3e)" % (what, err, lim, ref.abs().max().item())
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.rand(*shape, generator=g, dtype=torch.float64) * 2 - 1) * scale
+
+
+def cl(w):
+    """conv weight -> channels_last CUDA leaf (the layout the product modules use)."""
+    return w.detach().float().cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, KH, KW, ph, pw
+    (2, 16, 64, 64, 64, 3, 3, 1, 1),      # SRB conv (K2)
+    (2, 16, 64, 3, 64, 9, 9, 4, 4),       # block1 (K1) scalar gather path
+    (1, 32, 128, 64, 3, 9, 9, 4, 4),      # block8.1 (K11) narrow-N path
+    (2, 16, 64, 64, 256, 3, 3, 1, 1),     # upsample conv (K10)
+    (3, 32, 100, 1, 64, 3, 3, 1, 1),      # CRNN conv0
+    (2, 2, 27, 512, 512, 2, 2, 0, 0),     # CRNN conv6 (2x2, no padding)
+    (2, 8, 32, 32, 64, 3, 3, 1, 1),       # STN conv (Cin 32)
+    (5, 1, 2, 256, 256, 3, 3, 1, 1),      # STN last conv on a 1x2 map, ragged M
+    (1, 7, 5, 4, 37, 3, 3, 1, 1),         # odd sizes, mask channel count, Cout not /32
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(case):
+    n, h, w, cin, cout, kh, kw, ph, pw = case
+    x = rnd(n, cin, h, w, seed=1).requires_grad_(True)
+    wt = rnd(cout, cin, kh, kw, seed=2, scale=1 / math.sqrt(cin * kh * kw)).requires_grad_(True)
+    b = rnd(cout, seed=3).requires_grad_(True)
+    y = F.conv2d(x, wt, b, padding=(ph, pw))
+    gy = rnd(*y.shape, seed=4)
+    y.backward(gy)
+    xd = dev(x.permute(0, 2, 3, 1)).requires_grad_(True)
+    wd = cl(wt)
+    bd = dev(b).requires_grad_(True)
+    yd = K().conv2d(xd, wd, bd, pad=(ph, pw))
+    close(yd.permute(0, 3, 1, 2), y, what="conv fwd")
+    yd.backward(dev(gy.permute(0, 2, 3, 1)))
+    close(xd.grad.permute(0, 3, 1, 2), x.grad, what="conv dgrad")
+    close(wd.grad, wt.grad, 5e-5, what="conv wgrad")
+    close(bd.grad, b.grad, 5e-5, what="conv bias grad")
+
+
+def test_conv2d_fused_epilogue():
+    x = rnd(2, 64, 8, 8, seed=5).requires_grad_(True)
+    wt = rnd(64, 64, 3, 3, seed=6, scale=0.05).requires_grad_(True)
+    b = rnd(64, seed=7).requires_grad_(True)
+    r = rnd(2, 64, 8, 8, seed=8).requires_grad_(True)
+    y = F.relu(F.conv2d(x, wt, b, padding=1) + r)
+    gy = rnd(*y.shape, seed=9)
+    y.backward(gy)
+    xd = dev(x.permute(0, 2, 3, 1)).requires_grad_(True)
+    rd = dev(r.permute(0, 2, 3, 1)).requires_grad_(True)
+    wd, bd = cl(wt), dev(b).requires_grad_(True)
+    yd = K().conv2d(xd, wd, bd, pad=(1, 1), residual=rd, relu=True)
+    close(yd.permute(0, 3, 1, 2), y, what="fused fwd")
+    yd.backward(dev(gy.permute(0, 2, 3, 1)))
+    close(xd.grad.permute(0, 3, 1, 2), x.grad, what="fused dx")
+    close(rd.grad.permute(0, 3, 1, 2), r.grad, what="fused dres")
+    close(wd.grad, wt.grad, 5e-5, what="fused dw")
+
+
+@pytest.mark.parametrize("rows,nin,nout,alpha", [(300, 128, 128, 1.0), (7, 512, 40, 0.1), (130, 512, 37, 1.0),
+                                                 (2048, 128, 64, 1.0)])
+def test_linear(rows, nin, nout, alpha):
+    x = rnd(rows, nin, seed=1).requires_grad_(True)
+    wt = rnd(nout, nin, seed=2, scale=1 / math.sqrt(nin)).requires_grad_(True)
+    b = rnd(nout, seed=3).requires_grad_(True)
+    y = (alpha * x) @ wt.t() + b
+    gy = rnd(rows, nout, seed=4)
+    y.backward(gy)
+    xd, wd, bd = (dev(t).requires_grad_(True) for t in (x, wt, b))
+    yd = K().linear(xd, wd, bd, alpha=alpha)
+    close(yd, y, what="linear fwd")
+    yd.backward(dev(gy))
+    close(xd.grad, x.grad, what="linear dx")
+    close(wd.grad, wt.grad, 5e-5, what="linear dw")
+    close(bd.grad, b.grad, 5e-5, what="linear db")
+
+
+@pytest.mark.parametrize("b,t", [(2, 1024), (3, 256)])
+def test_attention(b, t):
+    q, k, v = (rnd(b, t, 128, seed=s, scale=2.0).requires_grad_(True) for s in (1, 2, 3))
+
+    def heads(z):
+        return z.view(b, t, 4, 32).transpose(1, 2)
+    s = heads(q) @ heads(k).transpose(-1, -2) / math.sqrt(32)
+    o = (torch.softmax(s, -1) @ heads(v)).transpose(1, 2).reshape(b, t, 128)
+    go = rnd(b, t, 128, seed=4)
+    o.backward(go)
+    qd, kd, vd = (dev(z).requires_grad_(True) for z in (q, k, v))
+    od = K().attention(qd, kd, vd, heads=4, p_drop=0.0)
+    close(od, o, what="attn fwd")
+    od.backward(dev(go))
+    close(qd.grad, q.grad, what="attn dq")
+    close(kd.grad, k.grad, what="attn dk")
+    close(vd.grad, v.grad, what="attn dv")
+
+
+def test_attention_spiked_scores():
+    """one key row strongly aligned with one query: exercises the online-softmax rescale."""
+    b, t = 1, 256
+    q, k, v = (rnd(b, t, 128, seed=s) for s in (1, 2, 3))
+    k[0, 200, :32] = q[0, 5, :32] * 40.0
+    q, k, v = (z.requires_grad_(True) for z in (q, k, v))
+    heads = lambda z: z.view(b, t, 4, 32).transpose(1, 2)
+    o = (torch.softmax(heads(q) @ heads(k).transpose(-1, -2) / math.sqrt(32), -1) @ heads(v)).transpose(1, 2).reshape(b, t, 128)
+    od = K().attention(dev(q), dev(k), dev(v), heads=4, p_drop=0.0)
+    close(od, o, what="attn spiked fwd")
+
+
+def test_attention_dropout():
+    """dropout: expectation preserved, backward uses the same mask as forward (checked through
+    linearity: with v -> ones the output equals the kept fraction / (1-p))."""
+    b, t, p = 1, 1024, 0.1
+    q, k = (dev(rnd(b, t, 128, seed=s)) for s in (1, 2))
+    v = torch.ones(b, t, 128, device="cuda").requires_grad_(True)
+    from fudanocr_amd.kernels import _Attention
+    o = _Attention.apply(q, k, v, 4, p, 12345)
+    o2 = _Attention.apply(q, k, v.detach(), 4, p, 12345)
+    assert torch.equal(o, o2), "same seed must give the same mask"
+    assert abs(o.mean().item() - 1.0) < 2e-2          # E[mask/(1-p)] = 1
+    assert o.std().item() > 1e-4                       # but not identically one
+    o.sum().backward()
+    # d(sum o)/dv[key] = sum_q Pdropped[q,key] ; its total over keys equals sum(o) when v == 1
+    assert abs(v.grad.sum().item() / 32 - o.sum().item() / 32) < 1e-2 * o.sum().item() / 32
+
+
+@pytest.mark.parametrize("act", [0, 1, 4])
+@pytest.mark.parametrize("training", [True, False])
+def test_batchnorm(act, training):
+    n, c, h, w = 3, 64, 5, 7
+    x = rnd(n, c, h, w, seed=1, scale=3).requires_grad_(True)
+    g = (rnd(c, seed=2) + 1.5).requires_grad_(True)
+    be = rnd(c, seed=3).requires_grad_(True)
+    res = rnd(n, c, h, w, seed=4).requires_grad_(True)
+    rm, rv = rnd(c, seed=5) * 0.1, rnd(c, seed=6) * 0.2 + 1.0
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y = F.batch_norm(x, rm_ref, rv_ref, g, be, training, 0.1, 1e-5)
+    if act == 1:
+        y = F.relu(y)
+    elif act == 4:
+        y = y * torch.tanh(F.softplus(y))
+    y = y + res
+    gy = rnd(*y.shape, seed=7)
+    y.backward(gy)
+    xd = dev(x.permute(0, 2, 3, 1)).requires_grad_(True)
+    rd = dev(res.permute(0, 2, 3, 1)).requires_grad_(True)
+    gd, bd = dev(g).requires_grad_(True), dev(be).requires_grad_(True)
+    rmd, rvd = dev(rm), dev(rv)
+    nbt = torch.zeros((), dtype=torch.long, device="cuda")
+    yd = K().batchnorm_act(xd, gd, bd, rmd, rvd, nbt if training else None, training, act=act, residual=rd)
+    close(yd.permute(0, 3, 1, 2), y, what="bn fwd")
+    yd.backward(dev(gy.permute(0, 2, 3, 1)))
+    close(xd.grad.permute(0, 3, 1, 2), x.grad, 5e-5, what="bn dx")
+    close(rd.grad.permute(0, 3, 1, 2), res.grad, what="bn dres")
+    if training:
+        close(gd.grad, g.grad, 5e-5, what="bn dgamma")
+        close(bd.grad, be.grad, 5e-5, what="bn dbeta")
+        close(rmd, rm_ref, what="running mean")
+        close(rvd, rv_ref, what="running var")
+        assert int(nbt.item()) == 1
+
+
+def test_layernorm_std():
+    x = rnd(70, 128, seed=1, scale=3).requires_grad_(True)
+    r = rnd(70, 128, seed=2).requires_grad_(True)
+    a = (rnd(128, seed=3) + 1.5).requires_grad_(True)
+    b = rnd(128, seed=4).requires_grad_(True)
+    z = x + r
+    y = a * (z - z.mean(-1, keepdim=True)) / (z.std(-1, keepdim=True) + 1e-6) + b
+    gy = rnd(70, 128, seed=5)
+    y.backward(gy)
+    xd, rd, ad, bd = (dev(t).requires_grad_(True) for t in (x, r, a, b))
+    yd = K().layernorm_std(xd, ad, bd, residual=rd)
+    close(yd, y, what="ln fwd")
+    yd.backward(dev(gy))
+    close(xd.grad, x.grad, what="ln dx")
+    close(rd.grad, r.grad, what="ln dres")
+    close(ad.grad, a.grad, 5e-5, what="ln da")
+    close(bd.grad, b.grad, 5e-5, what="ln db")
+
+
+def test_prelu_pixelshuffle_tanh_layout():
+    k = K()
+    x = rnd(2, 6, 8, 64, seed=1).requires_grad_(True)
+    s = torch.tensor([0.3], dtype=torch.float64, requires_grad=True)
+    y = F.prelu(x, s)
+    gy = rnd(*y.shape, seed=2)
+    y.backward(gy)
+    xd, sd = dev(x).requires_grad_(True), dev(s).requires_grad_(True)
+    yd = k.prelu(xd, sd)
+    close(yd, y, what="prelu")
+    yd.backward(dev(gy))
+    close(xd.grad, x.grad, what="prelu dx")
+    close(sd.grad, s.grad, 5e-5, what="prelu dslope")
+
+    pre = rnd(2, 256, 4, 6, seed=3, scale=4).requires_grad_(True)       # NCHW for the reference
+    z = F.pixel_shuffle(pre, 2)
+    z = z * torch.tanh(F.softplus(z))
+    gz = rnd(*z.shape, seed=4)
+    z.backward(gz)
+    pd = dev(pre.permute(0, 2, 3, 1)).requires_grad_(True)
+    zd = k.pixelshuffle_mish(pd)
+    close(zd.permute(0, 3, 1, 2), z, what="pixelshuffle+mish")
+    zd.backward(dev(gz.permute(0, 2, 3, 1)))
+    close(pd.grad.permute(0, 3, 1, 2), pre.grad, what="pixelshuffle+mish bwd")
+
+    u = rnd(2, 3, 5, 9, seed=5, scale=2).requires_grad_(True)
+    t = torch.tanh(u)
+    gt = rnd(*t.shape, seed=6)
+    t.backward(gt)
+    ud = dev(u.permute(0, 2, 3, 1)).requires_grad_(True)
+    td = k.to_nchw(ud, tanh=True)
+    close(td, t, what="tanh->nchw")
+    td.backward(dev(gt))
+    close(ud.grad.permute(0, 3, 1, 2), u.grad, what="tanh bwd")
+    close(k.to_nhwc(dev(u)), u.permute(0, 2, 3, 1), what="nchw->nhwc")
+
+
+def test_concat_dropout_mse():
+    k = K()
+    feat = rnd(2, 1024, 64, seed=1).requires_grad_(True)
+    pe = rnd(1024, 64, seed=2)
+    tok = torch.cat([feat, pe.unsqueeze(0).expand(2, -1, -1)], 2)
+    g = rnd(2, 1024, 128, seed=3)
+    tok.backward(g)
+    fd = dev(feat).requires_grad_(True)
+    td = k.concat_pe(fd, dev(pe))
+    close(td, tok, what="concat")
+    td.backward(dev(g))
+    close(fd.grad, feat.grad, what="concat bwd")
+
+    x = dev(rnd(4096, 128, seed=4)).requires_grad_(True)
+    y = k.dropout(x, 0.1, True)
+    keep = (y != 0).float().mean().item()
+    assert abs(keep - 0.9) < 5e-3, keep
+    mask = (y != 0)
+    close(y[mask], (x / 0.9)[mask], what="dropout scale")
+    y.backward(torch.ones_like(y))
+    close(x.grad, mask.float() / 0.9, what="dropout bwd mask")
+    assert k.dropout(x, 0.1, False) is x
+
+    a = rnd(3, 3, 32, 128, seed=5).requires_grad_(True)
+    b = rnd(3, 3, 32, 128, seed=6)
+    l = ((a - b) ** 2).mean() * 100
+    l.backward()
+    ad = dev(a).requires_grad_(True)
+    ld = k.mse_loss(ad, dev(b)) * 100
+    close(ld, l, what="mse")
+    ld.backward()
+    close(ad.grad, a.grad, what="mse bwd")
+
+
+@pytest.mark.parametrize("geom", [((2, 2), (2, 2), (0, 0), 6, 10), ((2, 2), (2, 1), (0, 1), 4, 26),
+                                  ((1, 2), (1, 2), (0, 0), 2, 4), ((2, 2), (2, 1), (0, 1), 2, 27)])
+def test_maxpool(geom):
+    kern, stride, pad, h, w = geom
+    x = rnd(2, 16, h, w, seed=1).requires_grad_(True)
+    y = F.max_pool2d(x, kern, stride, pad)
+    gy = rnd(*y.shape, seed=2)
+    y.backward(gy)
+    xd = dev(x.permute(0, 2, 3, 1)).requires_grad_(True)
+    yd = K().maxpool(xd, kern, stride, pad)
+    close(yd.permute(0, 3, 1, 2), y, what="maxpool")
+    yd.backward(dev(gy.permute(0, 2, 3, 1)))
+    close(xd.grad.permute(0, 3, 1, 2), x.grad, what="maxpool bwd")
+
+
+def test_tps_warp():
+    from oracle import sr_oracle as O
+    inv, rep, ctrl0 = O.tps_constants()
+    g = torch.Generator().manual_seed(3)
+    ctrl = ctrl0[None].repeat(3, 1, 1).double()
+    ctrl[1] += (torch.rand(20, 2, generator=g, dtype=torch.float64) - 0.5) * 0.2
+    ctrl[2] += (torch.rand(20, 2, generator=g, dtype=torch.float64) - 0.5) * 0.6     # leaves [0,1]: clamp path
+    ctrl.requires_grad_(True)
+    img = torch.rand(3, 3, 16, 64, generator=g, dtype=torch.float64)
+    P = {"tps.inverse_kernel": inv.double(), "tps.target_coordinate_repr": rep.double(),
+         "tps.padding_matrix": torch.zeros(3, 2, dtype=torch.float64)}
+    out = O.tps_warp(P, img, ctrl)
+    gout = rnd(*out.shape, seed=4)
+    out.backward(gout)
+    cd = dev(ctrl).requires_grad_(True)
+    od = K().tps_warp(dev(img.permute(0, 2, 3, 1)), cd, dev(inv), dev(rep))
+    close(od.permute(0, 3, 1, 2), out, 1e-4, what="tps fwd")
+    od.backward(dev(gout.permute(0, 2, 3, 1)))
+    close(cd.grad, ctrl.grad, 2e-3, what="tps d ctrl")
+
+
+def test_bicubic_gray():
+    x = rnd(3, 3, 32, 128, seed=1).requires_grad_(True)
+    g = F.interpolate(x, (32, 100), mode="bicubic", align_corners=False)
+    y = 0.299 * g[:, 0:1] + 0.587 * g[:, 1:2] + 0.114 * g[:, 2:3]
+    gy = rnd(*y.shape, seed=2)
+    y.backward(gy)
+    xd = dev(x).requires_grad_(True)
+    yd = K().bicubic_gray(xd, 100)
+    close(yd, y, what="bicubic+gray")
+    yd.backward(dev(gy))
+    close(xd.grad, x.grad, what="bicubic+gray bwd")
+
+
+@pytest.mark.parametrize("b", [3, 40])
+def test_lstm(b):
+    from oracle import sr_oracle as O
+    t, nin, hid = 26, 64, 256
+    P = {}
+    for suf in ("", "_reverse"):
+        P["weight_ih_l0" + suf] = rnd(4 * hid, nin, seed=1 + len(suf), scale=1 / 16)
+        P["weight_hh_l0" + suf] = rnd(4 * hid, hid, seed=2 + len(suf), scale=1 / 16)
+        P["bias_ih_l0" + suf] = rnd(4 * hid, seed=3 + len(suf), scale=0.1)
+        P["bias_hh_l0" + suf] = rnd(4 * hid, seed=4 + len(suf), scale=0.1)
+    x = rnd(t, b, nin, seed=9).requires_grad_(True)
+    y = O.lstm_bidir(P, "", x)
+    gy = rnd(*y.shape, seed=10)
+    y.backward(gy)
+    k = K()
+    wih = dev(torch.cat([P["weight_ih_l0"], P["weight_ih_l0_reverse"]], 0))
+    bih = dev(torch.cat([P["bias_ih_l0"], P["bias_ih_l0_reverse"]], 0))
+    whh = dev(torch.stack([P["weight_hh_l0"], P["weight_hh_l0_reverse"]], 0))
+    bhh = dev(torch.stack([P["bias_hh_l0"], P["bias_hh_l0_reverse"]], 0))
+    # sequence-first rows (t*B + b)
+    xd = dev(x).requires_grad_(True)
+    gx = k.linear(xd.view(t * b, nin), wih, bih)
+    yd = k.lstm_recurrence(gx, whh, bhh, t, b, b, 1)
+    close(yd, y, 5e-5, what="lstm fwd")
+    yd.backward(dev(gy))
+    close(xd.grad, x.grad, 1e-4, what="lstm dx")
+    # batch-major rows (b*T + t), the CRNN's first layer
+    xb = dev(x.transpose(0, 1)).requires_grad_(True)
+    gx = k.linear(xb.view(b * t, nin), wih, bih)
+    yb = k.lstm_recurrence(gx, whh, bhh, t, b, 1, t)
+    close(yb, y, 5e-5, what="lstm fwd (batch-major rows)")
+    yb.backward(dev(gy))
+    close(xb.grad.transpose(0, 1), x.grad, 1e-4, what="lstm dx (batch-major rows)")
+
+
+def test_ctc():
+    from oracle import sr_oracle as O
+    t, c = 26, 37
+    labels = ["abc", "aab", "zz99", "0", "hello12345", "aaaaaaaaaaaaa", "a1b2c3d4e5f6g7"]   # [5] needs 25 > ... feasible, [6] infeasible? (14 chars fits)
+    labels.append("aaaaaaaaaaaaaaaa")     # 16 repeats need 31 frames > 26: infeasible -> zero_infinity
+    b = len(labels)
+    logits = rnd(t, b, c, seed=1, scale=3).requires_grad_(True)
+    tgt, tlen = O.encode_labels(labels)
+    loss = O.ctc_from_logits(logits, tgt, tlen)
+    (loss * 100).backward()
+    ld = dev(logits).requires_grad_(True)
+    out = K().ctc_loss(ld, tgt.cuda(), tlen.cuda())
+    close(out, loss, what="ctc loss")
+    (out * 100).backward()
+    close(ld.grad, logits.grad, what="ctc grad")
+    assert torch.all(ld.grad[:, -1] == 0)
+
+
+def test_clip_adam():
+    from oracle import sr_oracle as O
+    k = K()
+    n = 10007
+    p = rnd(n, seed=1).float()
+    pr = p.clone().requires_grad_(True)
+    opt = O.AdamState([pr])
+    pd, md, vd = dev(p), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    ss = torch.zeros(1, device="cuda")
+    for step in range(1, 4):
+        g = rnd(n, seed=10 + step, scale=0.01 if step == 2 else 1.0).float()     # step 2: norm < 0.25 (no clip)
+        pr.grad = g.clone()
+        norm = O.clip_grad_norm([pr.grad], 0.25)
+        opt.step()
+        gd = dev(g)
+        k.grad_sumsq(gd, ss)
+        close(ss.sqrt(), norm.reshape(1), 1e-5, what="grad norm")
+        k.clip_adam(pd, gd, md, vd, ss, 1e-4, 0.5, 0.999, 1e-8, step, 0.25)
+        close(pd, pr, 1e-6, what="adam step %d" % step)

@@ -1,0 +1,182 @@
+"""GPU parity tests, model level: the HIP product modules (fudanocr_amd.model.*) against
+ (a) the golden vectors generated from the imported reference (tests/golden), and
+ (b) the CPU oracle on fresh seeded inputs.
+Gate (north_star): SR pixels and losses within 1e-3 relative (pixels: relative to the output's
+max magnitude -- near-zero tanh outputs need an absolute floor)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from fudanocr_amd.utils.synth import make_batch          # noqa: E402
+from fudanocr_amd.utils.weight_fill import fill_module_  # noqa: E402
+
+
+def rel_to_max(got, ref):
+    got = torch.as_tensor(np.asarray(got.detach().cpu() if torch.is_tensor(got) else got)).double()
+    ref = torch.as_tensor(np.asarray(ref)).double()
+    return ((got - ref).abs().max() / ref.abs().max()).item()
+
+
+def build(arch="tbsrn"):
+    from fudanocr_amd.smoke import build_models
+    return build_models(torch.device("cuda:0"), arch)
+
+
+def eval_dropout(net):
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.eval()
+
+
+def test_state_dict_schema(golden_dir):
+    ref = json.load(open(os.path.join(golden_dir, "schema.json")))
+    net, rec, _ = build()
+    for name, m in (("tbsrn", net), ("crnn", rec)):
+        mine = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()]
+        assert mine == ref[name]
+
+
+def test_tbsrn_eval_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "tbsrn_eval.npz"))
+    net, _, _ = build()
+    net.eval()
+    lr, _, _ = make_batch(4, 1234)
+    with torch.no_grad():
+        sr = net(lr.cuda())
+    assert rel_to_max(sr, g["sr"]) < 1e-3
+
+
+def test_tbsrn_train_mse_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "tbsrn_train_mse.npz"))
+    gn = json.load(open(os.path.join(golden_dir, "tbsrn_train_mse_gradnorms.json")))
+    net, _, _ = build()
+    net.train()
+    eval_dropout(net)
+    lr, hr, _ = make_batch(4, 1234)
+    from fudanocr_amd import kernels as K
+    sr = net(lr.cuda())
+    mse = K.mse_loss(sr, hr.cuda())
+    (mse * 100).backward()
+    assert rel_to_max(sr, g["sr"]) < 1e-3
+    assert abs(mse.item() - float(g["mse"])) < 1e-3 * float(g["mse"])
+    P = dict(net.named_parameters())
+    assert rel_to_max(P["block1.0.weight"].grad, g["g_block1_w"]) < 2e-2
+    assert rel_to_max(P["block8.1.bias"].grad, g["g_block8_b"]) < 2e-2
+    assert rel_to_max(P["stn_head.stn_fc2.weight"].grad, g["g_fc2_w"]) < 2e-2
+    assert rel_to_max(P["block2.conv1.weight"].grad, g["g_b2c1_w"]) < 2e-2
+    sd = net.state_dict()
+    assert rel_to_max(sd["block2.bn1.running_mean"], g["bn_rm"]) < 1e-3
+    assert rel_to_max(sd["block2.bn1.running_var"], g["bn_rv"]) < 1e-3
+    top = max(v for v in gn.values() if v is not None)
+    bad = []
+    for k, v in gn.items():
+        got = P[k].grad
+        if v is None:
+            if got is not None and float(got.abs().max()) != 0.0:
+                bad.append((k, "dead parameter has a gradient"))
+        else:
+            gv = float(got.norm()) if got is not None else float("nan")
+            if not abs(gv - v) <= 2e-2 * v + 1e-4 * top:
+                bad.append((k, gv, v))
+    assert not bad, bad[:10]
+
+
+def test_crnn_leg_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "crnn_leg.npz"))
+    _, rec, _ = build()
+    from fudanocr_amd import kernels as K
+    img = torch.rand(4, 3, 32, 128, generator=torch.Generator().manual_seed(77))
+    gray = K.bicubic_gray(img.cuda(), 100)
+    assert rel_to_max(gray, g["gray"]) < 1e-5
+    with torch.no_grad():
+        logits = rec(gray)
+    assert rel_to_max(logits, g["logits"]) < 1e-3
+
+
+def test_e2e_ctc_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "tbsrn_e2e_ctc.npz"))
+    gn = json.load(open(os.path.join(golden_dir, "tbsrn_e2e_ctc_gradnorms.json")))
+    net, rec, crit = build()
+    net.train()
+    eval_dropout(net)
+    lr, hr, labels = make_batch(4, 1234)
+    sr = net(lr.cuda())
+    loss, mse, _, ctc = crit(sr, hr.cuda(), labels)
+    (loss * 100).backward()
+    assert rel_to_max(sr, g["sr"]) < 1e-3
+    assert abs(mse.item() - float(g["mse"])) < 1e-3 * float(g["mse"])
+    assert abs(ctc.item() - float(g["ctc"])) < 1e-3 * float(g["ctc"])
+    P = dict(net.named_parameters())
+    assert rel_to_max(P["block1.0.weight"].grad, g["g_block1_w"]) < 2e-2
+    top = max(v for v in gn.values() if v is not None)
+    bad = [(k, float(P[k].grad.norm()), v) for k, v in gn.items()
+           if v is not None and not abs(float(P[k].grad.norm()) - v) <= 2e-2 * v + 1e-4 * top]
+    assert not bad, bad[:10]
+
+
+def test_traj3_golden(golden_dir):
+    """3 optimisation steps through the engine (flat buffers, fused clip+Adam) vs the reference
+    models stepped with torch's own clip_grad_norm_/Adam (fixture F8)."""
+    ref = json.load(open(os.path.join(golden_dir, "tbsrn_traj3.json")))
+    from fudanocr_amd.engine import TrainStep
+    net, rec, crit = build()
+    step = TrainStep(net, crit, dropout=False)
+    for s in range(3):
+        lr, hr, labels = make_batch(4, 1234 + s)
+        out = step(lr.cuda(), hr.cuda(), labels)
+        assert abs(out["loss"].item() - ref["loss"][s]) <= 1e-3 * abs(ref["loss"][s]), (s, out["loss"].item())
+        assert abs(step.opt.grad_norm().item() - ref["grad_norm"][s]) <= 2e-2 * ref["grad_norm"][s]
+    sd = net.state_dict()
+    bad = []
+    for k, v in ref["param_abs_sum"].items():
+        got = float(sd[k].double().abs().sum())
+        if not abs(got - v) <= 1e-3 * v + 1e-6:
+            bad.append((k, got, v))
+    assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize("batch", [8])
+def test_step_vs_oracle_fresh_batch(batch):
+    """One full step (TBSRN + CRNN + CTC) on a fresh seeded batch vs the CPU oracle."""
+    from fudanocr_amd.engine import TrainStep
+    from fudanocr_amd.utils.weight_fill import fill_dict_
+    from oracle import sr_oracle as O
+    net, rec, crit = build()
+    step = TrainStep(net, crit, dropout=False)
+    lr, hr, labels = make_batch(batch, 99)
+    out = step(lr.cuda(), hr.cuda(), labels)
+    P = O.make_params(O.schema_sr("tbsrn"))
+    fill_dict_({k: v.data for k, v in P.items()})
+    C = O.make_params(O.schema_crnn(), requires_grad=False)
+    fill_dict_(C)
+    opt = O.AdamState([v for v in P.values() if v.requires_grad])
+    tgt, tlen = O.encode_labels(labels)
+    r = O.train_step(P, opt, "tbsrn", lr, hr, C, tgt, tlen)
+    assert rel_to_max(out["sr"], r["sr"]) < 1e-3
+    assert abs(out["loss"].item() - r["loss"]) < 1e-3 * abs(r["loss"])
+    assert abs(out["ctc"].item() - r["ctc"]) < 1e-3 * abs(r["ctc"])
+    assert abs(step.opt.grad_norm().item() - r["grad_norm"]) < 2e-2 * r["grad_norm"]
+
+
+def test_full_size_properties():
+    """BASELINE full size (per-GPU batch 128): size-independent checks -- finite loss, output in
+    (-1,1), loss decreases over a few steps on a fixed batch, replicas of the step are
+    deterministic up to atomics noise."""
+    from fudanocr_amd.engine import TrainStep
+    net, rec, crit = build()
+    step = TrainStep(net, crit, dropout=True)
+    lr, hr, labels = make_batch(128, 7)
+    lr, hr = lr.cuda(), hr.cuda()
+    enc = crit.encode(labels, lr.device)
+    losses = []
+    for _ in range(6):
+        out = step(lr, hr, encoded=enc)
+        losses.append(out["loss"].item())
+    assert all(np.isfinite(losses)), losses
+    assert out["sr"].abs().max().item() < 1.0
+    assert losses[-1] < losses[0], losses
