@@ -47,9 +47,9 @@ class TPSSpatialTransformer(nn.Module):
                                 indexing="ij")
         xy = torch.stack([gx.reshape(-1) / (w - 1), gy.reshape(-1) / (h - 1)], 1)
         rep = torch.cat([_tps_basis(xy, ctrl), torch.ones(h * w, 1), xy], 1)
-        self.register_buffer("inverse_kernel", torch.inverse(system))
+        self.register_buffer("inverse_kernel", torch.inverse(system).contiguous())
         self.register_buffer("padding_matrix", torch.zeros(3, 2))
-        self.register_buffer("target_coordinate_repr", rep)
+        self.register_buffer("target_coordinate_repr", rep.contiguous())
         self.register_buffer("target_control_points", ctrl)
 
     def forward(self, input, source_control_points):

@@ -305,6 +305,9 @@ def test_tps_warp():
     inv, rep, ctrl0 = O.tps_constants()
     g = torch.Generator().manual_seed(3)
     ctrl = ctrl0[None].repeat(3, 1, 1).double()
+    # sample 0: the STN's initial frame (0.01 margin, a slight zoom).  The exact identity would put
+    # the border pixels ON the clamp boundary, where the gradient is a rounding-noise coin flip.
+    ctrl[0] = O.stn_fc2_bias().view(20, 2).double()
     ctrl[1] += (torch.rand(20, 2, generator=g, dtype=torch.float64) - 0.5) * 0.2
     ctrl[2] += (torch.rand(20, 2, generator=g, dtype=torch.float64) - 0.5) * 0.6     # leaves [0,1]: clamp path
     ctrl.requires_grad_(True)
