@@ -13,8 +13,8 @@ P, I, L, F, U = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ct
 
 # name -> argument types (every entry point returns int and takes the stream last)
 SIGNATURES = {
-    "focr_conv2d_fwd": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, I, P],
-    "focr_conv2d_wgrad": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "focr_conv2d_fwd": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, I, I, P],
+    "focr_conv2d_wgrad": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     "focr_weight_flip_transpose": [P, P, I, I, I, I, P],
     "focr_colsum": [P, P, L, I, I, P],
     "focr_attention_fwd": [P, P, P, P, P, I, I, I, I, F, F, U, P],
@@ -46,6 +46,10 @@ SIGNATURES = {
     "focr_bicubic_gray_bwd": [P, P, I, I, I, I, I, P],
     "focr_lstm_bidir_fwd": [P, P, P, P, P, P, I, I, I, I, I, P],
     "focr_lstm_bidir_bwd": [P, P, P, P, P, P, I, I, I, I, I, P],
+    "focr_gru_bidir_fwd": [P, P, P, P, P, I, I, I, I, I, I, P],
+    "focr_gru_bidir_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "focr_conv9x9_small_cout_fwd": [P, P, P, P, I, I, I, I, I, P],
+    "focr_conv9x9_small_cout_wgrad": [P, P, P, P, I, I, I, I, I, P],
     "focr_ctc_fwd": [P, P, P, P, P, P, P, I, I, I, P],
     "focr_scale_dev": [P, P, P, L, P],
     "focr_grad_sumsq": [P, P, L, F, P],

@@ -32,6 +32,7 @@ struct ConvGeom {
   int M;                  // N*OH*OW
   int ldy;                // output row pitch (floats) >= Cout
   int ldr;                // residual row pitch
+  int ldx;                // input pixel pitch (floats) >= Cin
 };
 
 // ---------------------------------------------------------------------------------------
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
         int iy = riy[i] + kh, ix = rix[i] + kw;
         bool ok = (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) v = *reinterpret_cast<const float4*>(X + ((size_t)(rbase[i] + iy * g.W + ix) * g.Cin + ci0));
+        if (ok) v = *reinterpret_cast<const float4*>(X + ((size_t)(rbase[i] + iy * g.W + ix) * g.ldx + ci0));
         areg[i] = v;
       }
 #pragma unroll
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
       for (int i = 0; i < 16; ++i) {
         int iy = riy[i] + kh, ix = rix[i] + kw;
         bool ok = kok && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-        asc[i] = ok ? X[(size_t)(rbase[i] + iy * g.W + ix) * g.Cin + ci] : 0.f;
+        asc[i] = ok ? X[(size_t)(rbase[i] + iy * g.W + ix) * g.ldx + ci] : 0.f;
       }
 #pragma unroll
       for (int i = 0; i < BV; ++i) {
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
           int oy = rem / g.OW, ox = rem - oy * g.OW;
           int iy = oy - g.padH + tapkh, ix = ox - g.padW + tapkw;
           if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
-            xv = *reinterpret_cast<const float4*>(X + ((size_t)((n * g.H + iy) * g.W + ix) * g.Cin + ci0));
+            xv = *reinterpret_cast<const float4*>(X + ((size_t)((n * g.H + iy) * g.W + ix) * g.ldx + ci0));
         }
         *reinterpret_cast<float4*>(&Ds[row * WP + (tid & 15) * 4]) = dv;
         *reinterpret_cast<float4*>(&Xs[row * WP + (tid & 15) * 4]) = xv;
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
             int oy = rem / g.OW, ox = rem - oy * g.OW;
             int iy = oy - g.padH + tapkh, ix = ox - g.padW + tapkw;
             if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
-              xv = X[(size_t)((n * g.H + iy) * g.W + ix) * g.Cin + ci0];
+              xv = X[(size_t)((n * g.H + iy) * g.W + ix) * g.ldx + ci0];
           }
         }
         Ds[row * WP + (tid & 63)] = dv;
@@ -359,21 +360,22 @@ static int fill_geom(ConvGeom& g, int N, int H, int W, int Cin, int Cout, int KH
   if (g.OH <= 0 || g.OW <= 0 || M <= 0 || M > 0x7fffffffL) return -1;
   if ((long)N * H * W * Cin > 0x7fffffffL * 4L) return -1;
   g.M = (int)M;
-  g.ldy = Cout; g.ldr = Cout;
+  g.ldy = Cout; g.ldr = Cout; g.ldx = Cin;
   return 0;
 }
 
 extern "C" int focr_conv2d_fwd(const float* x, const float* w, const float* bias,
                                const float* residual, float* y, int N, int H, int W, int Cin,
                                int Cout, int KH, int KW, int padH, int padW, float alpha, int relu,
-                               int ldy, int ldr, hipStream_t stream) {
+                               int ldy, int ldr, int ldx, hipStream_t stream) {
   ConvGeom g;
   FOCR_CHECK_ARG(x && w && y, "null pointer");
   FOCR_CHECK_ARG(fill_geom(g, N, H, W, Cin, Cout, KH, KW, padH, padW) == 0, "bad geometry");
   if (ldy > 0) g.ldy = ldy;
   if (ldr > 0) g.ldr = ldr;
-  FOCR_CHECK_ARG(g.ldy >= Cout && g.ldr >= Cout, "row pitch smaller than Cout");
-  bool vec = (Cin % BK == 0);
+  if (ldx > 0) g.ldx = ldx;
+  FOCR_CHECK_ARG(g.ldy >= Cout && g.ldr >= Cout && g.ldx >= Cin, "row pitch too small");
+  bool vec = (Cin % BK == 0) && (g.ldx % 4 == 0);
   bool wide = Cout > 32;
   dim3 grid(cdiv(g.M, BM), cdiv(Cout, wide ? 64 : 32));
   if (vec && wide)
@@ -391,17 +393,18 @@ extern "C" int focr_conv2d_fwd(const float* x, const float* w, const float* bias
 // dw must hold Cout*KH*KW*Cin floats, dbias (nullable) Cout floats; both are overwritten.
 extern "C" int focr_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N,
                                  int H, int W, int Cin, int Cout, int KH, int KW, int padH,
-                                 int padW, int ldd, hipStream_t stream) {
+                                 int padW, int ldd, int ldx, hipStream_t stream) {
   ConvGeom g;
   FOCR_CHECK_ARG(x && dy && dw, "null pointer");
   FOCR_CHECK_ARG(fill_geom(g, N, H, W, Cin, Cout, KH, KW, padH, padW) == 0, "bad geometry");
   if (ldd <= 0) ldd = Cout;
-  FOCR_CHECK_ARG(ldd >= Cout, "row pitch smaller than Cout");
+  if (ldx > 0) g.ldx = ldx;
+  FOCR_CHECK_ARG(ldd >= Cout && g.ldx >= Cin, "row pitch too small");
   if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cout * g.Ktot, stream) != hipSuccess) {
     focr_set_error("focr_conv2d_wgrad: memset failed");
     return FOCR_EHIP;
   }
-  bool vec = (Cin % 64 == 0) && (ldd % 4 == 0);
+  bool vec = (Cin % 64 == 0) && (ldd % 4 == 0) && (g.ldx % 4 == 0);
   int tiles = cdiv(g.Ktot, 64) * cdiv(Cout, 64);
   int splits = 2048 / tiles;
   int maxsplits = cdiv(g.M, 128);

@@ -168,3 +168,211 @@ extern "C" int focr_lstm_bidir_bwd(const float* dhseq, const float* whh, const f
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }
+
+// =======================================================================================
+// Bidirectional GRU of the TSRN SRB (model/tsrn.py:128-145: nn.GRU(64, 32, bidirectional,
+// batch_first), gate order (r,z,n), zero initial state).
+//
+// Wavefront scan: one wave owns 32 sequences of one direction for the WHOLE time loop -- one
+// launch per GruBlock, no per-step launches, no LDS, no barriers.  The trick is the operand
+// orientation of the f32 32x32x2 MFMA:  G^T[gate unit][seq] = sum_k W_hh[gate unit][k] h[seq][k]
+//   A = W_hh rows (constant, 48 VGPRs for the 3 gates), B = h.
+// The accumulator layout (lane = seq, register s <-> hidden unit u(s,half)) is exactly the B
+// operand layout of the next step when the K index is enumerated as k = u(s,half), so the hidden
+// state never leaves the accumulator registers between time steps.  The backward uses the same
+// identity with A = W_hh^T.
+// Map addressing: row(n,t) = (n/IC)*OS + (n%IC)*IS + t*TS  (see include/focr.h).
+// =======================================================================================
+#define GH 32
+__device__ __forceinline__ int unit_of(int s, int lh) { return (s & 3) + 8 * (s >> 2) + 4 * lh; }
+
+__global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ gx,
+                                                      const float* __restrict__ whh,
+                                                      const float* __restrict__ bhh,
+                                                      float* __restrict__ hseq, float* __restrict__ gates,
+                                                      int nseq, int T, int IC, int OS, int IS, int TS) {
+  const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int dir = wid & 1, grp = wid >> 1;
+  if (grp * 32 >= nseq) return;
+  const int seq = grp * 32 + li;
+  const bool valid = seq < nseq;
+  const int sc = valid ? seq : nseq - 1;
+  const long base_row = (long)(sc / IC) * OS + (long)(sc % IC) * IS;
+
+  float4 wa[3][4], bh[3][4];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      wa[g][q] = *reinterpret_cast<const float4*>(whh + ((size_t)dir * 96 + g * 32 + li) * GH + 8 * q + 4 * lh);
+      bh[g][q] = *reinterpret_cast<const float4*>(bhh + (size_t)dir * 96 + g * 32 + 8 * q + 4 * lh);
+    }
+  f32x16 h;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) h[r] = 0.f;
+
+  for (int step = 0; step < T; ++step) {
+    const int t = dir ? T - 1 - step : step;
+    const long row = base_row + (long)t * TS;
+    const float* gxr = gx + (size_t)row * 192 + dir * 96;
+    float4 xg[3][4];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xg[g][q] = *reinterpret_cast<const float4*>(gxr + g * 32 + 8 * q + 4 * lh);
+    f32x16 ar, az, an;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ar[r] = 0.f; az[r] = 0.f; an[r] = 0.f; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float wr[4] = {wa[0][q].x, wa[0][q].y, wa[0][q].z, wa[0][q].w};
+      const float wz[4] = {wa[1][q].x, wa[1][q].y, wa[1][q].z, wa[1][q].w};
+      const float wn[4] = {wa[2][q].x, wa[2][q].y, wa[2][q].z, wa[2][q].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ar = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[e], h[4 * q + e], ar, 0, 0, 0);
+        az = __builtin_amdgcn_mfma_f32_32x32x2f32(wz[e], h[4 * q + e], az, 0, 0, 0);
+        an = __builtin_amdgcn_mfma_f32_32x32x2f32(wn[e], h[4 * q + e], an, 0, 0, 0);
+      }
+    }
+    float* grow = gates + ((size_t)row * 2 + dir) * 128;
+    float* hrow = hseq + (size_t)row * 64 + dir * 32;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float xr[4] = {xg[0][q].x, xg[0][q].y, xg[0][q].z, xg[0][q].w};
+      const float xz[4] = {xg[1][q].x, xg[1][q].y, xg[1][q].z, xg[1][q].w};
+      const float xn[4] = {xg[2][q].x, xg[2][q].y, xg[2][q].z, xg[2][q].w};
+      const float br[4] = {bh[0][q].x, bh[0][q].y, bh[0][q].z, bh[0][q].w};
+      const float bz[4] = {bh[1][q].x, bh[1][q].y, bh[1][q].z, bh[1][q].w};
+      const float bn[4] = {bh[2][q].x, bh[2][q].y, bh[2][q].z, bh[2][q].w};
+      float rr[4], zz[4], nn[4], hn[4], hv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int s = 4 * q + e;
+        rr[e] = sigmoidf_(xr[e] + ar[s] + br[e]);
+        zz[e] = sigmoidf_(xz[e] + az[s] + bz[e]);
+        hn[e] = an[s] + bn[e];
+        nn[e] = tanhf(xn[e] + rr[e] * hn[e]);
+        hv[e] = (1.f - zz[e]) * nn[e] + zz[e] * h[s];
+        h[s] = hv[e];
+      }
+      if (valid) {
+        const int u = 8 * q + 4 * lh;
+        *reinterpret_cast<float4*>(grow + u) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+        *reinterpret_cast<float4*>(grow + 32 + u) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+        *reinterpret_cast<float4*>(grow + 64 + u) = make_float4(nn[0], nn[1], nn[2], nn[3]);
+        *reinterpret_cast<float4*>(grow + 96 + u) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+        *reinterpret_cast<float4*>(hrow + u) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ dhseq,
+                                                      const float* __restrict__ whh,
+                                                      const float* __restrict__ gates,
+                                                      const float* __restrict__ hseq, float* __restrict__ dgx,
+                                                      float* __restrict__ dgh, float* __restrict__ hprev,
+                                                      int nseq, int T, int IC, int OS, int IS, int TS) {
+  const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int dir = wid & 1, grp = wid >> 1;
+  if (grp * 32 >= nseq) return;
+  const int seq = grp * 32 + li;
+  const bool valid = seq < nseq;
+  const int sc = valid ? seq : nseq - 1;
+  const long base_row = (long)(sc / IC) * OS + (long)(sc % IC) * IS;
+
+  // A operand of dh_prev^T[k][seq] = sum_j W_hh[j][k] dg[seq][j]:  lane (k = li), step s -> j = u(s,lh)
+  float wt[3][16];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) wt[g][s] = whh[((size_t)dir * 96 + g * 32 + unit_of(s, lh)) * GH + li];
+  f32x16 dh;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dh[r] = 0.f;
+
+  for (int step = 0; step < T; ++step) {
+    const int t = dir ? step : T - 1 - step;               // reverse of the forward order
+    const bool has_prev = dir ? (t < T - 1) : (t > 0);
+    const long row = base_row + (long)t * TS;
+    const long prow = base_row + (long)(dir ? t + 1 : t - 1) * TS;
+    const float* grow = gates + ((size_t)row * 2 + dir) * 128;
+    float dar[16], daz[16], dhn[16], dhp[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int u = 8 * q + 4 * lh;
+      float4 g4 = *reinterpret_cast<const float4*>(dhseq + (size_t)row * 64 + dir * 32 + u);
+      float4 r4 = *reinterpret_cast<const float4*>(grow + u);
+      float4 z4 = *reinterpret_cast<const float4*>(grow + 32 + u);
+      float4 n4 = *reinterpret_cast<const float4*>(grow + 64 + u);
+      float4 h4 = *reinterpret_cast<const float4*>(grow + 96 + u);
+      float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (has_prev) p4 = *reinterpret_cast<const float4*>(hseq + (size_t)prow * 64 + dir * 32 + u);
+      const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
+      const float zz[4] = {z4.x, z4.y, z4.z, z4.w}, nn[4] = {n4.x, n4.y, n4.z, n4.w};
+      const float hn[4] = {h4.x, h4.y, h4.z, h4.w}, hp[4] = {p4.x, p4.y, p4.z, p4.w};
+      float o_r[4], o_z[4], o_n[4], o_h[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int s = 4 * q + e;
+        float dht = gg[e] + dh[s];
+        float dn = dht * (1.f - zz[e]);
+        float dz = dht * (hp[e] - nn[e]);
+        dhp[s] = dht * zz[e];
+        float dan = dn * (1.f - nn[e] * nn[e]);
+        o_n[e] = dan;
+        o_r[e] = dan * hn[e] * rr[e] * (1.f - rr[e]);
+        o_h[e] = dan * rr[e];
+        o_z[e] = dz * zz[e] * (1.f - zz[e]);
+        dar[s] = o_r[e]; daz[s] = o_z[e]; dhn[s] = o_h[e];
+      }
+      if (valid) {
+        float* xo = dgx + (size_t)row * 192 + dir * 96;
+        float* ho = dgh + (size_t)row * 192 + dir * 96;
+        *reinterpret_cast<float4*>(xo + u) = make_float4(o_r[0], o_r[1], o_r[2], o_r[3]);
+        *reinterpret_cast<float4*>(xo + 32 + u) = make_float4(o_z[0], o_z[1], o_z[2], o_z[3]);
+        *reinterpret_cast<float4*>(xo + 64 + u) = make_float4(o_n[0], o_n[1], o_n[2], o_n[3]);
+        *reinterpret_cast<float4*>(ho + u) = make_float4(o_r[0], o_r[1], o_r[2], o_r[3]);
+        *reinterpret_cast<float4*>(ho + 32 + u) = make_float4(o_z[0], o_z[1], o_z[2], o_z[3]);
+        *reinterpret_cast<float4*>(ho + 64 + u) = make_float4(o_h[0], o_h[1], o_h[2], o_h[3]);
+        *reinterpret_cast<float4*>(hprev + ((size_t)row * 2 + dir) * 32 + u) = p4;
+      }
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = dhp[r];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[0][s], dar[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[1][s], daz[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[2][s], dhn[s], acc, 0, 0, 0);
+    }
+    dh = acc;
+  }
+}
+
+extern "C" int focr_gru_bidir_fwd(const float* gx, const float* whh, const float* bhh, float* hseq,
+                                  float* gates, int nseq, int T, int IC, int OS, int IS, int TS,
+                                  hipStream_t stream) {
+  FOCR_CHECK_ARG(gx && whh && bhh && hseq && gates, "null pointer");
+  FOCR_CHECK_ARG(nseq > 0 && T > 0 && IC > 0, "bad argument");
+  int waves = cdiv(nseq, 32) * 2;
+  hipLaunchKernelGGL(gru_fwd_kernel, dim3(cdiv(waves, 4)), 256, 0, stream, gx, whh, bhh, hseq, gates, nseq, T, IC,
+                     OS, IS, TS);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+extern "C" int focr_gru_bidir_bwd(const float* dhseq, const float* whh, const float* gates,
+                                  const float* hseq, float* dgx, float* dgh, float* hprev, int nseq, int T,
+                                  int IC, int OS, int IS, int TS, hipStream_t stream) {
+  FOCR_CHECK_ARG(dhseq && whh && gates && hseq && dgx && dgh && hprev, "null pointer");
+  FOCR_CHECK_ARG(nseq > 0 && T > 0 && IC > 0, "bad argument");
+  int waves = cdiv(nseq, 32) * 2;
+  hipLaunchKernelGGL(gru_bwd_kernel, dim3(cdiv(waves, 4)), 256, 0, stream, dhseq, whh, gates, hseq, dgx, dgh,
+                     hprev, nseq, T, IC, OS, IS, TS);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}

@@ -51,12 +51,22 @@ def _new_seed():
 # ----------------------------------------------------------------------------------------
 # convolution / linear
 # ----------------------------------------------------------------------------------------
+def _is_out_layer(cin, cout, kh, kw, ph, pw, w, residual, alpha, relu):
+    """SR output layer shape handled by csrc/conv9x9_out.hip (taps folded into the MFMA N dim)."""
+    return (kh == 9 and kw == 9 and ph == 4 and pw == 4 and cin == 64 and cout <= 3 and w % 32 == 0
+            and w <= 128 and residual is None and alpha == 1.0 and not relu)
+
+
 def _conv_fwd_raw(x4, w_ohwi, bias, residual, cout, kh, kw, ph, pw, alpha, relu):
     n, h, w, cin = x4.shape
     oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
     y = torch.empty((n, oh, ow, cout), device=x4.device, dtype=torch.float32)
+    if _is_out_layer(cin, cout, kh, kw, ph, pw, w, residual, alpha, relu):
+        _lib.call("focr_conv9x9_small_cout_fwd", _p(x4), _p(w_ohwi), _p(bias), _p(y), n, h, w, cin, cout,
+                  _stream())
+        return y
     _lib.call("focr_conv2d_fwd", _p(x4), _p(w_ohwi), _p(bias), _p(residual), _p(y), n, h, w, cin, cout,
-              kh, kw, ph, pw, float(alpha), int(relu), 0, 0, _stream())
+              kh, kw, ph, pw, float(alpha), int(relu), 0, 0, 0, _stream())
     return y
 
 
@@ -112,8 +122,12 @@ class _Conv2d(torch.autograd.Function):
             need_db = has_bias and ctx.needs_input_grad[2]
             if need_db:
                 db = torch.empty(cout, device=dy.device, dtype=torch.float32)
-            _lib.call("focr_conv2d_wgrad", _p(x4), _p(dy4), _p(dw), _p(db), n, h, w, cin, cout, kh, kw, ph,
-                      pw, 0, _stream())
+            if _is_out_layer(cin, cout, kh, kw, ph, pw, w, None, alpha, relu) and not has_res:
+                _lib.call("focr_conv9x9_small_cout_wgrad", _p(x4), _p(dy4), _p(dw), _p(db), n, h, w, cin,
+                          cout, _stream())
+            else:
+                _lib.call("focr_conv2d_wgrad", _p(x4), _p(dy4), _p(dw), _p(db), n, h, w, cin, cout, kh, kw,
+                          ph, pw, 0, 0, _stream())
             if alpha != 1.0:
                 _lib.call("focr_axpy", _p(dw), _NULL, _p(dw), dw.numel(), alpha, _stream())
         elif has_bias and ctx.needs_input_grad[2]:
@@ -590,6 +604,69 @@ class _LSTMRecur(torch.autograd.Function):
 
 def lstm_recurrence(gx, whh, bhh, t_len, batch, st_t, st_b):
     return _LSTMRecur.apply(gx, whh, bhh, t_len, batch, st_t, st_b)
+
+
+# ----------------------------------------------------------------------------------------
+# bidirectional GRU of the TSRN blocks (recurrent part; the input projection is a `linear`)
+# ----------------------------------------------------------------------------------------
+def _po(t, off):
+    return ctypes.c_void_p(t.data_ptr() + 4 * off)
+
+
+class _GRURecur(torch.autograd.Function):
+    """gx [rows,192] (= x W_ih^T + b_ih, both directions), whh [2,96,32], bhh [2,96] -> h [rows,64].
+    Sequences are addressed in place on the NHWC map: row(n,t) = (n//IC)*OS + (n%IC)*IS + t*TS."""
+
+    @staticmethod
+    def forward(ctx, gx, whh, bhh, nseq, t_len, ic, os_, is_, ts):
+        _chk(gx, whh, bhh)
+        rows = gx.shape[0]
+        assert nseq * t_len == rows and whh.shape == (2, 96, 32)
+        hseq = torch.empty((rows, 64), device=gx.device)
+        gates = torch.empty((rows, 2, 128), device=gx.device)
+        _lib.call("focr_gru_bidir_fwd", _p(gx), _p(whh), _p(bhh), _p(hseq), _p(gates), nseq, t_len, ic, os_,
+                  is_, ts, _stream())
+        ctx.cfg = (rows, nseq, t_len, ic, os_, is_, ts)
+        ctx.save_for_backward(whh, gates, hseq)
+        return hseq
+
+    @staticmethod
+    def backward(ctx, dh):
+        whh, gates, hseq = ctx.saved_tensors
+        rows, nseq, t_len, ic, os_, is_, ts = ctx.cfg
+        dh = dh.contiguous()
+        dgx = torch.empty((rows, 192), device=dh.device)
+        dgh = torch.empty((rows, 192), device=dh.device)
+        hprev = torch.empty((rows, 2, 32), device=dh.device)
+        _lib.call("focr_gru_bidir_bwd", _p(dh), _p(whh), _p(gates), _p(hseq), _p(dgx), _p(dgh), _p(hprev), nseq,
+                  t_len, ic, os_, is_, ts, _stream())
+        dwhh = torch.empty((2, 96, 32), device=dh.device)
+        dbhh = torch.empty((2, 96), device=dh.device)
+        for d in (0, 1):     # dW_hh[d] = dgh[:, d]^T hprev[:, d]  -- the generic wgrad on strided views
+            _lib.call("focr_conv2d_wgrad", _po(hprev, 32 * d), _po(dgh, 96 * d), _po(dwhh, 96 * 32 * d),
+                      _po(dbhh, 96 * d), rows, 1, 1, 32, 96, 1, 1, 0, 0, 192, 64, _stream())
+        return dgx, dwhh, dbhh, None, None, None, None, None, None
+
+
+def gru_recurrence(gx, whh, bhh, nseq, t_len, ic, os_, is_, ts):
+    return _GRURecur.apply(gx, whh, bhh, nseq, t_len, ic, os_, is_, ts)
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _chk(a, b)
+        y = torch.empty_like(a)
+        _lib.call("focr_axpy", _p(a), _p(b), _p(y), a.numel(), 1.0, _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    return _Add.apply(a, b)
 
 
 # ----------------------------------------------------------------------------------------

@@ -1,0 +1,178 @@
+/* libfocr_hip.so -- C ABI of the MI355X (gfx950) kernels behind the FudanOCR
+ * scene-text-telescope / text-gestalt SR + CRNN-CTC training hot path.
+ *
+ * The reference has NO native/FFI layer for this path (pure Python/PyTorch):
+ * each entry point below replaces a torch op at the cited reference call site (paths under
+ * /root/reference/scene-text-telescope/).  The binding a reference maintainer would add is a
+ * ctypes stub; the in-tree one is fudanocr_amd/_lib.py.
+ *
+ * Conventions
+ *  - plain C types only; every pointer is a DEVICE pointer to fp32 data unless noted;
+ *  - activations are channel-last: [N,H,W,C] or [rows,C], contiguous;
+ *  - conv weights are [Cout][KH][KW][Cin] (a torch channels_last [Cout,Cin,KH,KW] tensor);
+ *  - the library never allocates, frees or retains device memory; workspaces are caller-owned;
+ *  - every call is asynchronous on `stream`, re-entrant, and never synchronises the device;
+ *  - return 0 on success, <0 on failure (FOCR_E*); message via focr_last_error() (thread-local).
+ */
+#ifndef FOCR_H
+#define FOCR_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* focr_stream_t; /* hipStream_t */
+
+#define FOCR_OK 0
+#define FOCR_EINVAL (-1)
+#define FOCR_EUNSUPPORTED (-2)
+#define FOCR_EHIP (-3)
+
+#define FOCR_ACT_NONE 0
+#define FOCR_ACT_RELU 1
+#define FOCR_ACT_MISH 4
+
+const char* focr_last_error(void);
+int focr_version(void);
+
+/* ---- convolution / linear: nn.Conv2d, nn.Linear (stride 1) --------------------------------
+ * model/tsrn.py:26-43,80-94,101-114,132  model/tbsrn.py:74,103,117-129,158-163
+ * model/stn_head.py:13-49,88-99          model/crnn/crnn.py:31-63,12,19
+ * y = [relu](alpha * conv(x,w) + bias + residual); ldy/ldr/ldx = row pitch of y/residual/x
+ * (0: dense).
+ * dgrad = the same call on focr_weight_flip_transpose()d weights with pad' = K-1-pad. */
+int focr_conv2d_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
+                    int N, int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW,
+                    float alpha, int relu, int ldy, int ldr, int ldx, focr_stream_t stream);
+/* dw[Cout][KH][KW][Cin], dbias[Cout] (nullable) are overwritten; ldd = row pitch of dy (0: Cout) */
+int focr_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N, int H, int W,
+                      int Cin, int Cout, int KH, int KW, int padH, int padW, int ldd, int ldx,
+                      focr_stream_t stream);
+/* w[Cout][KH][KW][Cin] -> wd[Cin][KH][KW][Cout] with both spatial axes flipped */
+int focr_weight_flip_transpose(const float* w, float* wd, int Cout, int KH, int KW, int Cin,
+                               focr_stream_t stream);
+/* out[c] = sum_r x[r*ld + c]   (bias gradients) */
+int focr_colsum(const float* x, float* out, long rows, int C, int ld, focr_stream_t stream);
+/* specialised 9x9, pad 4, Cin=64 -> Cout<=3|4 convolution (SR output layer, model/tsrn.py:43):
+ * the 9 horizontal taps are folded into the MFMA N dimension ((co,kw) = 27..36 columns) */
+int focr_conv9x9_small_cout_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H,
+                                int W, int Cin, int Cout, focr_stream_t stream);
+int focr_conv9x9_small_cout_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N, int H,
+                                  int W, int Cin, int Cout, focr_stream_t stream);
+
+/* ---- fused attention: model/tbsrn.py:132-150 (+ the head split/merge of :116-126) -----------
+ * q,k,v,o: [B,Ntok,ld], head h in columns h*32..h*32+31; lse: [B,H,Ntok]; Ntok % 128 == 0.
+ * p_drop: dropout on the probabilities (tbsrn.py:147-148), mask = hash(seed, b,h,q,key). */
+int focr_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B,
+                       int H, int Ntok, int ld, float scale, float p_drop, uint64_t seed,
+                       focr_stream_t stream);
+/* dwork: B*H*Ntok floats */
+int focr_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o,
+                       const float* lse, float* dq, float* dk, float* dv, float* dwork, int B, int H,
+                       int Ntok, int ld, float scale, float p_drop, uint64_t seed, focr_stream_t stream);
+
+/* ---- BatchNorm2d/1d (+activation, +residual): model/tsrn.py:81-86,35-39, stn_head.py:17-21,45-48,
+ *      crnn.py:44 ; torch semantics (biased var to normalise, unbiased in the running update) --- */
+int focr_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, long long* num_batches_tracked, const float* residual,
+                      float* y, float* save_mean, float* save_invstd, float* ws /*2C*/, long rows, int C,
+                      float momentum, float eps, int act, focr_stream_t stream);
+int focr_bn_eval_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean,
+                     const float* running_var, const float* residual, float* y, float* invstd_out,
+                     long rows, int C, float eps, int act, focr_stream_t stream);
+int focr_bn_bwd(const float* dz, const float* x, const float* gamma, const float* beta, const float* mean,
+                const float* invstd, float* dx, float* dgamma, float* dbeta, float* ws /*2C*/, long rows,
+                int C, int act, int train, focr_stream_t stream);
+
+/* ---- the reference's own LayerNorm (unbiased std, eps on std): model/tbsrn.py:23-36 ---------- */
+int focr_layernorm_fwd(const float* x, const float* residual, const float* a, const float* b, float* y,
+                       float* save_mean, float* save_rinv, long rows, int D, float eps,
+                       focr_stream_t stream);
+int focr_layernorm_bwd(const float* dy, const float* x, const float* residual, const float* a,
+                       const float* save_mean, const float* save_rinv, float* dx, float* da, float* db,
+                       long rows, int D, float eps, focr_stream_t stream);
+
+/* ---- activations / layout -------------------------------------------------------------------
+ * PReLU (single slope) tsrn.py:28; PixelShuffle(2)+mish tsrn.py:101-125; tanh tsrn.py:73 */
+int focr_prelu_fwd(const float* x, const float* slope, float* y, long n, focr_stream_t stream);
+int focr_prelu_bwd(const float* dy, const float* x, const float* slope, float* dx, float* dslope, long n,
+                   focr_stream_t stream);
+int focr_pixelshuffle_mish_fwd(const float* pre, float* z, int N, int H, int W, int C, focr_stream_t stream);
+int focr_pixelshuffle_mish_bwd(const float* dz, const float* pre, float* dpre, int N, int H, int W, int C,
+                               focr_stream_t stream);
+int focr_nchw_to_nhwc(const float* x, float* y, int N, int C, int HW, focr_stream_t stream);
+int focr_nhwc_to_nchw(const float* x, float* y, int N, int C, int HW, int do_tanh, focr_stream_t stream);
+int focr_tanh_bwd_to_nhwc(const float* dy_nchw, const float* y_nchw, float* dx_nhwc, int N, int C, int HW,
+                          focr_stream_t stream);
+int focr_relu_bwd(const float* dy, const float* y, float* dx, long n, focr_stream_t stream);
+/* tokens = [feat | positional encoding] tbsrn.py:83-86 ; column slice (+add) for its backward */
+int focr_concat_pe(const float* feat, const float* pe, float* tok, long rows, int Cf, int Cp, int T,
+                   focr_stream_t stream);
+int focr_slice_cols(const float* x, const float* add, float* out, long rows, int ld, int c0, int w,
+                    focr_stream_t stream);
+/* nn.Dropout tbsrn.py:160,163 : y = keep ? x/(1-p) : 0 ; the same call is its backward */
+int focr_dropout(const float* x, float* y, long n, float p, uint64_t seed, focr_stream_t stream);
+/* nn.MSELoss loss/text_focus_loss.py:44,86 ; upstream = device scalar */
+int focr_mse_fwd(const float* a, const float* b, float* out, long n, focr_stream_t stream);
+int focr_mse_bwd(const float* a, const float* b, const float* upstream, float* da, long n,
+                 focr_stream_t stream);
+int focr_axpy(const float* x, const float* add, float* y, long n, float alpha, focr_stream_t stream);
+int focr_scale_dev(const float* x, const float* s, float* y, long n, focr_stream_t stream);
+
+/* ---- pooling / resampling -------------------------------------------------------------------
+ * nn.MaxPool2d stn_head.py:34-42, crnn.py:52-62 (idx: uint8 window-local argmax) */
+int focr_maxpool_fwd(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, int kh, int kw,
+                     int sh, int sw, int ph, int pw, focr_stream_t stream);
+int focr_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int N, int H, int W, int C, int kh,
+                     int kw, int sh, int sw, int ph, int pw, focr_stream_t stream);
+/* TPS grid + F.grid_sample: model/tps_spatial_transformer.py:97-111,10-18 ; src: [B,H*W,2] */
+int focr_tps_fwd(const float* img, const float* ctrl, const float* inv_kernel, const float* coord_repr,
+                 float* out, float* src, int B, int H, int W, int C, int NC, focr_stream_t stream);
+int focr_tps_bwd(const float* dout, const float* img, const float* src, const float* inv_kernel,
+                 const float* coord_repr, float* dctrl, int B, int H, int W, int C, int NC,
+                 focr_stream_t stream);
+/* parse_crnn_data: interfaces/base.py:319-325 ; x NCHW [B,Cx>=3,H,IW] -> y [B,H,OW] */
+int focr_bicubic_gray_fwd(const float* x_nchw, float* y, int B, int Cx, int H, int IW, int OW,
+                          focr_stream_t stream);
+int focr_bicubic_gray_bwd(const float* dy, float* dx_nchw, int B, int Cx, int H, int IW, int OW,
+                          focr_stream_t stream);
+
+/* ---- recurrences ---------------------------------------------------------------------------
+ * nn.LSTM(bidirectional) crnn.py:11,15 : gx [rows][2][4H] (row(t,b) = t*st_t + b*st_b),
+ * whh [2][4H][H], bhh [2][4H], hseq [T][B][2H], gates [T][B][2][4H], cseq [T][B][2][H] */
+int focr_lstm_bidir_fwd(const float* gx, const float* whh, const float* bhh, float* hseq, float* gates,
+                        float* cseq, int T, int B, int H, int st_t, int st_b, focr_stream_t stream);
+int focr_lstm_bidir_bwd(const float* dhseq, const float* whh, const float* gates, const float* cseq,
+                        float* dgx, float* dc_carry /*2*B*H*/, int T, int B, int H, int st_t, int st_b,
+                        focr_stream_t stream);
+/* nn.GRU(64, 32, bidirectional, batch_first) tsrn.py:133,141 (gate order r,z,n).  All tensors are
+ * indexed by map row: row(seq n, time t) = (n/IC)*OS + (n%IC)*IS + t*TS, so both the horizontal
+ * (gru2) and the vertical (gru1, reference transposes the map) scans read the NHWC map in place.
+ * gx [rows][2][96] (= x W_ih^T + b_ih), whh [2][96][32], bhh [2][96], hseq [rows][64],
+ * gates [rows][2][128] = (r,z,n, W_hn h + b_hn).  Backward writes dgx (grad of gx), dgh (grad of
+ * W_hh h + b_hh: rows r,z as dgx, row n = d hn) and hprev [rows][2][32] (h_{t-1}) for the W_hh wgrad. */
+int focr_gru_bidir_fwd(const float* gx, const float* whh, const float* bhh, float* hseq, float* gates,
+                       int nseq, int T, int IC, int OS, int IS, int TS, focr_stream_t stream);
+int focr_gru_bidir_bwd(const float* dhseq, const float* whh, const float* gates, const float* hseq,
+                       float* dgx, float* dgh, float* hprev, int nseq, int T, int IC, int OS, int IS,
+                       int TS, focr_stream_t stream);
+
+/* ---- CTC: log_softmax + F.ctc_loss(blank 0, 'mean', zero_infinity) (label codec
+ *      utils/utils_crnn.py:21-53).  logits/grad [T,B,C]; loss: 1 float; nll: B floats ------------ */
+int focr_ctc_fwd(const float* logits, const int* targets, const int* target_lengths,
+                 const int* target_offsets, float* loss, float* nll, float* grad_logits, int T, int B,
+                 int C, focr_stream_t stream);
+
+/* ---- optimiser tail: clip_grad_norm_(0.25) + Adam (interfaces/super_resolution.py:83-84,
+ *      interfaces/base.py:194-198) on flat buffers; gscale = 1/world for DP averaging ----------- */
+int focr_grad_sumsq(const float* g, float* sumsq, long n, float gscale, focr_stream_t stream);
+int focr_clip_adam(float* p, const float* g, float* m, float* v, const float* sumsq, long n, float lr,
+                   float beta1, float beta2, float eps, int step, float max_norm, float gscale,
+                   focr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOCR_H */

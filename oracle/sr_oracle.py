@@ -562,5 +562,5 @@ def train_step(P, opt, arch, lr_img, hr_img, crnn_P=None, targets=None, target_l
     grads = [p.grad for p in opt.params if p.grad is not None]
     gnorm = clip_grad_norm(grads, 0.25)
     opt.step()
-    return {"loss": float(loss), "mse": float(mse), "ctc": None if ctc is None else float(ctc),
+    return {"loss": float(loss.detach()), "mse": float(mse.detach()), "ctc": None if ctc is None else float(ctc.detach()),
             "grad_norm": float(gnorm), "sr": sr.detach()}

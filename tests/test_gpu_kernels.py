@@ -409,3 +409,63 @@ def test_clip_adam():
         close(ss.sqrt(), norm.reshape(1), 1e-5, what="grad norm")
         k.clip_adam(pd, gd, md, vd, ss, 1e-4, 0.5, 0.999, 1e-8, step, 0.25)
         close(pd, pr, 1e-6, what="adam step %d" % step)
+
+
+@pytest.mark.parametrize("vertical", [False, True])
+def test_gru(vertical):
+    """TSRN GruBlock recurrence: both scan directions over an NHWC map, in place."""
+    from oracle import sr_oracle as O
+    b, h, w, c = 3, 16, 24, 64
+    P = {}
+    for suf in ("", "_reverse"):
+        P["weight_ih_l0" + suf] = rnd(96, 64, seed=1 + len(suf), scale=1 / 8).requires_grad_(True)
+        P["weight_hh_l0" + suf] = rnd(96, 32, seed=2 + len(suf), scale=1 / 5).requires_grad_(True)
+        P["bias_ih_l0" + suf] = rnd(96, seed=3 + len(suf), scale=0.1).requires_grad_(True)
+        P["bias_hh_l0" + suf] = rnd(96, seed=4 + len(suf), scale=0.1).requires_grad_(True)
+    x = rnd(b, h, w, c, seed=9).requires_grad_(True)                 # NHWC map
+    if vertical:
+        seq = x.permute(0, 2, 1, 3).reshape(b * w, h, c)
+        y = O.gru_bidir(P, "", seq).view(b, w, h, c).permute(0, 2, 1, 3)
+    else:
+        y = O.gru_bidir(P, "", x.reshape(b * h, w, c)).view(b, h, w, c)
+    gy = rnd(b, h, w, c, seed=10)
+    y.backward(gy)
+    k = K()
+    wih = dev(torch.cat([P["weight_ih_l0"], P["weight_ih_l0_reverse"]], 0)).requires_grad_(True)
+    bih = dev(torch.cat([P["bias_ih_l0"], P["bias_ih_l0_reverse"]], 0)).requires_grad_(True)
+    whh = dev(torch.stack([P["weight_hh_l0"], P["weight_hh_l0_reverse"]], 0)).requires_grad_(True)
+    bhh = dev(torch.stack([P["bias_hh_l0"], P["bias_hh_l0_reverse"]], 0)).requires_grad_(True)
+    xd = dev(x).requires_grad_(True)
+    gx = k.linear(xd.view(b * h * w, c), wih, bih)
+    if vertical:
+        yd = k.gru_recurrence(gx, whh, bhh, b * w, h, w, h * w, 1, w)
+    else:
+        yd = k.gru_recurrence(gx, whh, bhh, b * h, w, 1, w, 0, 1)
+    close(yd.view(b, h, w, c), y, 5e-5, what="gru fwd")
+    yd.backward(dev(gy).view(b * h * w, c))
+    close(xd.grad, x.grad, 1e-4, what="gru dx")
+    close(whh.grad, torch.stack([P["weight_hh_l0"].grad, P["weight_hh_l0_reverse"].grad]), 1e-4, what="gru dWhh")
+    close(bhh.grad, torch.stack([P["bias_hh_l0"].grad, P["bias_hh_l0_reverse"].grad]), 1e-4, what="gru dbhh")
+    close(wih.grad, torch.cat([P["weight_ih_l0"].grad, P["weight_ih_l0_reverse"].grad]), 1e-4, what="gru dWih")
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 128, 3), (2, 32, 64, 3), (1, 4, 32, 2)])
+def test_conv9x9_output_layer(shape):
+    """specialised 64 -> Cout<=3 9x9 kernels (taps folded into N) vs F.conv2d."""
+    n, h, w, cout = shape
+    x = rnd(n, 64, h, w, seed=1).requires_grad_(True)
+    wt = rnd(cout, 64, 9, 9, seed=2, scale=1 / 72).requires_grad_(True)
+    b = rnd(cout, seed=3).requires_grad_(True)
+    y = F.conv2d(x, wt, b, padding=4)
+    gy = rnd(*y.shape, seed=4)
+    y.backward(gy)
+    from fudanocr_amd import kernels
+    assert kernels._is_out_layer(64, cout, 9, 9, 4, 4, w, None, 1.0, False)
+    xd = dev(x.permute(0, 2, 3, 1)).requires_grad_(True)
+    wd, bd = cl(wt), dev(b).requires_grad_(True)
+    yd = kernels.conv2d(xd, wd, bd, pad=(4, 4))
+    close(yd.permute(0, 3, 1, 2), y, what="conv9x9 fwd")
+    yd.backward(dev(gy.permute(0, 2, 3, 1)))
+    close(xd.grad.permute(0, 3, 1, 2), x.grad, what="conv9x9 dgrad")
+    close(wd.grad, wt.grad, 5e-5, what="conv9x9 wgrad")
+    close(bd.grad, b.grad, 5e-5, what="conv9x9 bias grad")

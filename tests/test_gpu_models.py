@@ -36,14 +36,16 @@ def eval_dropout(net):
 def test_state_dict_schema(golden_dir):
     ref = json.load(open(os.path.join(golden_dir, "schema.json")))
     net, rec, _ = build()
-    for name, m in (("tbsrn", net), ("crnn", rec)):
+    tnet, _, _ = build("tsrn")
+    for name, m in (("tbsrn", net), ("crnn", rec), ("tsrn", tnet)):
         mine = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()]
         assert mine == ref[name]
 
 
-def test_tbsrn_eval_golden(golden_dir):
-    g = np.load(os.path.join(golden_dir, "tbsrn_eval.npz"))
-    net, _, _ = build()
+@pytest.mark.parametrize("arch", ["tbsrn", "tsrn"])
+def test_eval_golden(arch, golden_dir):
+    g = np.load(os.path.join(golden_dir, "%s_eval.npz" % arch))
+    net, _, _ = build(arch)
     net.eval()
     lr, _, _ = make_batch(4, 1234)
     with torch.no_grad():
@@ -51,10 +53,11 @@ def test_tbsrn_eval_golden(golden_dir):
     assert rel_to_max(sr, g["sr"]) < 1e-3
 
 
-def test_tbsrn_train_mse_golden(golden_dir):
-    g = np.load(os.path.join(golden_dir, "tbsrn_train_mse.npz"))
-    gn = json.load(open(os.path.join(golden_dir, "tbsrn_train_mse_gradnorms.json")))
-    net, _, _ = build()
+@pytest.mark.parametrize("arch", ["tbsrn", "tsrn"])
+def test_train_mse_golden(arch, golden_dir):
+    g = np.load(os.path.join(golden_dir, "%s_train_mse.npz" % arch))
+    gn = json.load(open(os.path.join(golden_dir, "%s_train_mse_gradnorms.json" % arch)))
+    net, _, _ = build(arch)
     net.train()
     eval_dropout(net)
     lr, hr, _ = make_batch(4, 1234)
@@ -98,10 +101,11 @@ def test_crnn_leg_golden(golden_dir):
     assert rel_to_max(logits, g["logits"]) < 1e-3
 
 
-def test_e2e_ctc_golden(golden_dir):
-    g = np.load(os.path.join(golden_dir, "tbsrn_e2e_ctc.npz"))
-    gn = json.load(open(os.path.join(golden_dir, "tbsrn_e2e_ctc_gradnorms.json")))
-    net, rec, crit = build()
+@pytest.mark.parametrize("arch", ["tbsrn", "tsrn"])
+def test_e2e_ctc_golden(arch, golden_dir):
+    g = np.load(os.path.join(golden_dir, "%s_e2e_ctc.npz" % arch))
+    gn = json.load(open(os.path.join(golden_dir, "%s_e2e_ctc_gradnorms.json" % arch)))
+    net, rec, crit = build(arch)
     net.train()
     eval_dropout(net)
     lr, hr, labels = make_batch(4, 1234)
@@ -119,12 +123,13 @@ def test_e2e_ctc_golden(golden_dir):
     assert not bad, bad[:10]
 
 
-def test_traj3_golden(golden_dir):
+@pytest.mark.parametrize("arch", ["tbsrn", "tsrn"])
+def test_traj3_golden(arch, golden_dir):
     """3 optimisation steps through the engine (flat buffers, fused clip+Adam) vs the reference
     models stepped with torch's own clip_grad_norm_/Adam (fixture F8)."""
-    ref = json.load(open(os.path.join(golden_dir, "tbsrn_traj3.json")))
+    ref = json.load(open(os.path.join(golden_dir, "%s_traj3.json" % arch)))
     from fudanocr_amd.engine import TrainStep
-    net, rec, crit = build()
+    net, rec, crit = build(arch)
     step = TrainStep(net, crit, dropout=False)
     for s in range(3):
         lr, hr, labels = make_batch(4, 1234 + s)

@@ -1,0 +1,125 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/focr.h
+declares (no compute calls without a GPU), label codec, flat parameter buffers, and the
+data-parallel gradient all-reduce path with 2 gloo processes."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "focr.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(?:int|const char\*)\s+(focr_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
+    return out
+
+
+def test_c_abi_exports_every_declared_symbol():
+    import __graft_entry__ as G
+    G.build()                                            # hipcc cross-compiles without a GPU
+    from fudanocr_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    decl = _header_functions()
+    assert len(decl) >= 40
+    for name, nargs in decl.items():
+        assert hasattr(lib, name), "declared in focr.h but not exported: " + name
+        if name in ("focr_last_error", "focr_version"):
+            continue
+        assert name in _lib.SIGNATURES, "no ctypes signature for " + name
+        assert len(_lib.SIGNATURES[name]) == nargs, (name, len(_lib.SIGNATURES[name]), nargs)
+    for name in _lib.SIGNATURES:
+        assert name in decl, "bound but not declared in focr.h: " + name
+    assert lib.focr_version() >= 100
+
+
+def test_product_fails_loudly_without_gpu_tensors():
+    """no CPU fallback: the ops refuse anything that is not a CUDA fp32 tensor."""
+    from fudanocr_amd import kernels as K
+    with pytest.raises(RuntimeError):
+        K.prelu(torch.zeros(8), torch.zeros(1))
+
+
+def test_label_codec():
+    from fudanocr_amd.utils.utils_crnn import get_crnn_pred, strLabelConverter
+    c = strLabelConverter("0123456789abcdefghijklmnopqrstuvwxyz")
+    t, l = c.encode(["Ab0", "zz"])
+    assert t.tolist() == [11, 12, 1, 36, 36] and l.tolist() == [3, 2]
+    assert c.decode(torch.IntTensor([11, 11, 0, 12, 12]), torch.IntTensor([5])) == "ab"
+    assert c.decode(t, l, raw=True) == ["ab0", "zz"]
+    scores = torch.zeros(1, 6, 37)
+    for i, k in enumerate([11, 11, 0, 11, 12, 0]):
+        scores[0, i, k] = 1
+    assert get_crnn_pred(scores) == ["aab"]
+
+
+def test_flat_buffers_alias_parameters():
+    from fudanocr_amd.engine import FlatBuffers
+    conv = torch.nn.Conv2d(4, 6, 3)
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+    lin = torch.nn.Linear(5, 3)
+    params = list(conv.parameters()) + list(lin.parameters())
+    before = [p.detach().clone() for p in params]
+    fb = FlatBuffers(params)
+    for p, b in zip(params, before):
+        assert torch.equal(p.detach(), b) and p.shape == b.shape
+        assert p.data_ptr() >= fb.flat_param.data_ptr()
+        assert p.grad is not None and float(p.grad.abs().sum()) == 0.0
+    assert conv.weight.permute(0, 2, 3, 1).is_contiguous()          # still physically OHWI
+    fb.flat_param.add_(1.0)
+    assert torch.allclose(conv.weight.detach(), before[0] + 1.0)
+    conv.weight.grad.fill_(2.0)
+    assert float(fb.flat_grad.sum()) == 2.0 * conv.weight.numel()
+    fb.zero_grad()
+    assert float(conv.weight.grad.abs().sum()) == 0.0
+
+
+DP_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from fudanocr_amd.engine import TrainStep
+rank = int(os.environ["RANK"])
+dist.init_process_group("gloo")
+torch.manual_seed(0)
+net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+step = TrainStep(net, crit=None, n_buckets=3)
+assert step.world == 2 and len(step.buckets) >= 2
+g = torch.Generator().manual_seed(100 + rank)
+x = torch.randn(4, 7, generator=g)
+step.flat.zero_grad()
+net(x).pow(2).mean().backward()
+local = step.flat.flat_grad.clone()
+step.allreduce_grads()
+both = [torch.zeros_like(local) for _ in range(2)]
+dist.all_gather(both, local)
+assert torch.allclose(step.flat.flat_grad, both[0] + both[1], atol=1e-7)
+# gradient of the 2-shard global batch = mean of shard gradients = flat_grad / world
+full = torch.cat([torch.randn(4, 7, generator=torch.Generator().manual_seed(100 + r)) for r in range(2)])
+net2 = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+net2.load_state_dict(net.state_dict())
+net2(full).pow(2).mean().backward()
+ref = torch.cat([p.grad.reshape(-1) for p in net2.parameters()])
+got = torch.cat([p.grad.reshape(-1) for p in net.parameters()]) / 2
+assert torch.allclose(got, ref, atol=1e-6), (got - ref).abs().max()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_data_parallel_allreduce_gloo_world2(tmp_path):
+    script = tmp_path / "dp_worker.py"
+    script.write_text(DP_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o)
