@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   float m = -1e30f, l = 0.f;
   const uint32_t thr = DROPOUT ? (uint32_t)(p_drop * 4294967296.0) : 0u;
   const float inv_keep = DROPOUT ? 1.f / (1.f - p_drop) : 1.f;
-  const uint64_t rowbase = ((uint64_t)(b * H + h) * Ntok + q) * (uint64_t)Ntok;
+  const uint32_t rowkey = rng_rowkey(seed, (uint32_t)((b * H + h) * Ntok + q));
 
   // staging: 64 rows x 8 float4 per tile, thread -> (row = idx>>3, c4 = idx&7), idx = tid+256*i
   // staging registers (named scalars: arrays captured by a lambda end up in scratch)
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         ls += p;
         if (DROPOUT) {
           int key = kt * 64 + sub * 32 + key_of(r, lh);
-          p = (rng_hash(seed, rowbase + key) >= thr) ? p * inv_keep : 0.f;
+          p = (rng_elem(rowkey, (uint32_t)key) >= thr) ? p * inv_keep : 0.f;
         }
         s[r] = p;
       }
@@ -162,6 +162,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
   __shared__ __attribute__((aligned(16))) float Qs[64 * KP];
   __shared__ __attribute__((aligned(16))) float Gs[64 * KP];   // dO tile
   __shared__ float Ls[64], Ds[64];
+  __shared__ uint32_t Rk[64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
   const int h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
@@ -206,7 +207,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
         make_float4(qreg1.x * scale, qreg1.y * scale, qreg1.z * scale, qreg1.w * scale);
     *reinterpret_cast<float4*>(&Gs[srow * KP + scol]) = greg0;
     *reinterpret_cast<float4*>(&Gs[(srow + 32) * KP + scol]) = greg1;
-    if (tid < 64) { Ls[tid] = lreg; Ds[tid] = dreg; }
+    if (tid < 64) {
+      Ls[tid] = lreg;
+      Ds[tid] = dreg;
+      if (DROPOUT) Rk[tid] = rng_rowkey(seed, (uint32_t)(sbase + qt * 64 + tid));
+    }
     __syncthreads();
     if (qt + 1 < ntiles) LOAD_QTILE(qt + 1);
 #pragma unroll
@@ -234,8 +239,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
         float p = __expf(s[r] - Ls[ql]);
         float pd = p, dpe = dp[r];
         if (DROPOUT) {
-          uint64_t idx = ((uint64_t)sbase + qt * 64 + ql) * (uint64_t)Ntok + key;
-          bool keep = rng_hash(seed, idx) >= thr;
+          bool keep = rng_elem(Rk[ql], (uint32_t)key) >= thr;
           pd = keep ? p * inv_keep : 0.f;
           dpe = keep ? dpe * inv_keep : 0.f;
         }
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
   for (int r = 0; r < 16; ++r) dqacc[r] = 0.f;
   const uint32_t thr = DROPOUT ? (uint32_t)(p_drop * 4294967296.0) : 0u;
   const float inv_keep = DROPOUT ? 1.f / (1.f - p_drop) : 1.f;
-  const uint64_t rowbase = ((uint64_t)sbase + q) * (uint64_t)Ntok;
+  const uint32_t rowkey = rng_rowkey(seed, (uint32_t)(sbase + q));
 
   // staging registers (named scalars: arrays captured by a lambda end up in scratch)
   float4 kreg0, kreg1, vreg0, vreg1;
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
         float dpe = dp[r];
         if (DROPOUT) {
           int key = kt * 64 + sub * 32 + key_of(r, lh);
-          dpe = (rng_hash(seed, rowbase + key) >= thr) ? dpe * inv_keep : 0.f;
+          dpe = (rng_elem(rowkey, (uint32_t)key) >= thr) ? dpe * inv_keep : 0.f;
         }
         s[r] = p * (dpe - dd);           // dS
       }

@@ -58,6 +58,19 @@ __device__ __forceinline__ float mish_grad_f(float x) {
   return t + x * (1.f - t * t) * sg;
 }
 
+// 32-bit two-level counter hash for the attention dropout mask (cheap: ~8 VALU ops per element):
+// rowkey = rng_rowkey(seed, global query row) once per row, then rng_elem(rowkey, key).
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t rng_rowkey(uint64_t seed, uint32_t row) {
+  return hash32(hash32(row ^ (uint32_t)seed) + (uint32_t)(seed >> 32));
+}
+__device__ __forceinline__ uint32_t rng_elem(uint32_t rowkey, uint32_t col) {
+  return hash32(rowkey ^ (col * 0x9E3779B1U));
+}
+
 // counter-based RNG for dropout masks: one 32-bit draw per (seed, index); the same
 // function regenerates the mask in the backward kernels.
 __device__ __forceinline__ uint32_t rng_hash(uint64_t seed, uint64_t idx) {
