@@ -208,7 +208,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
 template <bool VEC>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ X,
                                                          const float* __restrict__ dY,
-                                                         float* __restrict__ dW, ConvGeom g,
+                                                         float* __restrict__ dW,
+                                                         float* __restrict__ dbias, ConvGeom g,
                                                          int ldd, int pix_per_split) {
   __shared__ __attribute__((aligned(16))) float Ds[32 * WP];   // dY tile  [pixel][co]
   __shared__ __attribute__((aligned(16))) float Xs[32 * WP];   // A tile   [pixel][k]
@@ -241,6 +242,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // bias gradient (column sums of dY) rides along in the k-tile-0 blocks: wave 0, lane = co
+  const bool do_bias = dbias != nullptr && blockIdx.x == 0 && tid < 64;
+  float bsum = 0.f;
   const int wi = wave >> 1, wj = wave & 1;     // wave tile: co rows wi*32.., k cols wj*32..
   const int li = lane & 31, lh = lane >> 5;
 
@@ -294,6 +298,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
       }
     }
     __syncthreads();
+    if (do_bias) {
+#pragma unroll
+      for (int r = 0; r < 32; ++r) bsum += Ds[r * WP + tid];
+    }
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       float a = Ds[(2 * s + lh) * WP + wi * 32 + li];
@@ -302,6 +310,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
     }
     __syncthreads();
   }
+  if (do_bias && co0 + tid < g.Cout) atomicAdd(&dbias[co0 + tid], bsum);
   // acc[r]: row (co) = (r&3)+8*(r>>2)+4*lh, col (k) = li
   int k = k0 + wj * 32 + li;
   if (k < g.Ktot) {
@@ -413,21 +422,15 @@ extern "C" int focr_conv2d_wgrad(const float* x, const float* dy, float* dw, flo
   int pps = cdiv(cdiv(g.M, splits), 32) * 32;
   splits = cdiv(g.M, pps);
   dim3 grid(cdiv(g.Ktot, 64), cdiv(Cout, 64), splits);
-  if (vec)
-    hipLaunchKernelGGL((conv_wgrad_kernel<true>), grid, 256, 0, stream, x, dy, dw, g, ldd, pps);
-  else
-    hipLaunchKernelGGL((conv_wgrad_kernel<false>), grid, 256, 0, stream, x, dy, dw, g, ldd, pps);
-  FOCR_LAUNCH_CHECK();
-  if (dbias) {
-    if (hipMemsetAsync(dbias, 0, sizeof(float) * Cout, stream) != hipSuccess) {
-      focr_set_error("focr_conv2d_wgrad: memset failed");
-      return FOCR_EHIP;
-    }
-    int ry = cdiv(g.M, 512);
-    if (ry > 256) ry = 256;
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(Cout, 64), ry), 256, 0, stream, dy, dbias, (long)g.M, Cout, ldd);
-    FOCR_LAUNCH_CHECK();
+  if (dbias && hipMemsetAsync(dbias, 0, sizeof(float) * Cout, stream) != hipSuccess) {
+    focr_set_error("focr_conv2d_wgrad: memset failed");
+    return FOCR_EHIP;
   }
+  if (vec)
+    hipLaunchKernelGGL((conv_wgrad_kernel<true>), grid, 256, 0, stream, x, dy, dw, dbias, g, ldd, pps);
+  else
+    hipLaunchKernelGGL((conv_wgrad_kernel<false>), grid, 256, 0, stream, x, dy, dw, dbias, g, ldd, pps);
+  FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }
 

@@ -47,6 +47,7 @@ class FlatBuffers:
                 g = self.flat_grad[off:off + p.numel()].view(shape).permute(inv) if p.dim() else \
                     self.flat_grad[off:off + 1].view(())
                 p.grad = g
+                p._focr_grad = g          # kernels write the gradient here directly (kernels._target)
 
     def zero_grad(self):
         self.flat_grad.zero_()
@@ -56,6 +57,7 @@ class FlatBuffers:
                 inv = [order.index(d) for d in range(p.dim())]
                 p.grad = self.flat_grad[off:off + p.numel()].view(shape).permute(inv) if p.dim() else \
                     self.flat_grad[off:off + 1].view(())
+                p._focr_grad = p.grad
 
 
 class FusedClipAdam:

@@ -44,6 +44,13 @@ def _ohwi(w):
     return v if v.is_contiguous() else v.contiguous()
 
 
+def _target(param):
+    """Flat-gradient slice the engine attached to a parameter (engine.FlatBuffers), or None.
+    When present the backward kernels write the parameter gradient straight into it and hand
+    autograd `None` (no per-parameter accumulate kernels; every parameter is used once per step)."""
+    return getattr(param, "_focr_grad", None) if param is not None else None
+
+
 def _new_seed():
     return int(torch.randint(0, 2 ** 62, (1,), device="cpu").item())
 
@@ -91,6 +98,7 @@ class _Conv2d(torch.autograd.Function):
         _chk(x4, wk, bias, res4)
         y = _conv_fwd_raw(x4, wk, bias, res4, cout, kh, kw, ph, pw, alpha, relu)
         ctx.geom = (kh, kw, ph, pw, float(alpha), bool(relu), bias is not None, residual is not None)
+        ctx.targets = (_target(weight), _target(bias))
         ctx.save_for_backward(x4, weight, y if relu else None)
         return y if x.dim() == 4 else y.reshape(*lead, cout)
 
@@ -114,14 +122,17 @@ class _Conv2d(torch.autograd.Function):
             _lib.call("focr_weight_flip_transpose", _p(wk), _p(wd), cout, kh, kw, cin, _stream())
             dx4 = _conv_fwd_raw(dy4, wd, None, None, cin, kh, kw, kh - 1 - ph, kw - 1 - pw, alpha, False)
             dx = dx4 if len(ctx.x_shape) == 4 else dx4.reshape(ctx.x_shape)
+        tw, tb = ctx.targets
         if ctx.needs_input_grad[1]:
-            if weight.dim() == 2:
+            if tw is not None:
+                dw = tw
+            elif weight.dim() == 2:
                 dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
             else:   # logical [Cout,Cin,KH,KW] view of the physically-OHWI buffer the kernel fills
                 dw = torch.empty((cout, kh, kw, cin), device=dy.device).permute(0, 3, 1, 2)
             need_db = has_bias and ctx.needs_input_grad[2]
             if need_db:
-                db = torch.empty(cout, device=dy.device, dtype=torch.float32)
+                db = tb if tb is not None else torch.empty(cout, device=dy.device, dtype=torch.float32)
             if _is_out_layer(cin, cout, kh, kw, ph, pw, w, None, alpha, relu) and not has_res:
                 _lib.call("focr_conv9x9_small_cout_wgrad", _p(x4), _p(dy4), _p(dw), _p(db), n, h, w, cin,
                           cout, _stream())
@@ -131,8 +142,12 @@ class _Conv2d(torch.autograd.Function):
             if alpha != 1.0:
                 _lib.call("focr_axpy", _p(dw), _NULL, _p(dw), dw.numel(), alpha, _stream())
         elif has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty(cout, device=dy.device, dtype=torch.float32)
+            db = tb if tb is not None else torch.empty(cout, device=dy.device, dtype=torch.float32)
             _lib.call("focr_colsum", _p(dy4), _p(db), dy4.numel() // cout, cout, cout, _stream())
+        if tw is not None:
+            dw = None
+        if tb is not None:
+            db = None
         return dx, dw, db, dres, None, None, None
 
 
@@ -168,6 +183,7 @@ class _BatchNormAct(torch.autograd.Function):
             _lib.call("focr_bn_eval_fwd", _p(x), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(residual), _p(y),
                       _p(invstd), rows, c, float(eps), act, _stream())
         ctx.cfg = (rows, c, act, bool(training), residual is not None)
+        ctx.targets = (_target(gamma), _target(beta))
         ctx.save_for_backward(x, gamma, beta, mean, invstd)
         return y
 
@@ -179,11 +195,14 @@ class _BatchNormAct(torch.autograd.Function):
         dx = torch.empty_like(x)
         dg = db = None
         if training:
-            dg = torch.empty(c, device=x.device)
-            db = torch.empty(c, device=x.device)
+            tg, tb = ctx.targets
+            dg = tg if tg is not None else torch.empty(c, device=x.device)
+            db = tb if tb is not None else torch.empty(c, device=x.device)
             ws = torch.empty(2 * c, device=x.device)
             _lib.call("focr_bn_bwd", _p(dz), _p(x), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(dx), _p(dg),
                       _p(db), _p(ws), rows, c, act, 1, _stream())
+            dg = None if tg is not None else dg
+            db = None if tb is not None else db
         else:
             _lib.call("focr_bn_bwd", _p(dz), _p(x), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(dx), _NULL,
                       _NULL, _NULL, rows, c, act, 0, _stream())
@@ -210,6 +229,7 @@ class _LayerNormStd(torch.autograd.Function):
         _lib.call("focr_layernorm_fwd", _p(x), _p(residual), _p(a), _p(b), _p(y), _p(mean), _p(rinv), rows, d,
                   float(eps), _stream())
         ctx.cfg = (rows, d, float(eps), residual is not None)
+        ctx.targets = (_target(a), _target(b))
         ctx.save_for_backward(x, residual, a, mean, rinv)
         return y
 
@@ -219,11 +239,12 @@ class _LayerNormStd(torch.autograd.Function):
         rows, d, eps, has_res = ctx.cfg
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        da = torch.empty(d, device=x.device)
-        db = torch.empty(d, device=x.device)
+        ta, tb = ctx.targets
+        da = ta if ta is not None else torch.empty(d, device=x.device)
+        db = tb if tb is not None else torch.empty(d, device=x.device)
         _lib.call("focr_layernorm_bwd", _p(dy), _p(x), _p(residual), _p(a), _p(mean), _p(rinv), _p(dx), _p(da),
                   _p(db), rows, d, eps, _stream())
-        return dx, (dx if has_res else None), da, db, None
+        return dx, (dx if has_res else None), (None if ta is not None else da), (None if tb is not None else db), None
 
 
 def layernorm_std(x, a, b, residual=None, eps=1e-6):
@@ -239,6 +260,7 @@ class _PReLU(torch.autograd.Function):
         _chk(x, slope)
         y = torch.empty_like(x)
         _lib.call("focr_prelu_fwd", _p(x), _p(slope), _p(y), x.numel(), _stream())
+        ctx.target = _target(slope)
         ctx.save_for_backward(x, slope)
         return y
 
@@ -247,9 +269,9 @@ class _PReLU(torch.autograd.Function):
         x, slope = ctx.saved_tensors
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        ds = torch.empty(1, device=x.device)
+        ds = ctx.target if ctx.target is not None else torch.empty(1, device=x.device)
         _lib.call("focr_prelu_bwd", _p(dy), _p(x), _p(slope), _p(dx), _p(ds), x.numel(), _stream())
-        return dx, ds
+        return dx, (None if ctx.target is not None else ds)
 
 
 def prelu(x, slope):
