@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfocr_hip.so")
+# FOCR_LIB overrides the library path (kernel A/B experiments with tools/kbench.py only)
+LIB_PATH = os.environ.get("FOCR_LIB") or os.path.join(_HERE, "libfocr_hip.so")
 
 P, I, L, F, U = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_uint64
 
@@ -17,8 +18,8 @@ SIGNATURES = {
     "focr_conv2d_wgrad": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     "focr_weight_flip_transpose": [P, P, I, I, I, I, P],
     "focr_colsum": [P, P, L, I, I, P],
-    "focr_attention_fwd": [P, P, P, P, P, I, I, I, I, F, F, U, P],
-    "focr_attention_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, U, P],
+    "focr_attention_fwd": [P, P, P, P, P, P, I, I, I, I, F, F, U, P],
+    "focr_attention_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, P],
     "focr_bn_train_fwd": [P, P, P, P, P, P, P, P, P, P, P, L, I, F, F, I, P],
     "focr_bn_eval_fwd": [P, P, P, P, P, P, P, P, L, I, F, I, P],
     "focr_bn_bwd": [P, P, P, P, P, P, P, P, P, P, L, I, I, I, P],

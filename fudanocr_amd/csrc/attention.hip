@@ -13,7 +13,8 @@
 // free to permute, the only rule is that A and B use the same permutation.
 //
 // Layout: q,k,v,o,do,dq,dk,dv are [B, Ntok, ld] fp32 with head h at columns h*32..h*32+31.
-// LSE, D are [B, H, Ntok].
+// LSE, D are [B, H, Ntok].  Dropout keep-bits: uint32 [B, H, Ntok, Ntok/32] (bit = key % 32), written by
+// the forward kernel (two 16-bit draws per counter hash), read by both backward kernels.
 #include "focr_common.h"
 
 #define KP 36   // LDS pitch (floats) of tiles read with ds_read_b128 fragments
@@ -25,15 +26,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
                                                        const float* __restrict__ K,
                                                        const float* __restrict__ V,
                                                        float* __restrict__ O, float* __restrict__ LSE,
-                                                       int Ntok, int ld, float scale, float p_drop,
-                                                       uint64_t seed) {
+                                                       uint32_t* __restrict__ MASK, int Ntok, int ld,
+                                                       float scale, float p_drop, uint64_t seed, int nheads) {
   __shared__ __attribute__((aligned(16))) float Ks[64 * KP];
   __shared__ __attribute__((aligned(16))) float Vs[64 * 32];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
+  const int H = nheads, h = blockIdx.x % nheads, b = blockIdx.x / nheads;
   const size_t base = (size_t)b * Ntok * ld + h * 32;
-  const int q = blockIdx.x * 128 + wave * 32 + li;
+  const int q = blockIdx.y * 128 + wave * 32 + li;
 
   float4 qf[4];
 #pragma unroll
@@ -45,9 +46,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 #pragma unroll
   for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
   float m = -1e30f, l = 0.f;
-  const uint32_t thr = DROPOUT ? (uint32_t)(p_drop * 4294967296.0) : 0u;
-  const float inv_keep = DROPOUT ? 1.f / (1.f - p_drop) : 1.f;
+  // dropout: one 32-bit hash per PAIR of adjacent keys, 16 bits each (p quantised to 1/65536);
+  // the keep bits are packed (bit = key % 32) and written out for the two backward kernels
+  const uint32_t thr = DROPOUT ? (uint32_t)(p_drop * 65536.0f + 0.5f) : 0u;
+  const float inv_keep = DROPOUT ? 1.f / (1.f - (float)thr / 65536.f) : 1.f;
   const uint32_t rowkey = rng_rowkey(seed, (uint32_t)((b * H + h) * Ntok + q));
+  uint32_t mwords[2] = {0u, 0u};
 
   // staging: 64 rows x 8 float4 per tile, thread -> (row = idx>>3, c4 = idx&7), idx = tid+256*i
   // staging registers (named scalars: arrays captured by a lambda end up in scratch)
@@ -96,11 +100,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
       for (int r = 0; r < 16; ++r) {
         float p = __expf(s[r] - mn);
         ls += p;
-        if (DROPOUT) {
-          int key = kt * 64 + sub * 32 + key_of(r, lh);
-          p = (rng_elem(rowkey, (uint32_t)key) >= thr) ? p * inv_keep : 0.f;
-        }
         s[r] = p;
+      }
+      if (DROPOUT) {
+        uint32_t bits = 0u;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {          // regs (r, r+1) hold adjacent keys (2j, 2j+1)
+          int key = kt * 64 + sub * 32 + key_of(r, lh);
+          uint32_t hsh = rng_elem(rowkey, (uint32_t)(key >> 1));
+          bool k0 = (hsh & 0xffffu) >= thr, k1 = (hsh >> 16) >= thr;
+          s[r] = k0 ? s[r] * inv_keep : 0.f;
+          s[r + 1] = k1 ? s[r + 1] * inv_keep : 0.f;
+          bits |= ((k0 ? 1u : 0u) | (k1 ? 2u : 0u)) << ((r & 3) + 8 * (r >> 2));
+        }
+        bits <<= 4 * lh;
+        mwords[sub] = bits | __shfl_xor(bits, 32, 64);
       }
       l = l * alpha + ls;
 #pragma unroll
@@ -111,6 +125,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(v, s[r], oacc, 0, 0, 0);
       }
     }
+    if (DROPOUT && lh == 0)
+      *reinterpret_cast<uint2*>(MASK + ((size_t)(b * H + h) * Ntok + q) * (Ntok / 32) + kt * 2) =
+          make_uint2(mwords[0], mwords[1]);
     __syncthreads();
   }
   l += __shfl_xor(l, 32, 64);
@@ -157,18 +174,18 @@ template <bool DROPOUT>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ Dv,
-    float* __restrict__ dK, float* __restrict__ dV, int Ntok, int ld, float scale, float p_drop,
-    uint64_t seed) {
+    float* __restrict__ dK, float* __restrict__ dV, const uint32_t* __restrict__ MASK, int Ntok, int ld,
+    float scale, float p_drop, int nheads) {
   __shared__ __attribute__((aligned(16))) float Qs[64 * KP];
   __shared__ __attribute__((aligned(16))) float Gs[64 * KP];   // dO tile
   __shared__ float Ls[64], Ds[64];
-  __shared__ uint32_t Rk[64];
+  __shared__ uint32_t Mw[4][64];     // keep-bit word of (query, this wave's 32-key group)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
+  const int H = nheads, h = blockIdx.x % nheads, b = blockIdx.x / nheads;
   const size_t base = (size_t)b * Ntok * ld + h * 32;
   const size_t sbase = (size_t)(b * H + h) * Ntok;
-  const int key = blockIdx.x * 128 + wave * 32 + li;
+  const int key = blockIdx.y * 128 + wave * 32 + li;
 
   float4 kf[4], vf[4];
 #pragma unroll
@@ -179,11 +196,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
   f32x16 dkacc, dvacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dkacc[r] = 0.f; dvacc[r] = 0.f; }
-  const uint32_t thr = DROPOUT ? (uint32_t)(p_drop * 4294967296.0) : 0u;
-  const float inv_keep = DROPOUT ? 1.f / (1.f - p_drop) : 1.f;
+  const float inv_keep = DROPOUT ? 1.f / (1.f - (float)(uint32_t)(p_drop * 65536.0f + 0.5f) / 65536.f) : 1.f;
 
   float4 qreg0, qreg1, greg0, greg1;
   float lreg = 0.f, dreg = 0.f;
+  uint32_t mreg = 0u;
   const int srow = tid >> 3, scol = (tid & 7) * 4;
 #define LOAD_QTILE(qt)                                                                  \
   do {                                                                                  \
@@ -197,6 +214,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
       lreg = LSE[sbase + (qt) * 64 + tid];                                              \
       dreg = Dv[sbase + (qt) * 64 + tid];                                               \
     }                                                                                   \
+    if (DROPOUT)                                                                        \
+      mreg = MASK[(sbase + (qt) * 64 + (tid & 63)) * (Ntok / 32) + blockIdx.y * 4 + (tid >> 6)]; \
   } while (0)
   const int ntiles = Ntok / 64;
   LOAD_QTILE(0);
@@ -210,8 +229,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
     if (tid < 64) {
       Ls[tid] = lreg;
       Ds[tid] = dreg;
-      if (DROPOUT) Rk[tid] = rng_rowkey(seed, (uint32_t)(sbase + qt * 64 + tid));
     }
+    if (DROPOUT) Mw[tid >> 6][tid & 63] = mreg;
     __syncthreads();
     if (qt + 1 < ntiles) LOAD_QTILE(qt + 1);
 #pragma unroll
@@ -239,7 +258,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
         float p = __expf(s[r] - Ls[ql]);
         float pd = p, dpe = dp[r];
         if (DROPOUT) {
-          bool keep = rng_elem(Rk[ql], (uint32_t)key) >= thr;
+          bool keep = (Mw[wave][ql] >> li) & 1u;
           pd = keep ? p * inv_keep : 0.f;
           dpe = keep ? dpe * inv_keep : 0.f;
         }
@@ -276,15 +295,16 @@ template <bool DROPOUT>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ Dv,
-    float* __restrict__ dQ, int Ntok, int ld, float scale, float p_drop, uint64_t seed) {
+    float* __restrict__ dQ, const uint32_t* __restrict__ MASK, int Ntok, int ld, float scale, float p_drop,
+    int nheads) {
   __shared__ __attribute__((aligned(16))) float Ks[64 * KP];
   __shared__ __attribute__((aligned(16))) float Vs[64 * KP];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
+  const int H = nheads, h = blockIdx.x % nheads, b = blockIdx.x / nheads;
   const size_t base = (size_t)b * Ntok * ld + h * 32;
   const size_t sbase = (size_t)(b * H + h) * Ntok;
-  const int q = blockIdx.x * 128 + wave * 32 + li;
+  const int q = blockIdx.y * 128 + wave * 32 + li;
 
   float4 qf[4], gf[4];
 #pragma unroll
@@ -297,9 +317,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
   f32x16 dqacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) dqacc[r] = 0.f;
-  const uint32_t thr = DROPOUT ? (uint32_t)(p_drop * 4294967296.0) : 0u;
-  const float inv_keep = DROPOUT ? 1.f / (1.f - p_drop) : 1.f;
-  const uint32_t rowkey = rng_rowkey(seed, (uint32_t)(sbase + q));
+  const float inv_keep = DROPOUT ? 1.f / (1.f - (float)(uint32_t)(p_drop * 65536.0f + 0.5f) / 65536.f) : 1.f;
+  const uint32_t* mrow = MASK + (sbase + q) * (size_t)(Ntok / 32);
 
   // staging registers (named scalars: arrays captured by a lambda end up in scratch)
   float4 kreg0, kreg1, vreg0, vreg1;
@@ -322,6 +341,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
     *reinterpret_cast<float4*>(&Vs[(srow + 32) * KP + scol]) = vreg1;
     __syncthreads();
     if (kt + 1 < ntiles) LOAD_TILE(kt + 1);
+    uint2 mw = make_uint2(0u, 0u);
+    if (DROPOUT) mw = *reinterpret_cast<const uint2*>(mrow + kt * 2);
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       f32x16 s, dp;
@@ -345,8 +366,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
         float p = __expf(s[r] - lse);
         float dpe = dp[r];
         if (DROPOUT) {
-          int key = kt * 64 + sub * 32 + key_of(r, lh);
-          dpe = (rng_elem(rowkey, (uint32_t)key) >= thr) ? dpe * inv_keep : 0.f;
+          uint32_t w = sub ? mw.y : mw.x;
+          dpe = ((w >> key_of(r, lh)) & 1u) ? dpe * inv_keep : 0.f;
         }
         s[r] = p * (dpe - dd);           // dS
       }
@@ -367,37 +388,39 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
 }
 
 extern "C" int focr_attention_fwd(const float* q, const float* k, const float* v, float* o,
-                                  float* lse, int B, int H, int Ntok, int ld, float scale,
+                                  float* lse, uint32_t* mask, int B, int H, int Ntok, int ld, float scale,
                                   float p_drop, uint64_t seed, hipStream_t stream) {
   FOCR_CHECK_ARG(q && k && v && o && lse, "null pointer");
+  FOCR_CHECK_ARG(p_drop <= 0.f || mask, "dropout needs the keep-bit buffer [B,H,Ntok,Ntok/32]");
   FOCR_CHECK_ARG(Ntok % 128 == 0 && ld >= H * 32 && ld % 4 == 0, "need Ntok%128==0, head dim 32");
   FOCR_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "bad dropout probability");
-  dim3 grid(Ntok / 128, H, B);
+  dim3 grid(B * H, Ntok / 128);   // (batch,head) fast: all blocks of a head share one XCD's L2
   if (p_drop > 0.f)
-    hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, 256, 0, stream, q, k, v, o, lse, Ntok, ld, scale, p_drop, seed);
+    hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ld, scale, p_drop, seed, H);
   else
-    hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, 256, 0, stream, q, k, v, o, lse, Ntok, ld, scale, p_drop, seed);
+    hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ld, scale, p_drop, seed, H);
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }
 
 // dwork: B*H*Ntok floats of workspace (D = rowsum(dO*O))
 extern "C" int focr_attention_bwd(const float* q, const float* k, const float* v, const float* o,
-                                  const float* d_o, const float* lse, float* dq, float* dk,
-                                  float* dv, float* dwork, int B, int H, int Ntok, int ld,
-                                  float scale, float p_drop, uint64_t seed, hipStream_t stream) {
+                                  const float* d_o, const float* lse, const uint32_t* mask, float* dq,
+                                  float* dk, float* dv, float* dwork, int B, int H, int Ntok, int ld,
+                                  float scale, float p_drop, hipStream_t stream) {
   FOCR_CHECK_ARG(q && k && v && o && d_o && lse && dq && dk && dv && dwork, "null pointer");
+  FOCR_CHECK_ARG(p_drop <= 0.f || mask, "dropout needs the keep-bit buffer written by the forward");
   FOCR_CHECK_ARG(Ntok % 128 == 0 && ld >= H * 32 && ld % 4 == 0, "need Ntok%128==0, head dim 32");
   long total = (long)B * Ntok * H;
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(cdiv(total, 256)), 256, 0, stream, o, d_o, dwork, Ntok, ld, H, total);
   FOCR_LAUNCH_CHECK();
-  dim3 grid(Ntok / 128, H, B);
+  dim3 grid(B * H, Ntok / 128);   // (batch,head) fast: all blocks of a head share one XCD's L2
   if (p_drop > 0.f) {
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dk, dv, Ntok, ld, scale, p_drop, seed);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dq, Ntok, ld, scale, p_drop, seed);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dk, dv, mask, Ntok, ld, scale, p_drop, H);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dq, mask, Ntok, ld, scale, p_drop, H);
   } else {
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dk, dv, Ntok, ld, scale, p_drop, seed);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dq, Ntok, ld, scale, p_drop, seed);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dk, dv, mask, Ntok, ld, scale, p_drop, H);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dq, mask, Ntok, ld, scale, p_drop, H);
   }
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;

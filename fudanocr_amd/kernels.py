@@ -392,22 +392,23 @@ class _Attention(torch.autograd.Function):
         _chk(q, k, v)
         o = torch.empty_like(q)
         lse = torch.empty((b, heads, t), device=q.device)
+        mask = torch.empty((b, heads, t, t // 32), device=q.device, dtype=torch.int32) if p_drop > 0 else None
         scale = 1.0 / math.sqrt(d // heads)
-        _lib.call("focr_attention_fwd", _p(q), _p(k), _p(v), _p(o), _p(lse), b, heads, t, d, scale,
+        _lib.call("focr_attention_fwd", _p(q), _p(k), _p(v), _p(o), _p(lse), _p(mask), b, heads, t, d, scale,
                   float(p_drop), seed, _stream())
-        ctx.cfg = (b, heads, t, d, scale, float(p_drop), seed)
-        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.cfg = (b, heads, t, d, scale, float(p_drop))
+        ctx.save_for_backward(q, k, v, o, lse, mask)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v, o, lse = ctx.saved_tensors
-        b, heads, t, d, scale, p_drop, seed = ctx.cfg
+        q, k, v, o, lse, mask = ctx.saved_tensors
+        b, heads, t, d, scale, p_drop = ctx.cfg
         do = do.contiguous()
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         work = torch.empty((b, heads, t), device=q.device)
-        _lib.call("focr_attention_bwd", _p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(dq), _p(dk), _p(dv),
-                  _p(work), b, heads, t, d, scale, p_drop, seed, _stream())
+        _lib.call("focr_attention_bwd", _p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(mask), _p(dq), _p(dk),
+                  _p(dv), _p(work), b, heads, t, d, scale, p_drop, _stream())
         return dq, dk, dv, None, None, None
 
 

@@ -64,14 +64,16 @@ int focr_conv9x9_small_cout_wgrad(const float* x, const float* dy, float* dw, fl
 
 /* ---- fused attention: model/tbsrn.py:132-150 (+ the head split/merge of :116-126) -----------
  * q,k,v,o: [B,Ntok,ld], head h in columns h*32..h*32+31; lse: [B,H,Ntok]; Ntok % 128 == 0.
- * p_drop: dropout on the probabilities (tbsrn.py:147-148), mask = hash(seed, b,h,q,key). */
-int focr_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B,
-                       int H, int Ntok, int ld, float scale, float p_drop, uint64_t seed,
-                       focr_stream_t stream);
+ * p_drop: dropout on the probabilities (tbsrn.py:147-148); the forward draws the mask from a counter
+ * hash of (seed, b,h,q,key) and writes the keep bits to mask [B,H,Ntok,Ntok/32] uint32 (needed iff p>0). */
+int focr_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse,
+                       uint32_t* mask, int B, int H, int Ntok, int ld, float scale, float p_drop,
+                       uint64_t seed, focr_stream_t stream);
 /* dwork: B*H*Ntok floats */
 int focr_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o,
-                       const float* lse, float* dq, float* dk, float* dv, float* dwork, int B, int H,
-                       int Ntok, int ld, float scale, float p_drop, uint64_t seed, focr_stream_t stream);
+                       const float* lse, const uint32_t* mask, float* dq, float* dk, float* dv,
+                       float* dwork, int B, int H, int Ntok, int ld, float scale, float p_drop,
+                       focr_stream_t stream);
 
 /* ---- BatchNorm2d/1d (+activation, +residual): model/tsrn.py:81-86,35-39, stn_head.py:17-21,45-48,
  *      crnn.py:44 ; torch semantics (biased var to normalise, unbiased in the running update) --- */

@@ -159,6 +159,32 @@ def test_attention_dropout():
     assert abs(v.grad.sum().item() / 32 - o.sum().item() / 32) < 1e-2 * o.sum().item() / 32
 
 
+def test_attention_dropout_exact_against_extracted_mask():
+    """Forward writes the packed keep-bits; rebuild the dense mask from them and check o, dq, dk, dv
+    against a float64 reference using that very mask (covers the bit layout read by both backward
+    kernels) and that the keep rate is 1-p."""
+    from fudanocr_amd.kernels import _Attention
+    b, t, p = 2, 256, 0.1
+    q, k, v = (rnd(b, t, 128, seed=s, scale=1.5).requires_grad_(True) for s in (1, 2, 3))
+    qd, kd, vd = (dev(z).requires_grad_(True) for z in (q, k, v))
+    od = _Attention.apply(qd, kd, vd, 4, p, 777)
+    words = od.grad_fn.saved_tensors[5].cpu().to(torch.int64) & 0xFFFFFFFF          # [b,4,t,t/32]
+    bits = ((words.unsqueeze(-1) >> torch.arange(32)) & 1).reshape(b, 4, t, t).double()
+    keep = bits.mean().item()
+    assert abs(keep - 0.9) < 4e-3, keep
+    thr = round(p * 65536)
+    heads = lambda z: z.view(b, t, 4, 32).transpose(1, 2)
+    pr = torch.softmax(heads(q) @ heads(k).transpose(-1, -2) / math.sqrt(32), -1) * bits / (1 - thr / 65536)
+    o = (pr @ heads(v)).transpose(1, 2).reshape(b, t, 128)
+    go = rnd(b, t, 128, seed=4)
+    o.backward(go)
+    close(od, o, what="attn dropout fwd")
+    od.backward(dev(go))
+    close(qd.grad, q.grad, what="attn dropout dq")
+    close(kd.grad, k.grad, what="attn dropout dk")
+    close(vd.grad, v.grad, what="attn dropout dv")
+
+
 @pytest.mark.parametrize("act", [0, 1, 4])
 @pytest.mark.parametrize("training", [True, False])
 def test_batchnorm(act, training):
