@@ -15,18 +15,18 @@ P, I, L, F, U = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ct
 # name -> argument types (every entry point returns int and takes the stream last)
 SIGNATURES = {
     "focr_conv2d_fwd": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, I, I, P],
-    "focr_conv2d_wgrad": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
+    "focr_conv2d_wgrad": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
     "focr_weight_flip_transpose": [P, P, I, I, I, I, P],
     "focr_colsum": [P, P, L, I, I, P],
     "focr_attention_fwd": [P, P, P, P, P, P, I, I, I, I, F, F, U, P],
     "focr_attention_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, P],
     "focr_bn_train_fwd": [P, P, P, P, P, P, P, P, P, P, P, L, I, F, F, I, P],
     "focr_bn_eval_fwd": [P, P, P, P, P, P, P, P, L, I, F, I, P],
-    "focr_bn_bwd": [P, P, P, P, P, P, P, P, P, P, L, I, I, I, P],
+    "focr_bn_bwd": [P, P, P, P, P, P, P, P, P, L, I, I, I, I, P],
     "focr_layernorm_fwd": [P, P, P, P, P, P, P, L, I, F, P],
-    "focr_layernorm_bwd": [P, P, P, P, P, P, P, P, P, L, I, F, P],
+    "focr_layernorm_bwd": [P, P, P, P, P, P, P, P, P, L, I, F, I, P],
     "focr_prelu_fwd": [P, P, P, L, P],
-    "focr_prelu_bwd": [P, P, P, P, P, L, P],
+    "focr_prelu_bwd": [P, P, P, P, P, L, I, P],
     "focr_pixelshuffle_mish_fwd": [P, P, I, I, I, I, P],
     "focr_pixelshuffle_mish_bwd": [P, P, P, I, I, I, I, P],
     "focr_nchw_to_nhwc": [P, P, I, I, I, P],
@@ -50,7 +50,7 @@ SIGNATURES = {
     "focr_gru_bidir_fwd": [P, P, P, P, P, I, I, I, I, I, I, P],
     "focr_gru_bidir_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     "focr_conv9x9_small_cout_fwd": [P, P, P, P, I, I, I, I, I, P],
-    "focr_conv9x9_small_cout_wgrad": [P, P, P, P, I, I, I, I, I, P],
+    "focr_conv9x9_small_cout_wgrad": [P, P, P, P, I, I, I, I, I, I, P],
     "focr_ctc_fwd": [P, P, P, P, P, P, P, I, I, I, P],
     "focr_scale_dev": [P, P, P, L, P],
     "focr_grad_sumsq": [P, P, L, F, P],

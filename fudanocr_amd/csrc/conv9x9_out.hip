@@ -186,13 +186,14 @@ extern "C" int focr_conv9x9_small_cout_fwd(const float* x, const float* w, const
 }
 
 extern "C" int focr_conv9x9_small_cout_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N,
-                                             int H, int W, int Cin, int Cout, hipStream_t stream) {
+                                             int H, int W, int Cin, int Cout, int prezeroed,
+                                             hipStream_t stream) {
   FOCR_CHECK_ARG(x && dy && dw, "null pointer");
   if (Cin != C9 || Cout < 1 || Cout > 3 || W > 128 || W % 32) {
     focr_set_error("focr_conv9x9_small_cout_wgrad: needs Cin == 64, Cout <= 3, W in {32,64,96,128}");
     return FOCR_EUNSUPPORTED;
   }
-  if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cout * 81 * C9, stream) != hipSuccess) {
+  if (!prezeroed && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cout * 81 * C9, stream) != hipSuccess) {
     focr_set_error("focr_conv9x9_small_cout_wgrad: memset failed");
     return FOCR_EHIP;
   }

@@ -242,8 +242,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  // bias gradient (column sums of dY) rides along in the k-tile-0 blocks: wave 0, lane = co
-  const bool do_bias = dbias != nullptr && blockIdx.x == 0 && tid < 64;
+  // bias gradient (column sums of dY) rides along in the k-tile-0 blocks:
+  // thread -> column tid&63, rows 8*(tid>>6) .. +7 of every staged dY tile
+  const bool do_bias = dbias != nullptr && blockIdx.x == 0;
   float bsum = 0.f;
   const int wi = wave >> 1, wj = wave & 1;     // wave tile: co rows wi*32.., k cols wj*32..
   const int li = lane & 31, lh = lane >> 5;
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
     __syncthreads();
     if (do_bias) {
 #pragma unroll
-      for (int r = 0; r < 32; ++r) bsum += Ds[r * WP + tid];
+      for (int r = 0; r < 8; ++r) bsum += Ds[((tid >> 6) * 8 + r) * WP + (tid & 63)];
     }
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
@@ -310,14 +311,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
     }
     __syncthreads();
   }
-  if (do_bias && co0 + tid < g.Cout) atomicAdd(&dbias[co0 + tid], bsum);
+  if (do_bias) {   // block-uniform: fold the 4 row-group partials in LDS, then 64 atomics per block
+    Ds[tid] = bsum;
+    __syncthreads();
+    if (tid < 64 && co0 + tid < g.Cout) atomicAdd(&dbias[co0 + tid], Ds[tid] + Ds[64 + tid] + Ds[128 + tid] + Ds[192 + tid]);
+  }
   // acc[r]: row (co) = (r&3)+8*(r>>2)+4*lh, col (k) = li
   int k = k0 + wj * 32 + li;
   if (k < g.Ktot) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int co = co0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#ifdef WGRAD_NOATOMIC
+      if (co < g.Cout) dW[(size_t)co * g.Ktot + k] = acc[r];     // timing experiment only (wrong sums)
+#else
       if (co < g.Cout) atomicAdd(&dW[(size_t)co * g.Ktot + k], acc[r]);
+#endif
     }
   }
 }
@@ -399,30 +408,35 @@ extern "C" int focr_conv2d_fwd(const float* x, const float* w, const float* bias
   return FOCR_OK;
 }
 
-// dw must hold Cout*KH*KW*Cin floats, dbias (nullable) Cout floats; both are overwritten.
+// dw must hold Cout*KH*KW*Cin floats, dbias (nullable) Cout floats.  The kernel ACCUMULATES with fp32
+// atomics: prezeroed = 0 -> the buffers are cleared here first (overwrite semantics); prezeroed = 1 ->
+// the caller guarantees they are zero (e.g. slices of a gradient buffer zeroed once per step).
 extern "C" int focr_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N,
                                  int H, int W, int Cin, int Cout, int KH, int KW, int padH,
-                                 int padW, int ldd, int ldx, hipStream_t stream) {
+                                 int padW, int ldd, int ldx, int prezeroed, hipStream_t stream) {
   ConvGeom g;
   FOCR_CHECK_ARG(x && dy && dw, "null pointer");
   FOCR_CHECK_ARG(fill_geom(g, N, H, W, Cin, Cout, KH, KW, padH, padW) == 0, "bad geometry");
   if (ldd <= 0) ldd = Cout;
   if (ldx > 0) g.ldx = ldx;
   FOCR_CHECK_ARG(ldd >= Cout && g.ldx >= Cin, "row pitch too small");
-  if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cout * g.Ktot, stream) != hipSuccess) {
+  if (!prezeroed && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cout * g.Ktot, stream) != hipSuccess) {
     focr_set_error("focr_conv2d_wgrad: memset failed");
     return FOCR_EHIP;
   }
   bool vec = (Cin % 64 == 0) && (ldd % 4 == 0) && (g.ldx % 4 == 0);
   int tiles = cdiv(g.Ktot, 64) * cdiv(Cout, 64);
-  int splits = 2048 / tiles;
-  int maxsplits = cdiv(g.M, 128);
+#ifndef WGRAD_BLOCKS
+#define WGRAD_BLOCKS 2048
+#endif
+  int splits = WGRAD_BLOCKS / tiles;
+  int maxsplits = cdiv(g.M, 256);              // >= 8 reduction chunks per block
   if (splits > maxsplits) splits = maxsplits;
   if (splits < 1) splits = 1;
   int pps = cdiv(cdiv(g.M, splits), 32) * 32;
   splits = cdiv(g.M, pps);
   dim3 grid(cdiv(g.Ktot, 64), cdiv(Cout, 64), splits);
-  if (dbias && hipMemsetAsync(dbias, 0, sizeof(float) * Cout, stream) != hipSuccess) {
+  if (dbias && !prezeroed && hipMemsetAsync(dbias, 0, sizeof(float) * Cout, stream) != hipSuccess) {
     focr_set_error("focr_conv2d_wgrad: memset failed");
     return FOCR_EHIP;
   }

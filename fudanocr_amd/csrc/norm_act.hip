@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ invstd,
-    float* __restrict__ sums, long rows, int C, int act) {
+    float* __restrict__ sum_g, float* __restrict__ sum_gx, long rows, int C, int act) {
   __shared__ float red[2][4][64];
   int c = blockIdx.x * 64 + (threadIdx.x & 63);
   int rl = threadIdx.x >> 6;
@@ -129,8 +129,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
   __syncthreads();
   if (rl == 0 && c < C) {
     int t = threadIdx.x;
-    atomicAdd(&sums[c], red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t]);
-    atomicAdd(&sums[C + c], red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t]);
+    atomicAdd(&sum_g[c], red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t]);
+    atomicAdd(&sum_gx[c], red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t]);
   }
 }
 
@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ sums, float* __restrict__ dx, long total4, long rows, int C, int act) {
+    const float* __restrict__ sum_g, const float* __restrict__ sum_gx, float* __restrict__ dx, long total4,
+    long rows, int C, int act) {
   const float inv_rows = 1.f / (float)rows;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
        i += (long)gridDim.x * blockDim.x) {
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
       float g_ = gamma[c + e], is = invstd[c + e];
       float xh = (vv[e] - mean[c + e]) * is;
       float g = dd[e] * act_grad(g_ * xh + beta[c + e], act);
-      if (sums) g = g - sums[c + e] * inv_rows - xh * sums[C + c + e] * inv_rows;
+      if (sum_g) g = g - sum_g[c + e] * inv_rows - xh * sum_gx[c + e] * inv_rows;
       oo[e] = g_ * is * g;
     }
     reinterpret_cast<float4*>(dx)[i] = make_float4(oo[0], oo[1], oo[2], oo[3]);
@@ -511,30 +512,30 @@ extern "C" int focr_bn_eval_fwd(const float* x, const float* gamma, const float*
   return FOCR_OK;
 }
 
-// train-mode backward.  dgamma/dbeta: C floats each (overwritten); ws: 2*C floats.
-// train == 0: eval-mode backward (mean = running_mean, no batch-statistics terms, no dgamma).
+// train-mode backward.  dgamma/dbeta: C floats each.  They double as the reduction accumulators
+// (sum g*xhat = dgamma, sum g = dbeta): prezeroed = 0 -> cleared here first, 1 -> caller guarantees zeros.
+// train == 0: eval-mode backward (mean = running_mean, no batch-statistics terms, no dgamma/dbeta).
 extern "C" int focr_bn_bwd(const float* dz, const float* x, const float* gamma, const float* beta,
                            const float* mean, const float* invstd, float* dx, float* dgamma,
-                           float* dbeta, float* ws, long rows, int C, int act, int train,
+                           float* dbeta, long rows, int C, int act, int train, int prezeroed,
                            hipStream_t stream) {
   FOCR_CHECK_ARG(dz && x && gamma && beta && mean && invstd && dx, "null pointer");
   FOCR_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0, "need C % 4 == 0");
   long total4 = rows * C / 4;
   if (train) {
-    FOCR_CHECK_ARG(ws && dgamma && dbeta, "null pointer");
-    MEMSET0(ws, sizeof(float) * 2 * C);
-    dim3 g(cdiv(C, 64), row_slabs(rows));
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, g, 256, 0, stream, dz, x, gamma, beta, mean, invstd, ws, rows, C, act);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), 256, 0, stream, dz, x, gamma, beta, mean,
-                       invstd, (const float*)ws, dx, total4, rows, C, act);
-    if (hipMemcpyAsync(dbeta, ws, sizeof(float) * C, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
-        hipMemcpyAsync(dgamma, ws + C, sizeof(float) * C, hipMemcpyDeviceToDevice, stream) != hipSuccess) {
-      focr_set_error("focr_bn_bwd: memcpy failed");
-      return FOCR_EHIP;
+    FOCR_CHECK_ARG(dgamma && dbeta, "null pointer");
+    if (!prezeroed) {
+      MEMSET0(dgamma, sizeof(float) * C);
+      MEMSET0(dbeta, sizeof(float) * C);
     }
+    dim3 g(cdiv(C, 64), row_slabs(rows));
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, g, 256, 0, stream, dz, x, gamma, beta, mean, invstd, dbeta, dgamma,
+                       rows, C, act);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), 256, 0, stream, dz, x, gamma, beta, mean,
+                       invstd, (const float*)dbeta, (const float*)dgamma, dx, total4, rows, C, act);
   } else {
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), 256, 0, stream, dz, x, gamma, beta, mean,
-                       invstd, (const float*)nullptr, dx, total4, rows, C, act);
+                       invstd, (const float*)nullptr, (const float*)nullptr, dx, total4, rows, C, act);
   }
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
@@ -554,11 +555,13 @@ extern "C" int focr_layernorm_fwd(const float* x, const float* residual, const f
 extern "C" int focr_layernorm_bwd(const float* dy, const float* x, const float* residual,
                                   const float* a, const float* save_mean, const float* save_rinv,
                                   float* dx, float* da, float* db, long rows, int D, float eps,
-                                  hipStream_t stream) {
+                                  int prezeroed, hipStream_t stream) {
   FOCR_CHECK_ARG(dy && x && a && save_mean && save_rinv && dx && da && db, "null pointer");
   FOCR_CHECK_ARG(D == 128 && rows > 0, "only D == 128 is built");
-  MEMSET0(da, sizeof(float) * D);
-  MEMSET0(db, sizeof(float) * D);
+  if (!prezeroed) {
+    MEMSET0(da, sizeof(float) * D);
+    MEMSET0(db, sizeof(float) * D);
+  }
   long g = cdiv(rows, 4);
   if (g > 1024) g = 1024;
   hipLaunchKernelGGL((ln_bwd_kernel<128>), dim3((int)g), 256, 0, stream, dy, x, residual, a, save_mean,
@@ -574,9 +577,9 @@ extern "C" int focr_prelu_fwd(const float* x, const float* slope, float* y, long
   return FOCR_OK;
 }
 extern "C" int focr_prelu_bwd(const float* dy, const float* x, const float* slope, float* dx,
-                              float* dslope, long n, hipStream_t stream) {
+                              float* dslope, long n, int prezeroed, hipStream_t stream) {
   FOCR_CHECK_ARG(dy && x && slope && dx && dslope && n > 0 && n % 4 == 0, "need n % 4 == 0");
-  MEMSET0(dslope, sizeof(float));
+  if (!prezeroed) MEMSET0(dslope, sizeof(float));
   hipLaunchKernelGGL(prelu_bwd_kernel, dim3(ew_grid(n / 4)), 256, 0, stream, dy, x, slope, dx, dslope, n / 4);
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;

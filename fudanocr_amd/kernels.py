@@ -133,12 +133,14 @@ class _Conv2d(torch.autograd.Function):
             need_db = has_bias and ctx.needs_input_grad[2]
             if need_db:
                 db = tb if tb is not None else torch.empty(cout, device=dy.device, dtype=torch.float32)
+            # targets handed out by the engine are slices of the flat gradient buffer, zeroed once per step
+            pz = int(tw is not None and (db is None or tb is not None))
             if _is_out_layer(cin, cout, kh, kw, ph, pw, w, None, alpha, relu) and not has_res:
                 _lib.call("focr_conv9x9_small_cout_wgrad", _p(x4), _p(dy4), _p(dw), _p(db), n, h, w, cin,
-                          cout, _stream())
+                          cout, pz, _stream())
             else:
                 _lib.call("focr_conv2d_wgrad", _p(x4), _p(dy4), _p(dw), _p(db), n, h, w, cin, cout, kh, kw,
-                          ph, pw, 0, 0, _stream())
+                          ph, pw, 0, 0, pz, _stream())
             if alpha != 1.0:
                 _lib.call("focr_axpy", _p(dw), _NULL, _p(dw), dw.numel(), alpha, _stream())
         elif has_bias and ctx.needs_input_grad[2]:
@@ -198,14 +200,13 @@ class _BatchNormAct(torch.autograd.Function):
             tg, tb = ctx.targets
             dg = tg if tg is not None else torch.empty(c, device=x.device)
             db = tb if tb is not None else torch.empty(c, device=x.device)
-            ws = torch.empty(2 * c, device=x.device)
             _lib.call("focr_bn_bwd", _p(dz), _p(x), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(dx), _p(dg),
-                      _p(db), _p(ws), rows, c, act, 1, _stream())
+                      _p(db), rows, c, act, 1, int(tg is not None and tb is not None), _stream())
             dg = None if tg is not None else dg
             db = None if tb is not None else db
         else:
             _lib.call("focr_bn_bwd", _p(dz), _p(x), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(dx), _NULL,
-                      _NULL, _NULL, rows, c, act, 0, _stream())
+                      _NULL, rows, c, act, 0, 0, _stream())
         return dx, dg, db, None, None, None, (dz if has_res else None), None, None, None, None
 
 
@@ -243,7 +244,7 @@ class _LayerNormStd(torch.autograd.Function):
         da = ta if ta is not None else torch.empty(d, device=x.device)
         db = tb if tb is not None else torch.empty(d, device=x.device)
         _lib.call("focr_layernorm_bwd", _p(dy), _p(x), _p(residual), _p(a), _p(mean), _p(rinv), _p(dx), _p(da),
-                  _p(db), rows, d, eps, _stream())
+                  _p(db), rows, d, eps, int(ta is not None and tb is not None), _stream())
         return dx, (dx if has_res else None), (None if ta is not None else da), (None if tb is not None else db), None
 
 
@@ -270,7 +271,8 @@ class _PReLU(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         ds = ctx.target if ctx.target is not None else torch.empty(1, device=x.device)
-        _lib.call("focr_prelu_bwd", _p(dy), _p(x), _p(slope), _p(dx), _p(ds), x.numel(), _stream())
+        _lib.call("focr_prelu_bwd", _p(dy), _p(x), _p(slope), _p(dx), _p(ds), x.numel(),
+                  int(ctx.target is not None), _stream())
         return dx, (None if ctx.target is not None else ds)
 
 
@@ -667,7 +669,7 @@ class _GRURecur(torch.autograd.Function):
         dbhh = torch.empty((2, 96), device=dh.device)
         for d in (0, 1):     # dW_hh[d] = dgh[:, d]^T hprev[:, d]  -- the generic wgrad on strided views
             _lib.call("focr_conv2d_wgrad", _po(hprev, 32 * d), _po(dgh, 96 * d), _po(dwhh, 96 * 32 * d),
-                      _po(dbhh, 96 * d), rows, 1, 1, 32, 96, 1, 1, 0, 0, 192, 64, _stream())
+                      _po(dbhh, 96 * d), rows, 1, 1, 32, 96, 1, 1, 0, 0, 192, 64, 0, _stream())
         return dgx, dwhh, dbhh, None, None, None, None, None, None
 
 

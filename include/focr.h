@@ -46,10 +46,12 @@ int focr_version(void);
 int focr_conv2d_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
                     int N, int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW,
                     float alpha, int relu, int ldy, int ldr, int ldx, focr_stream_t stream);
-/* dw[Cout][KH][KW][Cin], dbias[Cout] (nullable) are overwritten; ldd = row pitch of dy (0: Cout) */
+/* dw[Cout][KH][KW][Cin], dbias[Cout] (nullable); ldd = row pitch of dy (0: Cout).  Gradient outputs of
+ * every *_wgrad/_bwd entry are accumulated with atomics: prezeroed=0 clears them first (overwrite),
+ * prezeroed=1 means the caller guarantees zeros (slices of a gradient buffer cleared once per step). */
 int focr_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N, int H, int W,
                       int Cin, int Cout, int KH, int KW, int padH, int padW, int ldd, int ldx,
-                      focr_stream_t stream);
+                      int prezeroed, focr_stream_t stream);
 /* w[Cout][KH][KW][Cin] -> wd[Cin][KH][KW][Cout] with both spatial axes flipped */
 int focr_weight_flip_transpose(const float* w, float* wd, int Cout, int KH, int KW, int Cin,
                                focr_stream_t stream);
@@ -60,7 +62,7 @@ int focr_colsum(const float* x, float* out, long rows, int C, int ld, focr_strea
 int focr_conv9x9_small_cout_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H,
                                 int W, int Cin, int Cout, focr_stream_t stream);
 int focr_conv9x9_small_cout_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N, int H,
-                                  int W, int Cin, int Cout, focr_stream_t stream);
+                                  int W, int Cin, int Cout, int prezeroed, focr_stream_t stream);
 
 /* ---- fused attention: model/tbsrn.py:132-150 (+ the head split/merge of :116-126) -----------
  * q,k,v,o: [B,Ntok,ld], head h in columns h*32..h*32+31; lse: [B,H,Ntok]; Ntok % 128 == 0.
@@ -85,8 +87,8 @@ int focr_bn_eval_fwd(const float* x, const float* gamma, const float* beta, cons
                      const float* running_var, const float* residual, float* y, float* invstd_out,
                      long rows, int C, float eps, int act, focr_stream_t stream);
 int focr_bn_bwd(const float* dz, const float* x, const float* gamma, const float* beta, const float* mean,
-                const float* invstd, float* dx, float* dgamma, float* dbeta, float* ws /*2C*/, long rows,
-                int C, int act, int train, focr_stream_t stream);
+                const float* invstd, float* dx, float* dgamma, float* dbeta, long rows, int C, int act,
+                int train, int prezeroed, focr_stream_t stream);
 
 /* ---- the reference's own LayerNorm (unbiased std, eps on std): model/tbsrn.py:23-36 ---------- */
 int focr_layernorm_fwd(const float* x, const float* residual, const float* a, const float* b, float* y,
@@ -94,13 +96,13 @@ int focr_layernorm_fwd(const float* x, const float* residual, const float* a, co
                        focr_stream_t stream);
 int focr_layernorm_bwd(const float* dy, const float* x, const float* residual, const float* a,
                        const float* save_mean, const float* save_rinv, float* dx, float* da, float* db,
-                       long rows, int D, float eps, focr_stream_t stream);
+                       long rows, int D, float eps, int prezeroed, focr_stream_t stream);
 
 /* ---- activations / layout -------------------------------------------------------------------
  * PReLU (single slope) tsrn.py:28; PixelShuffle(2)+mish tsrn.py:101-125; tanh tsrn.py:73 */
 int focr_prelu_fwd(const float* x, const float* slope, float* y, long n, focr_stream_t stream);
 int focr_prelu_bwd(const float* dy, const float* x, const float* slope, float* dx, float* dslope, long n,
-                   focr_stream_t stream);
+                   int prezeroed, focr_stream_t stream);
 int focr_pixelshuffle_mish_fwd(const float* pre, float* z, int N, int H, int W, int C, focr_stream_t stream);
 int focr_pixelshuffle_mish_bwd(const float* dz, const float* pre, float* dpre, int N, int H, int W, int C,
                                focr_stream_t stream);

@@ -71,7 +71,7 @@ if "conv" in what:
 
         def wg():
             _lib.call("focr_conv2d_wgrad", K._p(x), K._p(y), K._p(dw), K._p(db), n, h, w, cin, cout, ks, ks, pad, pad,
-                      0, 0, K._stream())
+                      0, 0, 0, K._stream())
         m, mn = timeit(fwd)
         m2, mn2 = timeit(wg)
         print("%-26s fwd median %7.1f us min %7.1f us %6.1f TF | wgrad median %7.1f us min %7.1f %6.1f TF"
