@@ -82,11 +82,32 @@ class FusedClipAdam:
         return self.sumsq.sqrt()
 
 
+class _Boundary(torch.autograd.Function):
+    """Identity whose backward fires a callback: when the gradient flows back past this point every
+    parameter gradient of the layers behind it is final, so their bucket can start its all-reduce."""
+
+    @staticmethod
+    def forward(ctx, x, cb):
+        ctx.cb = cb
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.cb()
+        return g, None
+
+
 class TrainStep:
-    """model: SR net (TBSRN/TSRN); crit: CTCFocusLoss.  One call = one optimisation step."""
+    """model: SR net (TBSRN/TSRN); crit: CTCFocusLoss.  One call = one optimisation step.
+
+    Data-parallel overlap: `boundaries` names top-level sub-modules (in forward order).  The flat
+    gradient range of everything from a boundary up to `tail` (modules whose gradients arrive last,
+    i.e. the STN head that sits in front of the network) is all-reduced on a side stream as soon as
+    backward has passed that boundary; the remainder goes out after backward.  RCCL runs on its own
+    stream, so these collectives overlap the remaining backward kernels."""
 
     def __init__(self, model, crit, lr=1e-4, betas=(0.5, 0.999), max_norm=0.25, process_group=None,
-                 n_buckets=4, dropout=True):
+                 n_buckets=4, dropout=True, boundaries=("block3", "block6"), tail=("stn_head",)):
         self.model, self.crit = model, crit
         self.dropout = dropout        # False: nn.Dropout slots stay in eval (parity runs)
         self.flat = FlatBuffers(list(model.parameters()))
@@ -96,14 +117,72 @@ class TrainStep:
         n = self.flat.numel
         edges = [n * i // n_buckets // 4 * 4 for i in range(n_buckets)] + [n]
         self.buckets = [(edges[i], edges[i + 1]) for i in range(n_buckets) if edges[i + 1] > edges[i]]
+        self._works, self._sent = [], []
+        self._plan_overlap(boundaries, tail)
+
+    # ---- overlap plan ---------------------------------------------------------------------------
+    def _offset_of(self, module):
+        ids = {id(p): off for p, off in zip(self.flat.params, self.flat.offsets)}
+        offs = [ids[id(p)] for p in module.parameters() if id(p) in ids]
+        return min(offs) if offs else None
+
+    def _plan_overlap(self, boundaries, tail):
+        self.ranges = []                       # [(module name, (lo, hi))] in firing (backward) order
+        mods = dict(self.model.named_children())
+        main_end = self.flat.numel
+        for t in tail:
+            if t in mods and self._offset_of(mods[t]) is not None:
+                main_end = min(main_end, self._offset_of(mods[t]))
+        hi = main_end
+        for name in reversed([b for b in boundaries if b in mods]):
+            lo = self._offset_of(mods[name])
+            if lo is None or lo >= hi:
+                continue
+            self.ranges.append((name, (lo, hi)))
+            mods[name].register_forward_pre_hook(self._make_hook(len(self.ranges) - 1))
+            hi = lo
+        self.rest = [(0, hi)] + ([(main_end, self.flat.numel)] if main_end < self.flat.numel else [])
+        self.comm_stream = torch.cuda.Stream() if (self.world > 1 and self.flat.flat_grad.is_cuda) else None
+
+    def _make_hook(self, idx):
+        def pre_hook(module, args):
+            if self.world == 1 or not torch.is_grad_enabled() or not args[0].requires_grad:
+                return None
+            return (_Boundary.apply(args[0], lambda: self._launch(self.ranges[idx][1])),) + tuple(args[1:])
+        return pre_hook
+
+    def _launch(self, rng):
+        lo, hi = rng
+        if hi <= lo:
+            return
+        self._sent.append(rng)
+        view = self.flat.flat_grad[lo:hi]
+        if self.comm_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record()                                    # gradients of this range are complete here
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def allreduce_grads(self):
+        """All-reduce whatever the backward hooks have not sent yet, then wait for everything."""
         if self.world == 1:
             return
-        works = [dist.all_reduce(self.flat.flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-                 for a, b in self.buckets]
-        for w in works:
+        sent = sorted(self._sent)
+        todo, pos = [], 0
+        for lo, hi in sent + [(self.flat.numel, self.flat.numel)]:
+            if lo > pos:
+                todo.append((pos, lo))
+            pos = max(pos, hi)
+        for lo, hi in todo:                                   # few large messages (xGMI ring is per-link bound)
+            step = max(4, (hi - lo + len(self.buckets) - 1) // len(self.buckets) // 4 * 4)
+            for a in range(lo, hi, step):
+                self._launch((a, min(hi, a + step)))
+        for w in self._works:
             w.wait()
+        self._works, self._sent = [], []
 
     def __call__(self, images_lr, images_hr, label_strs=None, encoded=None):
         self.model.train()
@@ -112,6 +191,7 @@ class TrainStep:
                 if isinstance(m, torch.nn.Dropout):
                     m.eval()
         self.flat.zero_grad()
+        self._works, self._sent = [], []
         sr = self.model(images_lr)
         loss, mse, _, ctc = self.crit(sr, images_hr, label_strs, encoded)
         (loss * 100).backward()

@@ -1,0 +1,108 @@
+"""TextBase: the reference's mission base class (interfaces/base.py:33-325) restated for one process per
+GPU on the HIP modules.  Same method names and call order; DataParallel (base.py:178-179) is replaced by
+fudanocr_amd.engine.TrainStep (flat buffers + RCCL all-reduce); the checkpoint dict keeps the reference
+schema (base.py:255-272) with un-prefixed state_dict keys."""
+import logging
+import os
+import shutil
+
+import torch
+
+from ..dataset.dataset import SyntheticTextZoom
+from ..loss.ctc_focus_loss import CTCFocusLoss
+from ..model import tbsrn, tsrn
+from ..model.crnn import crnn
+from ..utils import ssim_psnr, util
+from ..utils.utils_crnn import strLabelConverter
+from ..utils.weight_fill import fill_module_
+from .. import kernels as K
+
+
+class TextBase(object):
+    def __init__(self, config, args):
+        self.config, self.args = config, args
+        self.scale_factor = config.TRAIN.down_sample_scale
+        self.mask = bool(getattr(args, "mask", False))
+        self.resume = args.resume if args.resume is not None else config.TRAIN.resume
+        self.batch_size = args.batch_size if args.batch_size is not None else config.TRAIN.batch_size
+        self.exp_name = args.exp_name
+        self.voc_type = config.TRAIN.voc_type
+        if not torch.cuda.is_available():
+            raise RuntimeError("fudanocr_amd needs an MI355X: there is no CPU fallback (the CPU oracle is test-only)")
+        self.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        alphabet = "0123456789abcdefghijklmnopqrstuvwxyz"
+        self.converter_crnn = strLabelConverter(alphabet)
+        self.cal_psnr = ssim_psnr.calculate_psnr
+        self.cal_ssim = ssim_psnr.SSIM()
+        self.ckpt_path = os.path.join("checkpoint", self.exp_name)
+        if not args.test and not getattr(args, "demo", False):
+            if os.path.exists(self.ckpt_path) and not self.resume:
+                shutil.rmtree(self.ckpt_path)              # reference base.py:80-84
+            os.makedirs(self.ckpt_path, exist_ok=True)
+            logging.basicConfig(format="%(message)s", level=logging.INFO, force=True,
+                                handlers=[logging.FileHandler(os.path.join(self.ckpt_path, "log.txt")),
+                                          logging.StreamHandler()])
+        self.logging = logging
+
+    # ---- data ------------------------------------------------------------------------------
+    def get_train_data(self):
+        cfg = self.config.TRAIN
+        if cfg.train_data_dir:
+            raise NotImplementedError("TextZoom LMDB reader is not built in this image (SURVEY.md 8f N3)")
+        ds = SyntheticTextZoom(self.batch_size, int(getattr(cfg, "iters_per_epoch", 20)), cfg.manualSeed, self.mask)
+        return ds, ds
+
+    def get_val_data(self):
+        ds = SyntheticTextZoom(self.batch_size, 2, 99, self.mask)
+        return [ds], [ds]
+
+    # ---- model / optimiser --------------------------------------------------------------------
+    def generator_init(self):
+        a = self.args
+        common = dict(scale_factor=self.scale_factor, width=self.config.TRAIN.width, height=self.config.TRAIN.height,
+                      STN=a.STN, mask=self.mask, srb_nums=a.srb, hidden_units=a.hd_u)
+        if a.arch == "tbsrn":
+            model = tbsrn.TBSRN(**common)
+        elif a.arch == "tsrn":
+            model = tsrn.TSRN(**common)
+        else:
+            raise ValueError("only the hot-path architectures are built: tbsrn, tsrn")
+        model = model.to(self.device)
+        if self.resume:
+            self.logging.info("loading pre-trained model from %s " % self.resume)
+            model.load_state_dict(torch.load(self.resume, map_location=self.device)["state_dict_G"])
+        para_num = sum(p.numel() for p in model.parameters())
+        self.logging.info("Total Parameters {}".format(para_num))
+        rec, _ = self.CRNN_init() if getattr(a, "ctc", True) else (None, None)
+        return {"model": model, "crit": CTCFocusLoss(rec), "recognizer": rec}
+
+    def optimizer_init(self, model, crit):
+        from ..engine import TrainStep
+        cfg = self.config.TRAIN
+        return TrainStep(model, crit, lr=cfg.lr, betas=(cfg.beta1, 0.999), max_norm=0.25)
+
+    def CRNN_init(self):
+        model = crnn.CRNN(32, 1, 37, 256)
+        path = self.config.TRAIN.VAL.crnn_pretrained
+        if path:
+            self.logging.info("loading pretrained crnn model from %s" % path)
+            model.load_state_dict(torch.load(path, map_location="cpu"))
+        else:
+            fill_module_(model)
+        model = model.to(self.device).eval()
+        for p in model.parameters():
+            p.requires_grad = False
+        return model, None
+
+    def parse_crnn_data(self, imgs_input):
+        return K.bicubic_gray(imgs_input, 100)
+
+    def save_checkpoint(self, netG, epoch, iters, best_acc_dict, best_model_info, is_best, converge_list, exp_name):
+        os.makedirs(self.ckpt_path, exist_ok=True)
+        save_dict = {
+            "state_dict_G": {k: v.detach().cpu().contiguous() for k, v in netG.state_dict().items()},
+            "info": {"arch": self.args.arch, "iters": iters, "epochs": epoch, "batch_size": self.batch_size,
+                     "voc_type": self.voc_type, "up_scale_factor": self.scale_factor},
+            "best_history_res": best_acc_dict, "best_model_info": best_model_info,
+            "param_num": sum(p.nelement() for p in netG.parameters()), "converge": converge_list}
+        torch.save(save_dict, os.path.join(self.ckpt_path, "model_best.pth" if is_best else "checkpoint.pth"))

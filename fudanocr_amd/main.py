@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Entry point with the reference's command line (scene-text-telescope/main.py:17-40):
+  python -m fudanocr_amd.main --arch tbsrn --batch_size 128 --STN --exp_name X [--test] [--resume ckpt]
+Multi-GPU: launch with torch.distributed.run, one process per GPU (replaces yaml `ngpu` + DataParallel)."""
+import argparse
+import os
+
+import yaml
+
+from .interfaces.super_resolution import TextSR
+from .utils.util import AttrDict
+
+
+def main(config, args):
+    mission = TextSR(config, args)
+    if args.test:
+        return mission.test()
+    return mission.train()
+
+
+def parse(argv=None):
+    p = argparse.ArgumentParser(description="")
+    p.add_argument("--arch", default="tbsrn", choices=["tbsrn", "tsrn"])
+    p.add_argument("--text_focus", action="store_true", help="reference flag; the text-focus recognizer is out of scope")
+    p.add_argument("--exp_name", required=True, help="Type your experiment name")
+    p.add_argument("--test", action="store_true", default=False)
+    p.add_argument("--test_data_dir", type=str, default="")
+    p.add_argument("--batch_size", type=int, default=None)
+    p.add_argument("--resume", type=str, default=None)
+    p.add_argument("--rec", default="crnn", choices=["crnn"])
+    p.add_argument("--STN", action="store_true", default=False)
+    p.add_argument("--syn", action="store_true", default=False)
+    p.add_argument("--mixed", action="store_true", default=False)
+    p.add_argument("--mask", action="store_true", default=False)
+    p.add_argument("--hd_u", type=int, default=32)
+    p.add_argument("--srb", type=int, default=5)
+    p.add_argument("--demo", action="store_true", default=False)
+    p.add_argument("--demo_dir", type=str, default="./demo")
+    return p.parse_args(argv)
+
+
+if __name__ == "__main__":
+    args = parse()
+    cfg_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config", "super_resolution.yaml")
+    config = AttrDict(yaml.load(open(cfg_path), Loader=yaml.Loader))
+    main(config, args)

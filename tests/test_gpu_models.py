@@ -188,3 +188,27 @@ def test_full_size_properties():
     assert all(np.isfinite(losses)), losses
     assert out["sr"].abs().max().item() < 1.0
     assert losses[-1] < losses[0], losses
+
+
+def test_harness_train_eval_checkpoint(tmp_path, monkeypatch):
+    """TextSR harness (reference main.py -> interfaces): 3 synthetic training iterations, eval (PSNR/SSIM/
+    accuracy), checkpoint in the reference schema, reload into a fresh model."""
+    import os
+    import yaml
+    from fudanocr_amd import main as M
+    from fudanocr_amd.utils.util import AttrDict
+    monkeypatch.chdir(tmp_path)
+    cfg = AttrDict(yaml.load(open(os.path.join(os.path.dirname(M.__file__), "config", "super_resolution.yaml")),
+                             Loader=yaml.Loader))
+    cfg.TRAIN.iters_per_epoch, cfg.TRAIN.displayInterval, cfg.TRAIN.saveInterval = 3, 1, 2
+    args = M.parse(["--arch", "tbsrn", "--STN", "--exp_name", "t", "--batch_size", "8"])
+    res = M.main(cfg, args)
+    assert res["images_per_sec"] > 0
+    ck = torch.load(tmp_path / "checkpoint" / "t" / "model_best.pth", weights_only=False)
+    assert set(ck) == {"state_dict_G", "info", "best_history_res", "best_model_info", "param_num", "converge"}
+    assert ck["info"]["arch"] == "tbsrn" and ck["param_num"] == 3210335 and len(ck["state_dict_G"]) == 346
+    from fudanocr_amd.model import tbsrn
+    m = tbsrn.TBSRN(STN=True)
+    m.load_state_dict(ck["state_dict_G"])
+    conv = ck["converge"][-1]
+    assert 0 <= conv["acc"] <= 1 and conv["psnr"] > 0 and -1 <= conv["ssim"] <= 1

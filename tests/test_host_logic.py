@@ -23,6 +23,11 @@ def _header_functions():
     return out
 
 
+@pytest.fixture(scope="module")
+def golden_dir():
+    return os.path.join(ROOT, "tests", "golden")
+
+
 def test_c_abi_exports_every_declared_symbol():
     import __graft_entry__ as G
     G.build()                                            # hipcc cross-compiles without a GPU
@@ -89,26 +94,33 @@ from fudanocr_amd.engine import TrainStep
 rank = int(os.environ["RANK"])
 dist.init_process_group("gloo")
 torch.manual_seed(0)
-net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
-step = TrainStep(net, crit=None, n_buckets=3)
-assert step.world == 2 and len(step.buckets) >= 2
+def make():
+    return torch.nn.Sequential(__import__("collections").OrderedDict(
+        block1=torch.nn.Linear(7, 6), a1=torch.nn.Tanh(), block3=torch.nn.Linear(6, 5), a2=torch.nn.Tanh(),
+        block6=torch.nn.Linear(5, 3)))
+net = make()
+step = TrainStep(net, crit=None, n_buckets=3)      # boundaries block3 / block6 exist -> overlap hooks
+assert step.world == 2 and [n for n, _ in step.ranges] == ["block6", "block3"], step.ranges
 g = torch.Generator().manual_seed(100 + rank)
 x = torch.randn(4, 7, generator=g)
 step.flat.zero_grad()
 net(x).pow(2).mean().backward()
-local = step.flat.flat_grad.clone()
+assert len(step._sent) == 2, step._sent             # both boundary buckets were launched DURING backward
 step.allreduce_grads()
-both = [torch.zeros_like(local) for _ in range(2)]
-dist.all_gather(both, local)
-assert torch.allclose(step.flat.flat_grad, both[0] + both[1], atol=1e-7)
+# reference: every rank recomputes both shards' gradients locally and sums them
+tot = torch.zeros_like(step.flat.flat_grad)
+for r in range(2):
+    n2 = make(); n2.load_state_dict(net.state_dict())
+    n2(torch.randn(4, 7, generator=torch.Generator().manual_seed(100 + r))).pow(2).mean().backward()
+    for off, q in zip(step.flat.offsets, n2.parameters()):
+        tot[off:off + q.numel()] += q.grad.reshape(-1)
+assert torch.allclose(step.flat.flat_grad, tot, atol=1e-6), (step.flat.flat_grad - tot).abs().max()
 # gradient of the 2-shard global batch = mean of shard gradients = flat_grad / world
 full = torch.cat([torch.randn(4, 7, generator=torch.Generator().manual_seed(100 + r)) for r in range(2)])
-net2 = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
-net2.load_state_dict(net.state_dict())
+net2 = make(); net2.load_state_dict(net.state_dict())
 net2(full).pow(2).mean().backward()
-ref = torch.cat([p.grad.reshape(-1) for p in net2.parameters()])
-got = torch.cat([p.grad.reshape(-1) for p in net.parameters()]) / 2
-assert torch.allclose(got, ref, atol=1e-6), (got - ref).abs().max()
+for (p, off), q in zip(zip(step.flat.params, step.flat.offsets), net2.parameters()):
+    assert torch.allclose(step.flat.flat_grad[off:off + q.numel()] / 2, q.grad.reshape(-1), atol=1e-6)
 dist.destroy_process_group()
 print("rank", rank, "ok")
 """
@@ -123,3 +135,18 @@ def test_data_parallel_allreduce_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, o)
+
+
+def test_eval_metrics_match_reference(golden_dir):
+    """PSNR / SSIM / str_filt of the harness vs values produced by the reference's utils (fixture F9)."""
+    import json
+    from fudanocr_amd.utils import ssim_psnr
+    from fudanocr_amd.utils.util import str_filt
+    ref = json.load(open(os.path.join(golden_dir, "metrics.json")))
+    g = torch.Generator().manual_seed(11)
+    ia = torch.rand(3, 3, 32, 128, generator=g)
+    ib = (ia + 0.1 * torch.randn(3, 3, 32, 128, generator=g)).clamp(0, 1)
+    assert abs(float(ssim_psnr.calculate_psnr(ia, ib)) - ref["psnr"]) < 1e-4
+    assert abs(float(ssim_psnr.SSIM()(ia, ib)) - ref["ssim"]) < 1e-5
+    for text, voc, want in ref["str_filt"]:
+        assert str_filt(text, voc) == want

@@ -198,6 +198,16 @@ def main():
         tps_ctrl=ctrl.numpy(), tps_img=img2.numpy(), tps_out=warped.numpy(),
         tps_inv=tps.inverse_kernel.numpy(), tps_repr=tps.target_coordinate_repr.numpy(),
     )
+    # ---- F9: evaluation metrics (utils/ssim_psnr.py) and label filter (utils/util.py) ----
+    from utils import ssim_psnr as ref_metrics
+    from utils import util as ref_util
+    g = torch.Generator().manual_seed(11)
+    ia = torch.rand(3, 3, 32, 128, generator=g)
+    ib = (ia + 0.1 * torch.randn(3, 3, 32, 128, generator=g)).clamp(0, 1)
+    with open(os.path.join(OUT, "metrics.json"), "w") as f:
+        json.dump({"psnr": float(ref_metrics.calculate_psnr(ia, ib)), "ssim": float(ref_metrics.SSIM()(ia, ib)),
+                   "str_filt": [[t, v, ref_util.str_filt(t, v)] for t, v in
+                                (("Ab-9 z!", "lower"), ("Ab-9 z!", "all"), ("Ab-9 z!", "digit"), ("Ab-9 z!", "upper"))]}, f)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden written to", OUT, "total bytes", total)
 
