@@ -54,6 +54,8 @@ SIGNATURES = {
     "focr_ctc_fwd": [P, P, P, P, P, P, P, I, I, I, P],
     "focr_scale_dev": [P, P, P, L, P],
     "focr_grad_sumsq": [P, P, L, F, P],
+    "focr_set_precision": [I],
+    "focr_get_precision": [],
     "focr_clip_adam": [P, P, P, P, P, L, F, F, F, F, I, F, F, P],
 }
 
@@ -100,6 +102,15 @@ def stop_timing():
     out = {n: [a.elapsed_time(b) for a, b in ev] for n, ev in (_timed or {}).items()}
     _timed = None
     return out
+
+
+def set_precision(mode):
+    """0 = fp32 MFMA, 1 = split-bf16 ("bf16x3") MFMA for the kernels that have both paths."""
+    call("focr_set_precision", int(mode))
+
+
+def get_precision():
+    return load().focr_get_precision()
 
 
 def call(name, *args):

@@ -387,6 +387,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
                     dqacc[4 * g + 3] * scale);
 }
 
+int focr_attn_fwd_bx3(const float* q, const float* k, const float* v, float* o, float* lse, uint32_t* mask,
+                      int B, int H, int Ntok, int ld, float scale, float p_drop, uint64_t seed,
+                      hipStream_t stream);
+int focr_attn_bwd_bx3(const float* q, const float* k, const float* v, const float* d_o, const float* lse,
+                      const float* dwork, const uint32_t* mask, float* dq, float* dk, float* dv, int B, int H,
+                      int Ntok, int ld, float scale, float p_drop, hipStream_t stream);
+
 extern "C" int focr_attention_fwd(const float* q, const float* k, const float* v, float* o,
                                   float* lse, uint32_t* mask, int B, int H, int Ntok, int ld, float scale,
                                   float p_drop, uint64_t seed, hipStream_t stream) {
@@ -394,6 +401,11 @@ extern "C" int focr_attention_fwd(const float* q, const float* k, const float* v
   FOCR_CHECK_ARG(p_drop <= 0.f || mask, "dropout needs the keep-bit buffer [B,H,Ntok,Ntok/32]");
   FOCR_CHECK_ARG(Ntok % 128 == 0 && ld >= H * 32 && ld % 4 == 0, "need Ntok%128==0, head dim 32");
   FOCR_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "bad dropout probability");
+  if (focr_get_precision() == 1) {
+    focr_attn_fwd_bx3(q, k, v, o, lse, mask, B, H, Ntok, ld, scale, p_drop, seed, stream);
+    FOCR_LAUNCH_CHECK();
+    return FOCR_OK;
+  }
   dim3 grid(B * H, Ntok / 128);   // (batch,head) fast: all blocks of a head share one XCD's L2
   if (p_drop > 0.f)
     hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ld, scale, p_drop, seed, H);
@@ -414,6 +426,11 @@ extern "C" int focr_attention_bwd(const float* q, const float* k, const float* v
   long total = (long)B * Ntok * H;
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(cdiv(total, 256)), 256, 0, stream, o, d_o, dwork, Ntok, ld, H, total);
   FOCR_LAUNCH_CHECK();
+  if (focr_get_precision() == 1) {
+    focr_attn_bwd_bx3(q, k, v, d_o, lse, dwork, mask, dq, dk, dv, B, H, Ntok, ld, scale, p_drop, stream);
+    FOCR_LAUNCH_CHECK();
+    return FOCR_OK;
+  }
   dim3 grid(B * H, Ntok / 128);   // (batch,head) fast: all blocks of a head share one XCD's L2
   if (p_drop > 0.f) {
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dk, dv, mask, Ntok, ld, scale, p_drop, H);

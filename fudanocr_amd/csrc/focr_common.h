@@ -11,6 +11,7 @@
 #define FOCR_EHIP (-3)
 
 extern "C" void focr_set_error(const char* fmt, ...);
+extern "C" int focr_get_precision(void);
 
 #define FOCR_CHECK_ARG(cond, msg)                          \
   do {                                                     \

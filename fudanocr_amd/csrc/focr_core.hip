@@ -12,3 +12,17 @@ extern "C" void focr_set_error(const char* fmt, ...) {
 }
 extern "C" const char* focr_last_error(void) { return g_err; }
 extern "C" int focr_version(void) { return 100; }
+
+// contraction precision of the MFMA kernels that have both paths:
+//   0 = exact fp32 on the f32-input MFMA (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak)
+//   1 = split bf16 ("bf16x3": hi/lo operands, 3 products, fp32 accumulate) on v_mfma_f32_32x32x16_bf16
+static int g_precision = 1;
+extern "C" int focr_set_precision(int mode) {
+  if (mode != 0 && mode != 1) {
+    focr_set_error("focr_set_precision: mode must be 0 (fp32) or 1 (bf16x3)");
+    return FOCR_EINVAL;
+  }
+  g_precision = mode;
+  return FOCR_OK;
+}
+extern "C" int focr_get_precision(void) { return g_precision; }

@@ -36,6 +36,11 @@ typedef void* focr_stream_t; /* hipStream_t */
 
 const char* focr_last_error(void);
 int focr_version(void);
+/* contraction precision of the kernels that have both paths (process-wide):
+ *   0 = exact fp32 on the f32-input MFMA; 1 (default) = split bf16 "bf16x3" (hi/lo operands, 3 products,
+ *   fp32 accumulate) on the bf16 MFMA pipe -- same end-to-end error as fp32 (tools/exp_split_precision.py) */
+int focr_set_precision(int mode);
+int focr_get_precision(void);
 
 /* ---- convolution / linear: nn.Conv2d, nn.Linear (stride 1) --------------------------------
  * model/tsrn.py:26-43,80-94,101-114,132  model/tbsrn.py:74,103,117-129,158-163

@@ -39,6 +39,9 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), "declared in focr.h but not exported: " + name
         if name in ("focr_last_error", "focr_version"):
             continue
+        if name in ("focr_set_precision", "focr_get_precision"):
+            assert len(_lib.SIGNATURES[name]) == nargs
+            continue
         assert name in _lib.SIGNATURES, "no ctypes signature for " + name
         assert len(_lib.SIGNATURES[name]) == nargs, (name, len(_lib.SIGNATURES[name]), nargs)
     for name in _lib.SIGNATURES:

@@ -13,6 +13,7 @@ B = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 1
 what = [a for a in sys.argv[1:] if not a.startswith("--") and not a.isdigit()] or ["attn", "conv"]
 
 
+
 def timeit(fn, iters=8, warm=2):
     for _ in range(warm):
         fn()
@@ -26,7 +27,9 @@ def timeit(fn, iters=8, warm=2):
     return ts[len(ts) // 2] * 1e3, ts[0] * 1e3      # median, min in us
 
 
-print("lib:", _lib.LIB_PATH, " batch", B)
+if "--fp32" in sys.argv:
+    _lib.set_precision(0)
+print("lib:", _lib.LIB_PATH, " batch", B, " precision", _lib.get_precision())
 g = torch.Generator(device="cuda").manual_seed(0)
 if "attn" in what:
     q, k, v = (torch.randn(B, 1024, 128, device="cuda", generator=g) for _ in range(3))
