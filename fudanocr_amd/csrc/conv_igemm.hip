@@ -382,6 +382,10 @@ static int fill_geom(ConvGeom& g, int N, int H, int W, int Cin, int Cout, int KH
   return 0;
 }
 
+int focr_conv_fwd_bx3(const float* x, const float* w, const float* bias, const float* residual, float* y,
+                      int N, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int padH, int padW,
+                      int M, int ldy, int ldr, int ldx, float alpha, int relu, hipStream_t stream);
+
 extern "C" int focr_conv2d_fwd(const float* x, const float* w, const float* bias,
                                const float* residual, float* y, int N, int H, int W, int Cin,
                                int Cout, int KH, int KW, int padH, int padW, float alpha, int relu,
@@ -394,6 +398,12 @@ extern "C" int focr_conv2d_fwd(const float* x, const float* w, const float* bias
   if (ldx > 0) g.ldx = ldx;
   FOCR_CHECK_ARG(g.ldy >= Cout && g.ldr >= Cout && g.ldx >= Cin, "row pitch too small");
   bool vec = (Cin % BK == 0) && (g.ldx % 4 == 0);
+  if (vec && focr_get_precision() == 1) {
+    focr_conv_fwd_bx3(x, w, bias, residual, y, N, H, W, Cin, g.OH, g.OW, Cout, KH, KW, padH, padW, g.M, g.ldy,
+                      g.ldr, g.ldx, alpha, relu, stream);
+    FOCR_LAUNCH_CHECK();
+    return FOCR_OK;
+  }
   bool wide = Cout > 32;
   dim3 grid(cdiv(g.M, BM), cdiv(Cout, wide ? 64 : 32));
   if (vec && wide)

@@ -70,7 +70,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv2d(case):
+def test_conv2d(case, precision):
     n, h, w, cin, cout, kh, kw, ph, pw = case
     x = rnd(n, cin, h, w, seed=1).requires_grad_(True)
     wt = rnd(cout, cin, kh, kw, seed=2, scale=1 / math.sqrt(cin * kh * kw)).requires_grad_(True)
@@ -82,14 +82,14 @@ def test_conv2d(case):
     wd = cl(wt)
     bd = dev(b).requires_grad_(True)
     yd = K().conv2d(xd, wd, bd, pad=(ph, pw))
-    close(yd.permute(0, 3, 1, 2), y, what="conv fwd")
+    close(yd.permute(0, 3, 1, 2), y, ptol(precision), what="conv fwd")
     yd.backward(dev(gy.permute(0, 2, 3, 1)))
-    close(xd.grad.permute(0, 3, 1, 2), x.grad, what="conv dgrad")
-    close(wd.grad, wt.grad, 5e-5, what="conv wgrad")
+    close(xd.grad.permute(0, 3, 1, 2), x.grad, ptol(precision), what="conv dgrad")
+    close(wd.grad, wt.grad, ptol(precision, 5e-5), what="conv wgrad")
     close(bd.grad, b.grad, 5e-5, what="conv bias grad")
 
 
-def test_conv2d_fused_epilogue():
+def test_conv2d_fused_epilogue(precision):
     x = rnd(2, 64, 8, 8, seed=5).requires_grad_(True)
     wt = rnd(64, 64, 3, 3, seed=6, scale=0.05).requires_grad_(True)
     b = rnd(64, seed=7).requires_grad_(True)
@@ -101,16 +101,16 @@ def test_conv2d_fused_epilogue():
     rd = dev(r.permute(0, 2, 3, 1)).requires_grad_(True)
     wd, bd = cl(wt), dev(b).requires_grad_(True)
     yd = K().conv2d(xd, wd, bd, pad=(1, 1), residual=rd, relu=True)
-    close(yd.permute(0, 3, 1, 2), y, what="fused fwd")
+    close(yd.permute(0, 3, 1, 2), y, ptol(precision), what="fused fwd")
     yd.backward(dev(gy.permute(0, 2, 3, 1)))
-    close(xd.grad.permute(0, 3, 1, 2), x.grad, what="fused dx")
-    close(rd.grad.permute(0, 3, 1, 2), r.grad, what="fused dres")
-    close(wd.grad, wt.grad, 5e-5, what="fused dw")
+    close(xd.grad.permute(0, 3, 1, 2), x.grad, ptol(precision), what="fused dx")
+    close(rd.grad.permute(0, 3, 1, 2), r.grad, ptol(precision), what="fused dres")
+    close(wd.grad, wt.grad, ptol(precision, 5e-5), what="fused dw")
 
 
 @pytest.mark.parametrize("rows,nin,nout,alpha", [(300, 128, 128, 1.0), (7, 512, 40, 0.1), (130, 512, 37, 1.0),
                                                  (2048, 128, 64, 1.0)])
-def test_linear(rows, nin, nout, alpha):
+def test_linear(rows, nin, nout, alpha, precision):
     x = rnd(rows, nin, seed=1).requires_grad_(True)
     wt = rnd(nout, nin, seed=2, scale=1 / math.sqrt(nin)).requires_grad_(True)
     b = rnd(nout, seed=3).requires_grad_(True)
@@ -119,10 +119,10 @@ def test_linear(rows, nin, nout, alpha):
     y.backward(gy)
     xd, wd, bd = (dev(t).requires_grad_(True) for t in (x, wt, b))
     yd = K().linear(xd, wd, bd, alpha=alpha)
-    close(yd, y, what="linear fwd")
+    close(yd, y, ptol(precision), what="linear fwd")
     yd.backward(dev(gy))
-    close(xd.grad, x.grad, what="linear dx")
-    close(wd.grad, wt.grad, 5e-5, what="linear dw")
+    close(xd.grad, x.grad, ptol(precision), what="linear dx")
+    close(wd.grad, wt.grad, ptol(precision, 5e-5), what="linear dw")
     close(bd.grad, b.grad, 5e-5, what="linear db")
 
 
