@@ -160,3 +160,136 @@ int focr_conv_fwd_bx3(const float* x, const float* w, const float* bias, const f
     hipLaunchKernelGGL((conv_fwd_bx3_kernel<1>), grid, 256, 0, stream, x, w, bias, residual, y, g, alpha, relu);
   return 0;
 }
+
+// =======================================================================================
+// wgrad on the bf16 pipe:  dW[co][k] += sum_p dY[p][co] * A[p][k],  k inside one tap (Cin % 64 == 0)
+// The contraction index is the pixel, so both operands are staged TRANSPOSED in LDS
+// (Dt[co][pixel], Xt[k][pixel], bf16 hi/lo, pitch 72 -> 16-byte aligned, conflict-free fragment reads);
+// two adjacent pixels are packed per 32-bit LDS store.  64 co x 64 k tile, 4 waves as 2x2 of 32x32,
+// 64 pixels per stage (4 MFMA k-steps x 3 split products), split over pixel ranges + fp32 atomics.
+// =======================================================================================
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+#define WTP 72
+
+__device__ __forceinline__ void put_cols72(__bf16* Th, __bf16* Tl, int pp, int c0, float4 r0, float4 r1) {
+  const float a[4] = {r0.x, r0.y, r0.z, r0.w}, b[4] = {r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    bf16x2 h, l;
+    __bf16 x = (__bf16)a[e], y = (__bf16)b[e];
+    h[0] = x; h[1] = y;
+    l[0] = (__bf16)(a[e] - (float)x);
+    l[1] = (__bf16)(b[e] - (float)y);
+    *reinterpret_cast<bf16x2*>(&Th[(c0 + e) * WTP + 2 * pp]) = h;
+    *reinterpret_cast<bf16x2*>(&Tl[(c0 + e) * WTP + 2 * pp]) = l;
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_bx3_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                             float* __restrict__ dW, float* __restrict__ dbias,
+                                                             ConvGeomX g, int ldd, int pix_per_split) {
+  __shared__ __attribute__((aligned(16))) __bf16 Dth[64 * WTP], Dtl[64 * WTP], Xth[64 * WTP], Xtl[64 * WTP];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int k0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
+  const int pbeg = blockIdx.z * pix_per_split;
+  const int pend = min(g.M, pbeg + pix_per_split);
+  if (pbeg >= pend) return;
+  const int tap = k0 / g.Cin, ci0 = k0 - tap * g.Cin;
+  const int tkh = tap / g.KW, tkw = tap - tkh * g.KW;
+  const int c4 = (tid & 15) * 4;              // 4 channels owned by this thread
+  const int pp0 = tid >> 4;                   // pixel pairs pp0 and pp0 + 16
+  const bool do_bias = dbias != nullptr && blockIdx.x == 0;
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  float4 dv[2][2], xv[2][2];
+  auto load_chunk = [&](int pc) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int p = pc + 2 * (pp0 + 16 * it) + j;
+        float4 d = make_float4(0.f, 0.f, 0.f, 0.f), x = d;
+        if (p < pend) {
+          int co = co0 + c4;
+          if (co + 3 < g.Cout) {
+            d = *reinterpret_cast<const float4*>(dY + (size_t)p * ldd + co);
+          } else {
+            float t[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int e = 0; e < 4; ++e)
+              if (co + e < g.Cout) t[e] = dY[(size_t)p * ldd + co + e];
+            d = make_float4(t[0], t[1], t[2], t[3]);
+          }
+          int n = p / (g.OH * g.OW);
+          int rem = p - n * (g.OH * g.OW);
+          int oy = rem / g.OW, ox = rem - oy * g.OW;
+          int iy = oy - g.padH + tkh, ix = ox - g.padW + tkw;
+          if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
+            x = *reinterpret_cast<const float4*>(X + ((size_t)((n * g.H + iy) * g.W + ix) * g.ldx + ci0 + c4));
+        }
+        dv[it][j] = d;
+        xv[it][j] = x;
+      }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int wi = wave >> 1, wj = wave & 1;
+  const int aoff = (wi * 32 + li) * WTP + 8 * lh, boff = (wj * 32 + li) * WTP + 8 * lh;
+
+  load_chunk(pbeg);
+  for (int pc = pbeg; pc < pend; pc += 64) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      put_cols72(Dth, Dtl, pp0 + 16 * it, c4, dv[it][0], dv[it][1]);
+      put_cols72(Xth, Xtl, pp0 + 16 * it, c4, xv[it][0], xv[it][1]);
+      if (do_bias) {
+        bsum.x += dv[it][0].x + dv[it][1].x;
+        bsum.y += dv[it][0].y + dv[it][1].y;
+        bsum.z += dv[it][0].z + dv[it][1].z;
+        bsum.w += dv[it][0].w + dv[it][1].w;
+      }
+    }
+    __syncthreads();
+    if (pc + 64 < pend) load_chunk(pc + 64);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Dth[aoff + 16 * m]);
+      bf16x8 al = *reinterpret_cast<const bf16x8*>(&Dtl[aoff + 16 * m]);
+      bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Xth[boff + 16 * m]);
+      bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Xtl[boff + 16 * m]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  if (do_bias) {   // threads with equal (tid & 15) own the same 4 columns: fold the 16 row groups in LDS
+    float* red = reinterpret_cast<float*>(Dth);          // 16 x 64 floats fit (64*72*2 B = 9216 B >= 4096 B)
+    red[(tid >> 4) * 64 + c4 + 0] = bsum.x;
+    red[(tid >> 4) * 64 + c4 + 1] = bsum.y;
+    red[(tid >> 4) * 64 + c4 + 2] = bsum.z;
+    red[(tid >> 4) * 64 + c4 + 3] = bsum.w;
+    __syncthreads();
+    if (tid < 64 && co0 + tid < g.Cout) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += red[r * 64 + tid];
+      atomicAdd(&dbias[co0 + tid], s);
+    }
+  }
+  int k = k0 + wj * 32 + li;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int co = co0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (co < g.Cout) atomicAdd(&dW[(size_t)co * g.Ktot + k], acc[r]);
+  }
+}
+
+int focr_conv_wgrad_bx3(const float* x, const float* dy, float* dw, float* dbias, int N, int H, int W, int Cin,
+                        int OH, int OW, int Cout, int KH, int KW, int padH, int padW, int M, int ldd, int ldx,
+                        int splits, int pps, hipStream_t stream) {
+  ConvGeomX g{N, H, W, Cin, OH, OW, Cout, KH, KW, padH, padW, KH * KW * Cin, M, Cout, Cout, ldx};
+  dim3 grid(g.Ktot / 64, (Cout + 63) / 64, splits);
+  hipLaunchKernelGGL(conv_wgrad_bx3_kernel, grid, 256, 0, stream, x, dy, dw, dbias, g, ldd, pps);
+  return 0;
+}

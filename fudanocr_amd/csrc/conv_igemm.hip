@@ -386,6 +386,10 @@ int focr_conv_fwd_bx3(const float* x, const float* w, const float* bias, const f
                       int N, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int padH, int padW,
                       int M, int ldy, int ldr, int ldx, float alpha, int relu, hipStream_t stream);
 
+int focr_conv_wgrad_bx3(const float* x, const float* dy, float* dw, float* dbias, int N, int H, int W, int Cin,
+                        int OH, int OW, int Cout, int KH, int KW, int padH, int padW, int M, int ldd, int ldx,
+                        int splits, int pps, hipStream_t stream);
+
 extern "C" int focr_conv2d_fwd(const float* x, const float* w, const float* bias,
                                const float* residual, float* y, int N, int H, int W, int Cin,
                                int Cout, int KH, int KW, int padH, int padW, float alpha, int relu,
@@ -443,14 +447,17 @@ extern "C" int focr_conv2d_wgrad(const float* x, const float* dy, float* dw, flo
   int maxsplits = cdiv(g.M, 256);              // >= 8 reduction chunks per block
   if (splits > maxsplits) splits = maxsplits;
   if (splits < 1) splits = 1;
-  int pps = cdiv(cdiv(g.M, splits), 32) * 32;
+  int pps = cdiv(cdiv(g.M, splits), 64) * 64;
   splits = cdiv(g.M, pps);
   dim3 grid(cdiv(g.Ktot, 64), cdiv(Cout, 64), splits);
   if (dbias && !prezeroed && hipMemsetAsync(dbias, 0, sizeof(float) * Cout, stream) != hipSuccess) {
     focr_set_error("focr_conv2d_wgrad: memset failed");
     return FOCR_EHIP;
   }
-  if (vec)
+  if (vec && focr_get_precision() == 1)
+    focr_conv_wgrad_bx3(x, dy, dw, dbias, N, H, W, Cin, g.OH, g.OW, Cout, KH, KW, padH, padW, g.M, ldd, g.ldx, splits,
+                        pps, stream);
+  else if (vec)
     hipLaunchKernelGGL((conv_wgrad_kernel<true>), grid, 256, 0, stream, x, dy, dw, dbias, g, ldd, pps);
   else
     hipLaunchKernelGGL((conv_wgrad_kernel<false>), grid, 256, 0, stream, x, dy, dw, dbias, g, ldd, pps);
