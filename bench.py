@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA = vector f32 peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak; the bf16x3 split issues 3 MFMA flops per algorithmic flop
 FLOP_PER_IMG = 18.131e9           # TBSRN fwd+bwd 15.311 + frozen CRNN 2.820
 
 
@@ -82,6 +83,8 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--arch", default="tbsrn")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32"],
+                    help="contraction arithmetic: split-bf16 MFMA (default) or exact fp32 MFMA")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,6 +103,7 @@ def main():
     from fudanocr_amd.smoke import build_models
     from fudanocr_amd.utils.synth import make_batch
     _lib.load()
+    _lib.set_precision(1 if args.precision == "bf16x3" else 0)
     net, rec, crit = build_models(dev, args.arch)
     step = TrainStep(net, crit, dropout=True)
     lr, hr, labels = make_batch(args.batch, 1234 + rank)
@@ -130,23 +134,36 @@ def main():
     if rank == 0:
         imgs = args.batch * world * args.steps
         value = imgs / dt
-        # dominant kernel: fused attention forward (one launch per SRB): 4*B*H*N^2*d flops
+        # roofline kernel: fused attention forward (one launch per SRB): 4*B*H*N^2*d algorithmic flops;
+        # on-stream event time of the C-ABI call (a single kernel launch) in the timed region
         fwd_ms = sum(kt["focr_attention_fwd"]) / max(1, len(kt["focr_attention_fwd"]))
         flops_launch = 4.0 * args.batch * 4 * 1024 * 1024 * 32
         ach = flops_launch / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
+        bx3 = args.precision == "bf16x3"
+        peak = PEAK_BF16_MFMA_TFLOPS if bx3 else PEAK_F32_MFMA_TFLOPS
+        # HBM bytes per launch from the PMC passes (profiles/README.md): (2*FETCH_SIZE + WRITE_SIZE) KB,
+        # measured at per-GPU batch 128 only
+        traffic = None
+        if args.batch == 128:
+            traffic = 354.6e6 if bx3 else 1.18e9
         res = {
             "metric": "training images/sec (16x64->32x128 SR+CTC step)", "value": round(value, 2),
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16x3" if bx3 else "f32", "data": "synthetic",
             "config": {"workload": "TBSRN + frozen CRNN-CTC train step (BASELINE configs[2]), STN on, "
                                    "dropout on, 16x64->32x128", "per_gpu_batch": args.batch,
-                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "arch": args.arch},
-            "roofline": {"bound": "mfma", "kernel": "attn_fwd_kernel (fused QK^T-softmax-dropout-PV, f32 MFMA)",
-                         "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "arch": args.arch,
+                       "arithmetic": "split-bf16 MFMA (hi/lo operands, 3 products, fp32 accumulate)" if bx3
+                       else "exact fp32 MFMA"},
+            "roofline": {"bound": "mfma",
+                         "kernel": ("attn_fwd_bx3_kernel" if bx3 else "attn_fwd_kernel") +
+                                   " (fused QK^T-softmax-dropout-PV)",
+                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(ach / peak, 4), "traffic": traffic,
                          "avg_launch_ms": round(fwd_ms, 4),
-                         "step_frac_of_peak": round(value * FLOP_PER_IMG / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+                         "executed_mfma_frac": round((3 if bx3 else 1) * ach / peak, 4),
+                         "step_algorithmic_tflops": round(value * FLOP_PER_IMG / world / 1e12, 2)},
             "final_loss": round(loss, 5),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -26,15 +26,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
                                                        const float* __restrict__ K,
                                                        const float* __restrict__ V,
                                                        float* __restrict__ O, float* __restrict__ LSE,
-                                                       uint32_t* __restrict__ MASK, int Ntok, int ld,
+                                                       const uint32_t* __restrict__ MASK, int Ntok, int ld,
                                                        float scale, float p_drop, uint64_t seed, int nheads) {
   __shared__ __attribute__((aligned(16))) float Ks[64 * KP];
   __shared__ __attribute__((aligned(16))) float Vs[64 * 32];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
-  const int H = nheads, h = blockIdx.x % nheads, b = blockIdx.x / nheads;
+  int bh_, qb_;
+  attn_block_decode(blockIdx.x, gridDim.x / (Ntok / 128), Ntok / 128, bh_, qb_);
+  const int H = nheads, h = bh_ % nheads, b = bh_ / nheads;
   const size_t base = (size_t)b * Ntok * ld + h * 32;
-  const int q = blockIdx.y * 128 + wave * 32 + li;
+  const int q = qb_ * 128 + wave * 32 + li;
 
   float4 qf[4];
 #pragma unroll
@@ -50,8 +52,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   // the keep bits are packed (bit = key % 32) and written out for the two backward kernels
   const uint32_t thr = DROPOUT ? (uint32_t)(p_drop * 65536.0f + 0.5f) : 0u;
   const float inv_keep = DROPOUT ? 1.f / (1.f - (float)thr / 65536.f) : 1.f;
-  const uint32_t rowkey = rng_rowkey(seed, (uint32_t)((b * H + h) * Ntok + q));
-  uint32_t mwords[2] = {0u, 0u};
+  const uint32_t* mrow = MASK + ((size_t)(b * H + h) * Ntok + q) * (size_t)(Ntok / 32);
 
   // staging: 64 rows x 8 float4 per tile, thread -> (row = idx>>3, c4 = idx&7), idx = tid+256*i
   // staging registers (named scalars: arrays captured by a lambda end up in scratch)
@@ -75,6 +76,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     *reinterpret_cast<float4*>(&Vs[(srow + 32) * 32 + scol]) = vreg1;
     __syncthreads();
     if (kt + 1 < ntiles) LOAD_TILE(kt + 1);
+    uint2 mw = make_uint2(0u, 0u);
+    if (DROPOUT) mw = *reinterpret_cast<const uint2*>(mrow + kt * 2);
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       f32x16 s;
@@ -103,18 +106,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         s[r] = p;
       }
       if (DROPOUT) {
-        uint32_t bits = 0u;
+        const uint32_t w = sub ? mw.y : mw.x;
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {          // regs (r, r+1) hold adjacent keys (2j, 2j+1)
-          int key = kt * 64 + sub * 32 + key_of(r, lh);
-          uint32_t hsh = rng_elem(rowkey, (uint32_t)(key >> 1));
-          bool k0 = (hsh & 0xffffu) >= thr, k1 = (hsh >> 16) >= thr;
-          s[r] = k0 ? s[r] * inv_keep : 0.f;
-          s[r + 1] = k1 ? s[r + 1] * inv_keep : 0.f;
-          bits |= ((k0 ? 1u : 0u) | (k1 ? 2u : 0u)) << ((r & 3) + 8 * (r >> 2));
-        }
-        bits <<= 4 * lh;
-        mwords[sub] = bits | __shfl_xor(bits, 32, 64);
+        for (int r = 0; r < 16; ++r) s[r] = ((w >> key_of(r, lh)) & 1u) ? s[r] * inv_keep : 0.f;
       }
       l = l * alpha + ls;
 #pragma unroll
@@ -125,9 +119,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(v, s[r], oacc, 0, 0, 0);
       }
     }
-    if (DROPOUT && lh == 0)
-      *reinterpret_cast<uint2*>(MASK + ((size_t)(b * H + h) * Ntok + q) * (Ntok / 32) + kt * 2) =
-          make_uint2(mwords[0], mwords[1]);
     __syncthreads();
   }
   l += __shfl_xor(l, 32, 64);
@@ -140,6 +131,26 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     *reinterpret_cast<float4*>(orow + 8 * g + 4 * lh) = v;
   }
   if (lh == 0) LSE[(size_t)(b * H + h) * Ntok + q] = m + __logf(l);
+}
+
+// Dropout keep bits, 1 bit per score: word (row, j) covers keys 32j..32j+31 of query row `row`
+// (row = (b*H+h)*Ntok + q).  One counter hash yields two 16-bit draws (adjacent keys); p is quantised to
+// 1/65536.  A pure-VALU pre-pass: the three attention kernels then only test bits.
+__global__ __launch_bounds__(256) void attn_mask_kernel(uint32_t* __restrict__ mask, long nwords, int wpr,
+                                                        float p_drop, uint64_t seed) {
+  const uint32_t thr = (uint32_t)(p_drop * 65536.0f + 0.5f);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (long)gridDim.x * blockDim.x) {
+    uint32_t row = (uint32_t)(i / wpr), j = (uint32_t)(i % wpr);
+    uint32_t rk = rng_rowkey(seed, row);
+    uint32_t w = 0u;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      uint32_t hsh = rng_elem(rk, j * 16 + t);
+      w |= (((hsh & 0xffffu) >= thr) ? 1u : 0u) << (2 * t);
+      w |= (((hsh >> 16) >= thr) ? 1u : 0u) << (2 * t + 1);
+    }
+    mask[i] = w;
+  }
 }
 
 // D[b,h,q] = sum_d dO[q][d] * O[q][d]
@@ -182,10 +193,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
   __shared__ uint32_t Mw[4][64];     // keep-bit word of (query, this wave's 32-key group)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
-  const int H = nheads, h = blockIdx.x % nheads, b = blockIdx.x / nheads;
+  int bh_, qb_;
+  attn_block_decode(blockIdx.x, gridDim.x / (Ntok / 128), Ntok / 128, bh_, qb_);
+  const int H = nheads, h = bh_ % nheads, b = bh_ / nheads;
   const size_t base = (size_t)b * Ntok * ld + h * 32;
   const size_t sbase = (size_t)(b * H + h) * Ntok;
-  const int key = blockIdx.y * 128 + wave * 32 + li;
+  const int key = qb_ * 128 + wave * 32 + li;
 
   float4 kf[4], vf[4];
 #pragma unroll
@@ -215,7 +228,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
       dreg = Dv[sbase + (qt) * 64 + tid];                                               \
     }                                                                                   \
     if (DROPOUT)                                                                        \
-      mreg = MASK[(sbase + (qt) * 64 + (tid & 63)) * (Ntok / 32) + blockIdx.y * 4 + (tid >> 6)]; \
+      mreg = MASK[(sbase + (qt) * 64 + (tid & 63)) * (Ntok / 32) + qb_ * 4 + (tid >> 6)]; \
   } while (0)
   const int ntiles = Ntok / 64;
   LOAD_QTILE(0);
@@ -301,10 +314,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
   __shared__ __attribute__((aligned(16))) float Vs[64 * KP];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
-  const int H = nheads, h = blockIdx.x % nheads, b = blockIdx.x / nheads;
+  int bh_, qb_;
+  attn_block_decode(blockIdx.x, gridDim.x / (Ntok / 128), Ntok / 128, bh_, qb_);
+  const int H = nheads, h = bh_ % nheads, b = bh_ / nheads;
   const size_t base = (size_t)b * Ntok * ld + h * 32;
   const size_t sbase = (size_t)(b * H + h) * Ntok;
-  const int q = blockIdx.y * 128 + wave * 32 + li;
+  const int q = qb_ * 128 + wave * 32 + li;
 
   float4 qf[4], gf[4];
 #pragma unroll
@@ -401,12 +416,18 @@ extern "C" int focr_attention_fwd(const float* q, const float* k, const float* v
   FOCR_CHECK_ARG(p_drop <= 0.f || mask, "dropout needs the keep-bit buffer [B,H,Ntok,Ntok/32]");
   FOCR_CHECK_ARG(Ntok % 128 == 0 && ld >= H * 32 && ld % 4 == 0, "need Ntok%128==0, head dim 32");
   FOCR_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "bad dropout probability");
+  if (p_drop > 0.f) {
+    long nwords = (long)B * H * Ntok * (Ntok / 32);
+    long gsz = (nwords + 255) / 256;
+    if (gsz > 4096) gsz = 4096;
+    hipLaunchKernelGGL(attn_mask_kernel, dim3((int)gsz), 256, 0, stream, mask, nwords, Ntok / 32, p_drop, seed);
+  }
   if (focr_get_precision() == 1) {
     focr_attn_fwd_bx3(q, k, v, o, lse, mask, B, H, Ntok, ld, scale, p_drop, seed, stream);
     FOCR_LAUNCH_CHECK();
     return FOCR_OK;
   }
-  dim3 grid(B * H, Ntok / 128);   // (batch,head) fast: all blocks of a head share one XCD's L2
+  dim3 grid(B * H * (Ntok / 128));   // see attn_block_decode()
   if (p_drop > 0.f)
     hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ld, scale, p_drop, seed, H);
   else
@@ -431,7 +452,7 @@ extern "C" int focr_attention_bwd(const float* q, const float* k, const float* v
     FOCR_LAUNCH_CHECK();
     return FOCR_OK;
   }
-  dim3 grid(B * H, Ntok / 128);   // (batch,head) fast: all blocks of a head share one XCD's L2
+  dim3 grid(B * H * (Ntok / 128));   // see attn_block_decode()
   if (p_drop > 0.f) {
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dk, dv, mask, Ntok, ld, scale, p_drop, H);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dq, mask, Ntok, ld, scale, p_drop, H);

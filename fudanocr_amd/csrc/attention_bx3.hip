@@ -97,15 +97,17 @@ __device__ __forceinline__ void row_frag(const float* p, float sc, bf16x8& hi, b
 template <bool DROPOUT>
 __global__ __launch_bounds__(256) void attn_fwd_bx3_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                            const float* __restrict__ V, float* __restrict__ O,
-                                                           float* __restrict__ LSE, uint32_t* __restrict__ MASK,
+                                                           float* __restrict__ LSE, const uint32_t* __restrict__ MASK,
                                                            int Ntok, int ld, float scale, float p_drop,
                                                            uint64_t seed, int nheads) {
   __shared__ __attribute__((aligned(16))) __bf16 Kh[64 * RP], Kl[64 * RP];
   __shared__ __attribute__((aligned(16))) __bf16 Vth[32 * TP], Vtl[32 * TP];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-  const int H = nheads, h = blockIdx.x % nheads, b = blockIdx.x / nheads;
+  int bh_, qb_;
+  attn_block_decode(blockIdx.x, gridDim.x / (Ntok / 128), Ntok / 128, bh_, qb_);
+  const int H = nheads, h = bh_ % nheads, b = bh_ / nheads;
   const size_t base = (size_t)b * Ntok * ld + h * 32;
-  const int q = blockIdx.y * 128 + wave * 32 + li;
+  const int q = qb_ * 128 + wave * 32 + li;
 
   bf16x8 qh[2], ql[2];
 #pragma unroll
@@ -116,8 +118,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bx3_kernel(const float* __restri
   float mrun = -1e30f, l = 0.f;
   const uint32_t thr = DROPOUT ? (uint32_t)(p_drop * 65536.0f + 0.5f) : 0u;
   const float inv_keep = DROPOUT ? 1.f / (1.f - (float)thr / 65536.f) : 1.f;
-  const uint32_t rowkey = rng_rowkey(seed, (uint32_t)((b * H + h) * Ntok + q));
-  uint32_t mwords[2] = {0u, 0u};
+  const uint32_t* mrow = MASK + ((size_t)(b * H + h) * Ntok + q) * (size_t)(Ntok / 32);
 
   const int rp = tid >> 3, c0 = (tid & 7) * 4;         // key pair, first of 4 d columns
   float4 k0, k1, v0, v1;
@@ -136,6 +137,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bx3_kernel(const float* __restri
     put_cols(Vth, Vtl, rp, c0, v0, v1);
     __syncthreads();
     if (kt + 1 < ntiles) LOAD_KV(kt + 1);
+    uint2 mw = make_uint2(0u, 0u);
+    if (DROPOUT) mw = *reinterpret_cast<const uint2*>(mrow + kt * 2);
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       f32x16 s;
@@ -162,18 +165,9 @@ __global__ __launch_bounds__(256) void attn_fwd_bx3_kernel(const float* __restri
         s[r] = p;
       }
       if (DROPOUT) {
-        uint32_t bits = 0u;
+        const uint32_t w = sub ? mw.y : mw.x;
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          int key = kt * 64 + sub * 32 + key_of_b(r, lh);
-          uint32_t hsh = rng_elem(rowkey, (uint32_t)(key >> 1));
-          bool keep0 = (hsh & 0xffffu) >= thr, keep1 = (hsh >> 16) >= thr;
-          s[r] = keep0 ? s[r] * inv_keep : 0.f;
-          s[r + 1] = keep1 ? s[r + 1] * inv_keep : 0.f;
-          bits |= ((keep0 ? 1u : 0u) | (keep1 ? 2u : 0u)) << ((r & 3) + 8 * (r >> 2));
-        }
-        bits <<= 4 * lh;
-        mwords[sub] = bits | __shfl_xor(bits, 32, 64);
+        for (int r = 0; r < 16; ++r) s[r] = ((w >> key_of_b(r, lh)) & 1u) ? s[r] * inv_keep : 0.f;
       }
       l = l * alpha + ls;
 #pragma unroll
@@ -190,9 +184,6 @@ __global__ __launch_bounds__(256) void attn_fwd_bx3_kernel(const float* __restri
         MFMA3(oacc, vh, vl, ph, pl);
       }
     }
-    if (DROPOUT && lh == 0)
-      *reinterpret_cast<uint2*>(MASK + ((size_t)(b * H + h) * Ntok + q) * (Ntok / 32) + kt * 2) =
-          make_uint2(mwords[0], mwords[1]);
     __syncthreads();
   }
   l += __shfl_xor(l, 32, 64);
@@ -222,10 +213,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bx3_kernel(
   __shared__ float Ls[64], Ds[64];
   __shared__ uint32_t Mw[4][64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-  const int H = nheads, h = blockIdx.x % nheads, b = blockIdx.x / nheads;
+  int bh_, qb_;
+  attn_block_decode(blockIdx.x, gridDim.x / (Ntok / 128), Ntok / 128, bh_, qb_);
+  const int H = nheads, h = bh_ % nheads, b = bh_ / nheads;
   const size_t base = (size_t)b * Ntok * ld + h * 32;
   const size_t sbase = (size_t)(b * H + h) * Ntok;
-  const int key = blockIdx.y * 128 + wave * 32 + li;
+  const int key = qb_ * 128 + wave * 32 + li;
 
   bf16x8 kh[2], kl[2], vh[2], vl[2];
 #pragma unroll
@@ -254,7 +247,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bx3_kernel(
       dreg = Dv[sbase + (qt) * 64 + tid];                                             \
     }                                                                                 \
     if (DROPOUT)                                                                      \
-      mreg = MASK[(sbase + (qt) * 64 + (tid & 63)) * (Ntok / 32) + blockIdx.y * 4 + (tid >> 6)]; \
+      mreg = MASK[(sbase + (qt) * 64 + (tid & 63)) * (Ntok / 32) + qb_ * 4 + (tid >> 6)]; \
   } while (0)
   const int ntiles = Ntok / 64;
   LOAD_QG(0);
@@ -340,10 +333,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bx3_kernel(
   __shared__ __attribute__((aligned(16))) __bf16 Kh[64 * RP], Kl[64 * RP], Vh[64 * RP], Vl[64 * RP];
   __shared__ __attribute__((aligned(16))) __bf16 Kth[32 * TP], Ktl[32 * TP];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-  const int H = nheads, h = blockIdx.x % nheads, b = blockIdx.x / nheads;
+  int bh_, qb_;
+  attn_block_decode(blockIdx.x, gridDim.x / (Ntok / 128), Ntok / 128, bh_, qb_);
+  const int H = nheads, h = bh_ % nheads, b = bh_ / nheads;
   const size_t base = (size_t)b * Ntok * ld + h * 32;
   const size_t sbase = (size_t)(b * H + h) * Ntok;
-  const int q = blockIdx.y * 128 + wave * 32 + li;
+  const int q = qb_ * 128 + wave * 32 + li;
 
   bf16x8 qh[2], ql[2], gh[2], gl[2];
 #pragma unroll
@@ -419,7 +414,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bx3_kernel(
 int focr_attn_fwd_bx3(const float* q, const float* k, const float* v, float* o, float* lse, uint32_t* mask,
                       int B, int H, int Ntok, int ld, float scale, float p_drop, uint64_t seed,
                       hipStream_t stream) {
-  dim3 grid(B * H, Ntok / 128);
+  dim3 grid(B * H * (Ntok / 128));
   if (p_drop > 0.f)
     hipLaunchKernelGGL((attn_fwd_bx3_kernel<true>), grid, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ld, scale,
                        p_drop, seed, H);
@@ -431,7 +426,7 @@ int focr_attn_fwd_bx3(const float* q, const float* k, const float* v, float* o, 
 int focr_attn_bwd_bx3(const float* q, const float* k, const float* v, const float* d_o, const float* lse,
                       const float* dwork, const uint32_t* mask, float* dq, float* dk, float* dv, int B, int H,
                       int Ntok, int ld, float scale, float p_drop, hipStream_t stream) {
-  dim3 grid(B * H, Ntok / 128);
+  dim3 grid(B * H * (Ntok / 128));
   if (p_drop > 0.f) {
     hipLaunchKernelGGL((attn_bwd_dkv_bx3_kernel<true>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dk, dv,
                        mask, Ntok, ld, scale, p_drop, H);

@@ -72,6 +72,20 @@ __device__ __forceinline__ uint32_t rng_elem(uint32_t rowkey, uint32_t col) {
   return hash32(rowkey ^ (col * 0x9E3779B1U));
 }
 
+// Attention block order: 1-D grid of BH * nqb blocks.  Workgroups are dispatched round-robin over the
+// 8 XCDs (block id % 8), so ids {x, x+8, x+16, ...} share an XCD and its L2: give those consecutive
+// ids to the nqb query/key blocks of ONE (batch, head), whose K/V (256 KB) then stays L2-resident.
+__device__ __forceinline__ void attn_block_decode(int id, int BH, int nqb, int& bh, int& qb) {
+  if ((BH & 7) == 0) {
+    int xcd = id & 7, t = id >> 3;
+    qb = t % nqb;
+    bh = (t / nqb) * 8 + xcd;
+  } else {
+    bh = id % BH;
+    qb = id / BH;
+  }
+}
+
 // counter-based RNG for dropout masks: one 32-bit draw per (seed, index); the same
 // function regenerates the mask in the backward kernels.
 __device__ __forceinline__ uint32_t rng_hash(uint64_t seed, uint64_t idx) {

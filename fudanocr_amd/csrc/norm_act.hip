@@ -30,28 +30,46 @@ __device__ __forceinline__ float act_grad(float x, int act) {
 // column reductions over [rows][C] (C % 4 == 0 not required): block = 64 columns x 4 row lanes
 // mode 0: sum x          mode 1: sum (x - mean)^2, mean = sum0[c]/rows
 // ---------------------------------------------------------------------------------------
+// Vectorised: thread = 4 consecutive channels (float4), C4 = C/4 threads per row, 256/C4 rows per pass.
 __global__ __launch_bounds__(256) void bn_colstat_kernel(const float* __restrict__ x,
                                                          const float* __restrict__ sum0,
                                                          float* __restrict__ out, long rows, int C,
                                                          int mode) {
-  __shared__ float red[4][64];
-  int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  int rl = threadIdx.x >> 6;
+  __shared__ float4 red[256];
+  const int C4 = C >> 2;
+  // channel groups handled by this block: blockIdx.x covers min(C4, 256) float4 columns
+  const int cols = C4 < 256 ? C4 : 256;            // float4 columns per block
+  const int rl_n = 256 / cols;                     // row lanes
+  const int col = blockIdx.x * cols + (threadIdx.x % cols);
+  const int rl = threadIdx.x / cols;
   long rows_per = (rows + gridDim.y - 1) / gridDim.y;
   long r0 = (long)blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
-  float s = 0.f;
-  if (c < C) {
-    float mean = mode ? sum0[c] / (float)rows : 0.f;
-    for (long r = r0 + rl; r < r1; r += 4) {
-      float v = x[r * C + c] - mean;
-      s += mode ? v * v : v;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col < C4 && rl < rl_n) {
+    float4 mean = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mode) {
+      float4 t = *reinterpret_cast<const float4*>(sum0 + col * 4);
+      float ir = 1.f / (float)rows;
+      mean = make_float4(t.x * ir, t.y * ir, t.z * ir, t.w * ir);
+    }
+    for (long r = r0 + rl; r < r1; r += rl_n) {
+      float4 v = *reinterpret_cast<const float4*>(x + r * C + col * 4);
+      v.x -= mean.x; v.y -= mean.y; v.z -= mean.z; v.w -= mean.w;
+      if (mode) { s.x += v.x * v.x; s.y += v.y * v.y; s.z += v.z * v.z; s.w += v.w * v.w; }
+      else { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
     }
   }
-  red[rl][threadIdx.x & 63] = s;
+  red[threadIdx.x] = s;
   __syncthreads();
-  if (rl == 0 && c < C) {
-    int t = threadIdx.x;
-    atomicAdd(&out[c], red[0][t] + red[1][t] + red[2][t] + red[3][t]);
+  if (rl == 0 && col < C4) {
+    for (int j = 1; j < rl_n; ++j) {
+      float4 t = red[j * cols + (threadIdx.x % cols)];
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    atomicAdd(&out[col * 4 + 0], s.x);
+    atomicAdd(&out[col * 4 + 1], s.y);
+    atomicAdd(&out[col * 4 + 2], s.z);
+    atomicAdd(&out[col * 4 + 3], s.w);
   }
 }
 
@@ -104,33 +122,52 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   }
 }
 
-// backward pass 1: sums[c] = sum g, sums[C + c] = sum g * xhat, g = dz * act'(gamma*xhat+beta)
+// backward pass 1: sum_g[c] = sum g, sum_gx[c] = sum g * xhat, g = dz * act'(gamma*xhat+beta); float4 columns
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ invstd,
     float* __restrict__ sum_g, float* __restrict__ sum_gx, long rows, int C, int act) {
-  __shared__ float red[2][4][64];
-  int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  int rl = threadIdx.x >> 6;
+  __shared__ float4 red0[256], red1[256];
+  const int C4 = C >> 2;
+  const int cols = C4 < 256 ? C4 : 256;
+  const int rl_n = 256 / cols;
+  const int col = blockIdx.x * cols + (threadIdx.x % cols);
+  const int rl = threadIdx.x / cols;
   long rows_per = (rows + gridDim.y - 1) / gridDim.y;
   long r0 = (long)blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
-  float s0 = 0.f, s1 = 0.f;
-  if (c < C) {
-    float g_ = gamma[c], b_ = beta[c], mu = mean[c], is = invstd[c];
-    for (long r = r0 + rl; r < r1; r += 4) {
-      float xh = (x[r * C + c] - mu) * is;
-      float g = dz[r * C + c] * act_grad(g_ * xh + b_, act);
-      s0 += g;
-      s1 += g * xh;
+  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+  if (col < C4 && rl < rl_n) {
+    float4 g4 = *reinterpret_cast<const float4*>(gamma + col * 4), b4 = *reinterpret_cast<const float4*>(beta + col * 4);
+    float4 m4 = *reinterpret_cast<const float4*>(mean + col * 4), i4 = *reinterpret_cast<const float4*>(invstd + col * 4);
+    const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+    const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ii[4] = {i4.x, i4.y, i4.z, i4.w};
+    for (long r = r0 + rl; r < r1; r += rl_n) {
+      float4 xv = *reinterpret_cast<const float4*>(x + r * C + col * 4);
+      float4 dv = *reinterpret_cast<const float4*>(dz + r * C + col * 4);
+      const float xx[4] = {xv.x, xv.y, xv.z, xv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float xh = (xx[e] - mm[e]) * ii[e];
+        float g = dd[e] * act_grad(gg[e] * xh + bb[e], act);
+        s0[e] += g;
+        s1[e] += g * xh;
+      }
     }
   }
-  red[0][rl][threadIdx.x & 63] = s0;
-  red[1][rl][threadIdx.x & 63] = s1;
+  red0[threadIdx.x] = make_float4(s0[0], s0[1], s0[2], s0[3]);
+  red1[threadIdx.x] = make_float4(s1[0], s1[1], s1[2], s1[3]);
   __syncthreads();
-  if (rl == 0 && c < C) {
-    int t = threadIdx.x;
-    atomicAdd(&sum_g[c], red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t]);
-    atomicAdd(&sum_gx[c], red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t]);
+  if (rl == 0 && col < C4) {
+    float4 a = red0[threadIdx.x], b = red1[threadIdx.x];
+    for (int j = 1; j < rl_n; ++j) {
+      float4 t = red0[j * cols + (threadIdx.x % cols)], u = red1[j * cols + (threadIdx.x % cols)];
+      a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+      b.x += u.x; b.y += u.y; b.z += u.z; b.w += u.w;
+    }
+    atomicAdd(&sum_g[col * 4 + 0], a.x); atomicAdd(&sum_g[col * 4 + 1], a.y);
+    atomicAdd(&sum_g[col * 4 + 2], a.z); atomicAdd(&sum_g[col * 4 + 3], a.w);
+    atomicAdd(&sum_gx[col * 4 + 0], b.x); atomicAdd(&sum_gx[col * 4 + 1], b.y);
+    atomicAdd(&sum_gx[col * 4 + 2], b.z); atomicAdd(&sum_gx[col * 4 + 3], b.w);
   }
 }
 
@@ -484,7 +521,7 @@ extern "C" int focr_bn_train_fwd(const float* x, const float* gamma, const float
   FOCR_CHECK_ARG(x && gamma && beta && y && save_mean && save_invstd && ws, "null pointer");
   FOCR_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0, "need C % 4 == 0");
   MEMSET0(ws, sizeof(float) * 2 * C);
-  dim3 g(cdiv(C, 64), row_slabs(rows));
+  dim3 g(cdiv(C, 1024), row_slabs(rows));
   hipLaunchKernelGGL(bn_colstat_kernel, g, 256, 0, stream, x, (const float*)nullptr, ws, rows, C, 0);
   hipLaunchKernelGGL(bn_colstat_kernel, g, 256, 0, stream, x, (const float*)ws, ws + C, rows, C, 1);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), 64, 0, stream, (const float*)ws,
@@ -528,7 +565,7 @@ extern "C" int focr_bn_bwd(const float* dz, const float* x, const float* gamma, 
       MEMSET0(dgamma, sizeof(float) * C);
       MEMSET0(dbeta, sizeof(float) * C);
     }
-    dim3 g(cdiv(C, 64), row_slabs(rows));
+    dim3 g(cdiv(C, 1024), row_slabs(rows));
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, g, 256, 0, stream, dz, x, gamma, beta, mean, invstd, dbeta, dgamma,
                        rows, C, act);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), 256, 0, stream, dz, x, gamma, beta, mean,
