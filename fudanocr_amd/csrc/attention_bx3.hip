@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bx3_kernel(const float* __restri
   float mrun = -1e30f, l = 0.f;
   const uint32_t thr = DROPOUT ? (uint32_t)(p_drop * 65536.0f + 0.5f) : 0u;
   const float inv_keep = DROPOUT ? 1.f / (1.f - (float)thr / 65536.f) : 1.f;
-  const uint32_t* mrow = MASK + ((size_t)(b * H + h) * Ntok + q) * (size_t)(Ntok / 32);
+  const uint2* mrow = reinterpret_cast<const uint2*>(MASK) + (size_t)(b * H + h) * (Ntok / 64) * Ntok + q;
 
   const int rp = tid >> 3, c0 = (tid & 7) * 4;         // key pair, first of 4 d columns
   float4 k0, k1, v0, v1;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bx3_kernel(const float* __restri
     __syncthreads();
     if (kt + 1 < ntiles) LOAD_KV(kt + 1);
     uint2 mw = make_uint2(0u, 0u);
-    if (DROPOUT) mw = *reinterpret_cast<const uint2*>(mrow + kt * 2);
+    if (DROPOUT) mw = mrow[(size_t)kt * Ntok];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       f32x16 s;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bx3_kernel(const float* __restri
       if (DROPOUT) {
         const uint32_t w = sub ? mw.y : mw.x;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = ((w >> key_of_b(r, lh)) & 1u) ? s[r] * inv_keep : 0.f;
+        for (int r = 0; r < 16; ++r) s[r] = ((w >> key_of_b(r, lh)) & 1u) ? s[r] : 0.f;   // 1/(1-p) applied once at the end
       }
       l = l * alpha + ls;
 #pragma unroll
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bx3_kernel(const float* __restri
     __syncthreads();
   }
   l += __shfl_xor(l, 32, 64);
-  float inv = 1.f / l;
+  float inv = inv_keep / l;
   float* orow = O + base + (size_t)q * ld;
 #pragma unroll
   for (int g = 0; g < 4; ++g)
@@ -246,8 +246,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bx3_kernel(
       lreg = LSE[sbase + (qt) * 64 + tid];                                            \
       dreg = Dv[sbase + (qt) * 64 + tid];                                             \
     }                                                                                 \
-    if (DROPOUT)                                                                      \
-      mreg = MASK[(sbase + (qt) * 64 + (tid & 63)) * (Ntok / 32) + qb_ * 4 + (tid >> 6)]; \
+    if (DROPOUT) {                                                                    \
+      int g_ = qb_ * 4 + (tid >> 6);                                                  \
+      mreg = MASK[((sbase / Ntok * (Ntok / 64) + (g_ >> 1)) * Ntok + (qt) * 64 + (tid & 63)) * 2 + (g_ & 1)]; \
+    }                                                                                 \
   } while (0)
   const int ntiles = Ntok / 64;
   LOAD_QG(0);
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bx3_kernel(
         float pd = p, dpe = dp[r];
         if (DROPOUT) {
           bool keep = (Mw[wave][qlq] >> li) & 1u;
-          pd = keep ? p * inv_keep : 0.f;
+          pd = keep ? p : 0.f;              // 1/(1-p) folded into the dV store
           dpe = keep ? dpe * inv_keep : 0.f;
         }
         s[r] = pd;
@@ -315,7 +317,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bx3_kernel(
     *reinterpret_cast<float4*>(dkrow + 8 * g + 4 * lh) =
         make_float4(dkacc[4 * g], dkacc[4 * g + 1], dkacc[4 * g + 2], dkacc[4 * g + 3]);
     *reinterpret_cast<float4*>(dvrow + 8 * g + 4 * lh) =
-        make_float4(dvacc[4 * g], dvacc[4 * g + 1], dvacc[4 * g + 2], dvacc[4 * g + 3]);
+        make_float4(dvacc[4 * g] * inv_keep, dvacc[4 * g + 1] * inv_keep, dvacc[4 * g + 2] * inv_keep,
+                    dvacc[4 * g + 3] * inv_keep);
   }
 }
 
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bx3_kernel(
 #pragma unroll
   for (int r = 0; r < 16; ++r) dqacc[r] = 0.f;
   const float inv_keep = DROPOUT ? 1.f / (1.f - (float)(uint32_t)(p_drop * 65536.0f + 0.5f) / 65536.f) : 1.f;
-  const uint32_t* mrow = MASK + (sbase + q) * (size_t)(Ntok / 32);
+  const uint2* mrow = reinterpret_cast<const uint2*>(MASK) + sbase * (size_t)(Ntok / 64) + q;
 
   const int rp = tid >> 3, c0 = (tid & 7) * 4;
   float4 k0, k1, v0, v1;
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bx3_kernel(
     __syncthreads();
     if (kt + 1 < ntiles) LOAD_KV(kt + 1);
     uint2 mw = make_uint2(0u, 0u);
-    if (DROPOUT) mw = *reinterpret_cast<const uint2*>(mrow + kt * 2);
+    if (DROPOUT) mw = mrow[(size_t)kt * Ntok];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       f32x16 s, dp;

@@ -394,7 +394,7 @@ class _Attention(torch.autograd.Function):
         _chk(q, k, v)
         o = torch.empty_like(q)
         lse = torch.empty((b, heads, t), device=q.device)
-        mask = torch.empty((b, heads, t, t // 32), device=q.device, dtype=torch.int32) if p_drop > 0 else None
+        mask = torch.empty((b, heads, t // 64, t, 2), device=q.device, dtype=torch.int32) if p_drop > 0 else None
         scale = 1.0 / math.sqrt(d // heads)
         _lib.call("focr_attention_fwd", _p(q), _p(k), _p(v), _p(o), _p(lse), _p(mask), b, heads, t, d, scale,
                   float(p_drop), seed, _stream())

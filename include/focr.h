@@ -72,7 +72,8 @@ int focr_conv9x9_small_cout_wgrad(const float* x, const float* dy, float* dw, fl
 /* ---- fused attention: model/tbsrn.py:132-150 (+ the head split/merge of :116-126) -----------
  * q,k,v,o: [B,Ntok,ld], head h in columns h*32..h*32+31; lse: [B,H,Ntok]; Ntok % 128 == 0.
  * p_drop: dropout on the probabilities (tbsrn.py:147-148); the forward draws the mask from a counter
- * hash of (seed, b,h,q,key) and writes the keep bits to mask [B,H,Ntok,Ntok/32] uint32 (needed iff p>0). */
+ * hash of (seed, b,h,q,key) into mask: uint32 [B,H,Ntok/64,Ntok,2], word (kt,q,sub) = keys 64kt+32sub..+31
+ * (B*H*Ntok*Ntok/32 words, needed iff p>0). */
 int focr_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse,
                        uint32_t* mask, int B, int H, int Ntok, int ld, float scale, float p_drop,
                        uint64_t seed, focr_stream_t stream);

@@ -183,7 +183,8 @@ def test_attention_dropout_exact_against_extracted_mask(precision):
     q, k, v = (rnd(b, t, 128, seed=s, scale=1.5).requires_grad_(True) for s in (1, 2, 3))
     qd, kd, vd = (dev(z).requires_grad_(True) for z in (q, k, v))
     od = _Attention.apply(qd, kd, vd, 4, p, 777)
-    words = od.grad_fn.saved_tensors[5].cpu().to(torch.int64) & 0xFFFFFFFF          # [b,4,t,t/32]
+    words = od.grad_fn.saved_tensors[5].cpu().to(torch.int64) & 0xFFFFFFFF          # [b,4,t/64,t,2]
+    words = words.permute(0, 1, 3, 2, 4).reshape(b, 4, t, t // 32)                   # -> [b,4,q,key/32]
     bits = ((words.unsqueeze(-1) >> torch.arange(32)) & 1).reshape(b, 4, t, t).double()
     keep = bits.mean().item()
     assert abs(keep - 0.9) < 4e-3, keep

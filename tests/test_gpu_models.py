@@ -143,7 +143,13 @@ def test_traj3_golden(arch, golden_dir):
     bad = []
     for k, v in ref["param_abs_sum"].items():
         got = float(sd[k].double().abs().sum())
-        if not abs(got - v) <= 1e-3 * v + 1e-6:
+        tol = 1e-3 * v + 1e-6
+        # a conv/linear bias that feeds a train-mode BatchNorm has a mathematically zero gradient: Adam turns its
+        # rounding noise into +-lr steps, so two correct fp32 implementations differ by up to steps*lr per element
+        if k.endswith(".bias") and (".conv1." in k or ".conv2." in k or k.startswith(("block7.0", "stn_head.stn_convnet",
+                                                                                  "stn_head.stn_fc1.0"))):
+            tol += 3 * 1e-4 * sd[k].numel()
+        if not abs(got - v) <= tol:
             bad.append((k, got, v))
     assert not bad, bad[:10]
 
