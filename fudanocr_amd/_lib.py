@@ -54,6 +54,7 @@ SIGNATURES = {
     "focr_ctc_fwd": [P, P, P, P, P, P, P, I, I, I, P],
     "focr_scale_dev": [P, P, P, L, P],
     "focr_grad_sumsq": [P, P, L, F, P],
+    "focr_bn_ws_floats": [L, I],
     "focr_set_precision": [I],
     "focr_get_precision": [],
     "focr_clip_adam": [P, P, P, P, P, L, F, F, F, F, I, F, F, P],
@@ -80,6 +81,7 @@ def load():
     lib.focr_last_error.argtypes = []
     lib.focr_version.restype = ctypes.c_int
     lib.focr_version.argtypes = []
+    lib.focr_bn_ws_floats.restype = ctypes.c_long
     _lib = lib
     return lib
 

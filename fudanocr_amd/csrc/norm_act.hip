@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void bn_colstat_kernel(const float* __restrict
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (col < C4 && rl < rl_n) {
     float4 mean = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (mode) {
+    if (mode) {   // sum0 = folded column sums of pass 0
       float4 t = *reinterpret_cast<const float4*>(sum0 + col * 4);
       float ir = 1.f / (float)rows;
       mean = make_float4(t.x * ir, t.y * ir, t.z * ir, t.w * ir);
@@ -66,11 +66,18 @@ __global__ __launch_bounds__(256) void bn_colstat_kernel(const float* __restrict
       float4 t = red[j * cols + (threadIdx.x % cols)];
       s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
-    atomicAdd(&out[col * 4 + 0], s.x);
-    atomicAdd(&out[col * 4 + 1], s.y);
-    atomicAdd(&out[col * 4 + 2], s.z);
-    atomicAdd(&out[col * 4 + 3], s.w);
+    // deterministic: slab partials, summed in fixed order by bn_fold_kernel (no atomics in the forward)
+    *reinterpret_cast<float4*>(out + (size_t)blockIdx.y * C + col * 4) = s;
   }
+}
+
+// out[c] = sum over slabs of part[slab][c], fixed order
+__global__ void bn_fold_kernel(const float* __restrict__ part, float* __restrict__ out, int slabs, int C) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int j = 0; j < slabs; ++j) s += part[(size_t)j * C + c];
+  out[c] = s;
 }
 
 __global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sq,
@@ -512,7 +519,10 @@ static inline int row_slabs(long rows) {
     }                                                                         \
   } while (0)
 
-// ws: 2*C floats of scratch.  running_mean/var/nbt may be null (no running update).
+// ws: focr_bn_ws_floats(rows, C) floats of scratch.  running_mean/var/nbt may be null (no running update).
+// Statistics are reduced deterministically (slab partials + fixed-order fold): bit-identical run to run.
+extern "C" long focr_bn_ws_floats(long rows, int C) { return (long)(row_slabs(rows) + 2) * C; }
+
 extern "C" int focr_bn_train_fwd(const float* x, const float* gamma, const float* beta,
                                  float* running_mean, float* running_var, long long* nbt,
                                  const float* residual, float* y, float* save_mean,
@@ -520,13 +530,17 @@ extern "C" int focr_bn_train_fwd(const float* x, const float* gamma, const float
                                  float eps, int act, hipStream_t stream) {
   FOCR_CHECK_ARG(x && gamma && beta && y && save_mean && save_invstd && ws, "null pointer");
   FOCR_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0, "need C % 4 == 0");
-  MEMSET0(ws, sizeof(float) * 2 * C);
-  dim3 g(cdiv(C, 1024), row_slabs(rows));
-  hipLaunchKernelGGL(bn_colstat_kernel, g, 256, 0, stream, x, (const float*)nullptr, ws, rows, C, 0);
-  hipLaunchKernelGGL(bn_colstat_kernel, g, 256, 0, stream, x, (const float*)ws, ws + C, rows, C, 1);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), 64, 0, stream, (const float*)ws,
-                     (const float*)(ws + C), save_mean, save_invstd, running_mean, running_var, nbt, rows, C,
-                     momentum, eps);
+  const int slabs = row_slabs(rows);
+  float* sum = ws;                 // [C]
+  float* sq = ws + C;              // [C]
+  float* part = ws + 2 * C;        // [slabs][C]
+  dim3 g(cdiv(C, 1024), slabs);
+  hipLaunchKernelGGL(bn_colstat_kernel, g, 256, 0, stream, x, (const float*)nullptr, part, rows, C, 0);
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 64)), 64, 0, stream, (const float*)part, sum, slabs, C);
+  hipLaunchKernelGGL(bn_colstat_kernel, g, 256, 0, stream, x, (const float*)sum, part, rows, C, 1);
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 64)), 64, 0, stream, (const float*)part, sq, slabs, C);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), 64, 0, stream, (const float*)sum, (const float*)sq,
+                     save_mean, save_invstd, running_mean, running_var, nbt, rows, C, momentum, eps);
   long total4 = rows * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total4)), 256, 0, stream, x, gamma, beta,
                      (const float*)save_mean, (const float*)save_invstd, residual, y, total4, C, act);

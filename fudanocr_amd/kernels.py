@@ -175,7 +175,7 @@ class _BatchNormAct(torch.autograd.Function):
         if training:
             mean = torch.empty(c, device=x.device)
             invstd = torch.empty(c, device=x.device)
-            ws = torch.empty(2 * c, device=x.device)
+            ws = torch.empty(_lib.load().focr_bn_ws_floats(rows, c), device=x.device)
             _lib.call("focr_bn_train_fwd", _p(x), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(nbt),
                       _p(residual), _p(y), _p(mean), _p(invstd), _p(ws), rows, c, float(momentum), float(eps),
                       act, _stream())

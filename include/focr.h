@@ -85,9 +85,10 @@ int focr_attention_bwd(const float* q, const float* k, const float* v, const flo
 
 /* ---- BatchNorm2d/1d (+activation, +residual): model/tsrn.py:81-86,35-39, stn_head.py:17-21,45-48,
  *      crnn.py:44 ; torch semantics (biased var to normalise, unbiased in the running update) --- */
+long focr_bn_ws_floats(long rows, int C);     /* workspace size (floats) of focr_bn_train_fwd */
 int focr_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
                       float* running_var, long long* num_batches_tracked, const float* residual,
-                      float* y, float* save_mean, float* save_invstd, float* ws /*2C*/, long rows, int C,
+                      float* y, float* save_mean, float* save_invstd, float* ws, long rows, int C,
                       float momentum, float eps, int act, focr_stream_t stream);
 int focr_bn_eval_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean,
                      const float* running_var, const float* residual, float* y, float* invstd_out,
