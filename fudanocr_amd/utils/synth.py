@@ -13,9 +13,10 @@ ALPHABET = "0123456789abcdefghijklmnopqrstuvwxyz"
 def make_batch(batch, seed=1234, in_planes=3, height=16, width=64, scale=2):
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
-    lr = torch.rand(batch, in_planes, height, width, generator=g, dtype=torch.float32)
-    hr = torch.rand(batch, in_planes, height * scale, width * scale, generator=g,
-                    dtype=torch.float32)
+    # integer draws / 2^24: exact in fp32 and bit-identical on every host (see weight_fill._u)
+    lr = torch.randint(0, 1 << 24, (batch, in_planes, height, width), generator=g).to(torch.float32) / float(1 << 24)
+    hr = torch.randint(0, 1 << 24, (batch, in_planes, height * scale, width * scale),
+                       generator=g).to(torch.float32) / float(1 << 24)
     lens = torch.randint(3, 11, (batch,), generator=g)
     labels = []
     for n in lens.tolist():

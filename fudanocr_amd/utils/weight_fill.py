@@ -23,9 +23,16 @@ import torch
 
 
 def _u(shape, lo, hi, key):
+    """Uniform[lo, hi) on a 2^24 grid, BIT-IDENTICAL on every host: integer draws (mt19937), then one
+    correctly rounded float64 multiply and an exact cast.  (`rand()*(hi-lo)+lo` is not: a fused
+    multiply-add on one CPU vs mul+add on another moves values by 1 ulp, which this network's B=4
+    batch-norm chain amplifies to ~1e-3 on the SR pixels.)"""
     g = torch.Generator(device="cpu")
     g.manual_seed(zlib.crc32(key.encode("utf-8")))
-    return torch.rand(shape, generator=g, dtype=torch.float32) * (hi - lo) + lo
+    k = torch.randint(0, 1 << 24, tuple(shape), generator=g, dtype=torch.int64)
+    step = (hi - lo) / float(1 << 24)
+    off = int(round(lo / step))                 # range start snapped to the grid (exact for symmetric ranges)
+    return ((k + off).to(torch.float64) * step).to(torch.float32)
 
 
 def fill_value(key, shape, siblings):
