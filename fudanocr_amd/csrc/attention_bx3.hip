@@ -165,9 +165,9 @@ __global__ __launch_bounds__(256) void attn_fwd_bx3_kernel(const float* __restri
         s[r] = p;
       }
       if (DROPOUT) {
-        const uint32_t w = sub ? mw.y : mw.x;
+        const uint32_t w = (sub ? mw.y : mw.x) >> (4 * lh);      // lane-half shift once, then constant bits
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = ((w >> key_of_b(r, lh)) & 1u) ? s[r] : 0.f;   // 1/(1-p) applied once at the end
+        for (int r = 0; r < 16; ++r) s[r] = keep_if_bit(s[r], w, (r & 3) + 8 * (r >> 2));   // 1/(1-p) at the end
       }
       l = l * alpha + ls;
 #pragma unroll
@@ -283,9 +283,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bx3_kernel(
         float p = __expf(s[r] - Ls[qlq]);
         float pd = p, dpe = dp[r];
         if (DROPOUT) {
-          bool keep = (Mw[wave][qlq] >> li) & 1u;
-          pd = keep ? p : 0.f;              // 1/(1-p) folded into the dV store
-          dpe = keep ? dpe * inv_keep : 0.f;
+          uint32_t w = Mw[wave][qlq] << (31 - li);      // this lane's key bit -> sign bit
+          int mk = ((int)w) >> 31;
+          pd = __int_as_float(__float_as_int(p) & mk);              // 1/(1-p) folded into the dV store
+          dpe = __int_as_float(__float_as_int(dpe * inv_keep) & mk);
         }
         s[r] = pd;
         dp[r] = p * (dpe - Ds[qlq]);
@@ -386,8 +387,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bx3_kernel(
         float p = __expf(s[r] - lse);
         float dpe = dp[r];
         if (DROPOUT) {
-          uint32_t w = sub ? mw.y : mw.x;
-          dpe = ((w >> key_of_b(r, lh)) & 1u) ? dpe * inv_keep : 0.f;
+          uint32_t w = (sub ? mw.y : mw.x) >> (4 * lh);
+          dpe = keep_if_bit(dpe * inv_keep, w, (r & 3) + 8 * (r >> 2));
         }
         s[r] = p * (dpe - dd);
       }

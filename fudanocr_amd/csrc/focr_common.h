@@ -86,6 +86,12 @@ __device__ __forceinline__ void attn_block_decode(int id, int BH, int nqb, int& 
   }
 }
 
+// keep-bit application in 2 VALU ops: sign-extended 1-bit field (0 / 0xFFFFFFFF, v_bfe_i32) AND float bits
+__device__ __forceinline__ float keep_if_bit(float v, uint32_t w, int bit) {
+  int m = ((int)(w << (31 - bit))) >> 31;
+  return __int_as_float(__float_as_int(v) & m);
+}
+
 // counter-based RNG for dropout masks: one 32-bit draw per (seed, index); the same
 // function regenerates the mask in the backward kernels.
 __device__ __forceinline__ uint32_t rng_hash(uint64_t seed, uint64_t idx) {
