@@ -95,7 +95,7 @@ __device__ __forceinline__ void row_frag(const float* p, float sc, bf16x8& hi, b
 // forward
 // =======================================================================================
 template <bool DROPOUT>
-__global__ __launch_bounds__(256) void attn_fwd_bx3_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+__global__ __launch_bounds__(256, 4) void attn_fwd_bx3_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                            const float* __restrict__ V, float* __restrict__ O,
                                                            float* __restrict__ LSE, const uint32_t* __restrict__ MASK,
                                                            int Ntok, int ld, float scale, float p_drop,
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bx3_kernel(const float* __restri
 //   dK^T[d][key] = sum_q Qs[q][d] dS[q][key] : A = Qs^T (LDS transposed), B = split(dS) regs
 // =======================================================================================
 template <bool DROPOUT>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_bx3_kernel(
+__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ Dv,
     float* __restrict__ dK, float* __restrict__ dV, const uint32_t* __restrict__ MASK, int Ntok, int ld,
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bx3_kernel(
 //   dQ^T[d][q] = sum_key K[key][d] dS[q][key] : A = K^T (LDS transposed), B = split(dS) regs
 // =======================================================================================
 template <bool DROPOUT>
-__global__ __launch_bounds__(256) void attn_bwd_dq_bx3_kernel(
+__global__ __launch_bounds__(256, 4) void attn_bwd_dq_bx3_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ Dv,
     float* __restrict__ dQ, const uint32_t* __restrict__ MASK, int Ntok, int ld, float scale, float p_drop,
