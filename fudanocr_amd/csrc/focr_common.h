@@ -46,16 +46,23 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// mish(x) = x * tanh(softplus(x)), softplus threshold 20 (reference tsrn.py:117-125)
-__device__ __forceinline__ float mish_f(float x) {
-  float sp = x > 20.f ? x : log1pf(expf(x));
-  return x * tanhf(sp);
+// mish(x) = x * tanh(softplus(x)), softplus threshold 20 (reference tsrn.py:117-125), with ONE exp:
+//   e = exp(x), w = e^2 + 2e  ->  tanh(log(1+e)) = w / (w + 2)   (exact identity; x > 20 -> softplus = x,
+//   tanh(x) = 1 in fp32).  Replaces expf + log1pf + tanhf on every BN-mish / pixel-shuffle element.
+__device__ __forceinline__ float mish_tanh_sp(float x) {
+  if (x > 20.f) return 1.f;
+  float e = __expf(x);
+  float w = e * (e + 2.f);
+  return w / (w + 2.f);
 }
-// d mish / dx
+__device__ __forceinline__ float mish_f(float x) { return x * mish_tanh_sp(x); }
+// d mish / dx = t + x * (1 - t^2) * sigmoid(x)
 __device__ __forceinline__ float mish_grad_f(float x) {
-  float sp = x > 20.f ? x : log1pf(expf(x));
-  float t = tanhf(sp);
-  float sg = x > 20.f ? 1.f : 1.f / (1.f + expf(-x));   // d softplus / dx
+  if (x > 20.f) return 1.f;
+  float e = __expf(x);
+  float w = e * (e + 2.f);
+  float t = w / (w + 2.f);
+  float sg = e / (1.f + e);
   return t + x * (1.f - t * t) * sg;
 }
 

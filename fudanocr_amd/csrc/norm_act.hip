@@ -71,13 +71,28 @@ __global__ __launch_bounds__(256) void bn_colstat_kernel(const float* __restrict
   }
 }
 
-// out[c] = sum over slabs of part[slab][c], fixed order
-__global__ void bn_fold_kernel(const float* __restrict__ part, float* __restrict__ out, int slabs, int C) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int j = 0; j < slabs; ++j) s += part[(size_t)j * C + c];
-  out[c] = s;
+// out[c] = sum over slabs of part[slab][c]: one block per 4 channels, 256 threads stride the slabs, then a
+// fixed-order LDS tree -> deterministic and parallel
+__global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                      int slabs, int C) {
+  __shared__ float4 red[256];
+  const int c4 = blockIdx.x;                       // float4 column
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j = threadIdx.x; j < slabs; j += 256) {
+    float4 v = *reinterpret_cast<const float4*>(part + (size_t)j * C + c4 * 4);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+#pragma unroll
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) {
+      float4 a = red[threadIdx.x], b = red[threadIdx.x + w];
+      red[threadIdx.x] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *reinterpret_cast<float4*>(out + c4 * 4) = red[0];
 }
 
 __global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sq,
@@ -536,9 +551,9 @@ extern "C" int focr_bn_train_fwd(const float* x, const float* gamma, const float
   float* part = ws + 2 * C;        // [slabs][C]
   dim3 g(cdiv(C, 1024), slabs);
   hipLaunchKernelGGL(bn_colstat_kernel, g, 256, 0, stream, x, (const float*)nullptr, part, rows, C, 0);
-  hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 64)), 64, 0, stream, (const float*)part, sum, slabs, C);
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(C / 4), 256, 0, stream, (const float*)part, sum, slabs, C);
   hipLaunchKernelGGL(bn_colstat_kernel, g, 256, 0, stream, x, (const float*)sum, part, rows, C, 1);
-  hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 64)), 64, 0, stream, (const float*)part, sq, slabs, C);
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(C / 4), 256, 0, stream, (const float*)part, sq, slabs, C);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), 64, 0, stream, (const float*)sum, (const float*)sq,
                      save_mean, save_invstd, running_mean, running_var, nbt, rows, C, momentum, eps);
   long total4 = rows * C / 4;
