@@ -168,20 +168,23 @@ int focr_conv_fwd_bx3(const float* x, const float* w, const float* bias, const f
 // two adjacent pixels are packed per 32-bit LDS store.  64 co x 64 k tile, 4 waves as 2x2 of 32x32,
 // 64 pixels per stage (4 MFMA k-steps x 3 split products), split over pixel ranges + fp32 atomics.
 // =======================================================================================
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 #define WTP 72
 
-__device__ __forceinline__ void put_cols72(__bf16* Th, __bf16* Tl, int pp, int c0, float4 r0, float4 r1) {
-  const float a[4] = {r0.x, r0.y, r0.z, r0.w}, b[4] = {r1.x, r1.y, r1.z, r1.w};
+// 4 pixels x 4 channels held by one thread -> for each channel one 8-byte store of its 4 pixels (hi and lo)
+__device__ __forceinline__ void put_quad(__bf16* Th, __bf16* Tl, int c0, int px0, const float4 (&r)[4]) {
+  const float v[4][4] = {{r[0].x, r[0].y, r[0].z, r[0].w}, {r[1].x, r[1].y, r[1].z, r[1].w},
+                         {r[2].x, r[2].y, r[2].z, r[2].w}, {r[3].x, r[3].y, r[3].z, r[3].w}};
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    bf16x2 h, l;
-    __bf16 x = (__bf16)a[e], y = (__bf16)b[e];
-    h[0] = x; h[1] = y;
-    l[0] = (__bf16)(a[e] - (float)x);
-    l[1] = (__bf16)(b[e] - (float)y);
-    *reinterpret_cast<bf16x2*>(&Th[(c0 + e) * WTP + 2 * pp]) = h;
-    *reinterpret_cast<bf16x2*>(&Tl[(c0 + e) * WTP + 2 * pp]) = l;
+    bf16x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __bf16 x = (__bf16)v[j][e];
+      h[j] = x;
+      l[j] = (__bf16)(v[j][e] - (float)x);
+    }
+    *reinterpret_cast<bf16x4*>(&Th[(c0 + e) * WTP + px0]) = h;
+    *reinterpret_cast<bf16x4*>(&Tl[(c0 + e) * WTP + px0]) = l;
   }
 }
 
@@ -196,39 +199,46 @@ __global__ __launch_bounds__(256) void conv_wgrad_bx3_kernel(const float* __rest
   if (pbeg >= pend) return;
   const int tap = k0 / g.Cin, ci0 = k0 - tap * g.Cin;
   const int tkh = tap / g.KW, tkw = tap - tkh * g.KW;
-  const int c4 = (tid & 15) * 4;              // 4 channels owned by this thread
-  const int pp0 = tid >> 4;                   // pixel pairs pp0 and pp0 + 16
+  // staging: the 16 lanes of a group own 16 consecutive pixel quads (conflict-free 8-byte LDS stores),
+  // the group index selects the 4-channel column
+  const int pq = tid & 15, c4 = (tid >> 4) * 4;
   const bool do_bias = dbias != nullptr && blockIdx.x == 0;
-  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool co_full = co0 + c4 + 3 < g.Cout;
 
-  float4 dv[2][2], xv[2][2];
+  float4 dv[4], xv[4];
   auto load_chunk = [&](int pc) {
+    int p = pc + 4 * pq;
+    int n = 0, oy = 0, ox = 0;
+    if (p < pend) {                       // decode the first pixel once, then walk
+      n = p / (g.OH * g.OW);
+      int rem = p - n * (g.OH * g.OW);
+      oy = rem / g.OW;
+      ox = rem - oy * g.OW;
+    }
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        int p = pc + 2 * (pp0 + 16 * it) + j;
-        float4 d = make_float4(0.f, 0.f, 0.f, 0.f), x = d;
-        if (p < pend) {
-          int co = co0 + c4;
-          if (co + 3 < g.Cout) {
-            d = *reinterpret_cast<const float4*>(dY + (size_t)p * ldd + co);
-          } else {
-            float t[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int e = 0; e < 4; ++e)
-              if (co + e < g.Cout) t[e] = dY[(size_t)p * ldd + co + e];
-            d = make_float4(t[0], t[1], t[2], t[3]);
-          }
-          int n = p / (g.OH * g.OW);
-          int rem = p - n * (g.OH * g.OW);
-          int oy = rem / g.OW, ox = rem - oy * g.OW;
-          int iy = oy - g.padH + tkh, ix = ox - g.padW + tkw;
-          if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
-            x = *reinterpret_cast<const float4*>(X + ((size_t)((n * g.H + iy) * g.W + ix) * g.ldx + ci0 + c4));
+    for (int j = 0; j < 4; ++j) {
+      float4 d = make_float4(0.f, 0.f, 0.f, 0.f), x = d;
+      if (p + j < pend) {
+        if (co_full) {
+          d = *reinterpret_cast<const float4*>(dY + (size_t)(p + j) * ldd + co0 + c4);
+        } else {
+          float t[4] = {0.f, 0.f, 0.f, 0.f};
+          for (int e = 0; e < 4; ++e)
+            if (co0 + c4 + e < g.Cout) t[e] = dY[(size_t)(p + j) * ldd + co0 + c4 + e];
+          d = make_float4(t[0], t[1], t[2], t[3]);
         }
-        dv[it][j] = d;
-        xv[it][j] = x;
+        int iy = oy - g.padH + tkh, ix = ox - g.padW + tkw;
+        if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
+          x = *reinterpret_cast<const float4*>(X + ((size_t)((n * g.H + iy) * g.W + ix) * g.ldx + ci0 + c4));
       }
+      dv[j] = d;
+      xv[j] = x;
+      if (++ox == g.OW) {
+        ox = 0;
+        if (++oy == g.OH) { oy = 0; ++n; }
+      }
+    }
   };
   f32x16 acc;
 #pragma unroll
@@ -238,15 +248,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_bx3_kernel(const float* __rest
 
   load_chunk(pbeg);
   for (int pc = pbeg; pc < pend; pc += 64) {
+    put_quad(Dth, Dtl, c4, 4 * pq, dv);
+    put_quad(Xth, Xtl, c4, 4 * pq, xv);
+    if (do_bias) {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      put_cols72(Dth, Dtl, pp0 + 16 * it, c4, dv[it][0], dv[it][1]);
-      put_cols72(Xth, Xtl, pp0 + 16 * it, c4, xv[it][0], xv[it][1]);
-      if (do_bias) {
-        bsum.x += dv[it][0].x + dv[it][1].x;
-        bsum.y += dv[it][0].y + dv[it][1].y;
-        bsum.z += dv[it][0].z + dv[it][1].z;
-        bsum.w += dv[it][0].w + dv[it][1].w;
+      for (int j = 0; j < 4; ++j) {
+        bsum[0] += dv[j].x; bsum[1] += dv[j].y; bsum[2] += dv[j].z; bsum[3] += dv[j].w;
       }
     }
     __syncthreads();
@@ -263,18 +270,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_bx3_kernel(const float* __rest
     }
     __syncthreads();
   }
-  if (do_bias) {   // threads with equal (tid & 15) own the same 4 columns: fold the 16 row groups in LDS
-    float* red = reinterpret_cast<float*>(Dth);          // 16 x 64 floats fit (64*72*2 B = 9216 B >= 4096 B)
-    red[(tid >> 4) * 64 + c4 + 0] = bsum.x;
-    red[(tid >> 4) * 64 + c4 + 1] = bsum.y;
-    red[(tid >> 4) * 64 + c4 + 2] = bsum.z;
-    red[(tid >> 4) * 64 + c4 + 3] = bsum.w;
+  if (do_bias) {   // the 16 lanes sharing (tid >> 4) own the same 4 columns: fold them in LDS, 64 atomics per block
+    float* red = reinterpret_cast<float*>(Dth);          // 16 x 64 floats (4096 B) fit in the 9216-B tile
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[pq * 64 + c4 + e] = bsum[e];
     __syncthreads();
     if (tid < 64 && co0 + tid < g.Cout) {
-      float s = 0.f;
+      float s2 = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s += red[r * 64 + tid];
-      atomicAdd(&dbias[co0 + tid], s);
+      for (int r = 0; r < 16; ++r) s2 += red[r * 64 + tid];
+      atomicAdd(&dbias[co0 + tid], s2);
     }
   }
   int k = k0 + wj * 32 + li;
