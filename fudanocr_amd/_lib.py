@@ -18,8 +18,8 @@ SIGNATURES = {
     "focr_conv2d_wgrad": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
     "focr_weight_flip_transpose": [P, P, I, I, I, I, P],
     "focr_colsum": [P, P, L, I, I, P],
-    "focr_attention_fwd": [P, P, P, P, P, P, I, I, I, I, F, F, U, P],
-    "focr_attention_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, P],
+    "focr_attention_fwd": [P, P, P, P, P, P, I, I, I, I, I, F, F, U, P],
+    "focr_attention_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, F, P],
     "focr_bn_train_fwd": [P, P, P, P, P, P, P, P, P, P, P, L, I, F, F, I, P],
     "focr_bn_eval_fwd": [P, P, P, P, P, P, P, P, L, I, F, I, P],
     "focr_bn_bwd": [P, P, P, P, P, P, P, P, P, L, I, I, I, I, P],

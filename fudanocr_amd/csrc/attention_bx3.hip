@@ -98,7 +98,7 @@ template <bool DROPOUT>
 __global__ __launch_bounds__(256, 4) void attn_fwd_bx3_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                            const float* __restrict__ V, float* __restrict__ O,
                                                            float* __restrict__ LSE, const uint32_t* __restrict__ MASK,
-                                                           int Ntok, int ld, float scale, float p_drop,
+                                                           int Ntok, int ld, int ldo, float scale, float p_drop,
                                                            uint64_t seed, int nheads) {
   __shared__ __attribute__((aligned(16))) __bf16 Kh[64 * RP], Kl[64 * RP];
   __shared__ __attribute__((aligned(16))) __bf16 Vth[32 * TP], Vtl[32 * TP];
@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_bx3_kernel(const float* __res
   attn_block_decode(blockIdx.x, gridDim.x / (Ntok / 128), Ntok / 128, bh_, qb_);
   const int H = nheads, h = bh_ % nheads, b = bh_ / nheads;
   const size_t base = (size_t)b * Ntok * ld + h * 32;
+  const size_t baseo = (size_t)b * Ntok * ldo + h * 32;
   const int q = qb_ * 128 + wave * 32 + li;
 
   bf16x8 qh[2], ql[2];
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_bx3_kernel(const float* __res
   }
   l += __shfl_xor(l, 32, 64);
   float inv = inv_keep / l;
-  float* orow = O + base + (size_t)q * ld;
+  float* orow = O + baseo + (size_t)q * ldo;
 #pragma unroll
   for (int g = 0; g < 4; ++g)
     *reinterpret_cast<float4*>(orow + 8 * g + 4 * lh) =
@@ -206,7 +207,7 @@ template <bool DROPOUT>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ Dv,
-    float* __restrict__ dK, float* __restrict__ dV, const uint32_t* __restrict__ MASK, int Ntok, int ld,
+    float* __restrict__ dK, float* __restrict__ dV, const uint32_t* __restrict__ MASK, int Ntok, int ld, int ldo,
     float scale, float p_drop, int nheads) {
   __shared__ __attribute__((aligned(16))) __bf16 Qh[64 * RP], Ql[64 * RP], Gh[64 * RP], Gl[64 * RP];
   __shared__ __attribute__((aligned(16))) __bf16 Qth[32 * TP], Qtl[32 * TP], Gth[32 * TP], Gtl[32 * TP];
@@ -217,6 +218,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
   attn_block_decode(blockIdx.x, gridDim.x / (Ntok / 128), Ntok / 128, bh_, qb_);
   const int H = nheads, h = bh_ % nheads, b = bh_ / nheads;
   const size_t base = (size_t)b * Ntok * ld + h * 32;
+  const size_t baseo = (size_t)b * Ntok * ldo + h * 32;
   const size_t sbase = (size_t)(b * H + h) * Ntok;
   const int key = qb_ * 128 + wave * 32 + li;
 
@@ -240,8 +242,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
     size_t o0_ = base + (size_t)((qt) * 64 + 2 * rp) * ld + c0;                       \
     q0 = *reinterpret_cast<const float4*>(Q + o0_);                                   \
     q1 = *reinterpret_cast<const float4*>(Q + o0_ + ld);                              \
-    g0 = *reinterpret_cast<const float4*>(dO + o0_);                                  \
-    g1 = *reinterpret_cast<const float4*>(dO + o0_ + ld);                             \
+    g0 = *reinterpret_cast<const float4*>(dO + baseo + (size_t)((qt) * 64 + 2 * rp) * ldo + c0);       \
+    g1 = *reinterpret_cast<const float4*>(dO + baseo + (size_t)((qt) * 64 + 2 * rp + 1) * ldo + c0);   \
     if (tid < 64) {                                                                   \
       lreg = LSE[sbase + (qt) * 64 + tid];                                            \
       dreg = Dv[sbase + (qt) * 64 + tid];                                             \
@@ -332,7 +334,7 @@ template <bool DROPOUT>
 __global__ __launch_bounds__(256, 4) void attn_bwd_dq_bx3_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ Dv,
-    float* __restrict__ dQ, const uint32_t* __restrict__ MASK, int Ntok, int ld, float scale, float p_drop,
+    float* __restrict__ dQ, const uint32_t* __restrict__ MASK, int Ntok, int ld, int ldo, float scale, float p_drop,
     int nheads) {
   __shared__ __attribute__((aligned(16))) __bf16 Kh[64 * RP], Kl[64 * RP], Vh[64 * RP], Vl[64 * RP];
   __shared__ __attribute__((aligned(16))) __bf16 Kth[32 * TP], Ktl[32 * TP];
@@ -341,6 +343,7 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_bx3_kernel(
   attn_block_decode(blockIdx.x, gridDim.x / (Ntok / 128), Ntok / 128, bh_, qb_);
   const int H = nheads, h = bh_ % nheads, b = bh_ / nheads;
   const size_t base = (size_t)b * Ntok * ld + h * 32;
+  const size_t baseo = (size_t)b * Ntok * ldo + h * 32;
   const size_t sbase = (size_t)(b * H + h) * Ntok;
   const int q = qb_ * 128 + wave * 32 + li;
 
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_bx3_kernel(
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
     row_frag(Q + base + (size_t)q * ld + 16 * m + 8 * lh, scale, qh[m], ql[m]);
-    row_frag(dO + base + (size_t)q * ld + 16 * m + 8 * lh, 1.f, gh[m], gl[m]);
+    row_frag(dO + baseo + (size_t)q * ldo + 16 * m + 8 * lh, 1.f, gh[m], gl[m]);
   }
   const float lse = LSE[sbase + q], dd = Dv[sbase + q];
   f32x16 dqacc;
@@ -416,31 +419,31 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_bx3_kernel(
 
 // launchers used by the dispatching C ABI entry points in attention.hip
 int focr_attn_fwd_bx3(const float* q, const float* k, const float* v, float* o, float* lse, uint32_t* mask,
-                      int B, int H, int Ntok, int ld, float scale, float p_drop, uint64_t seed,
+                      int B, int H, int Ntok, int ld, int ldo, float scale, float p_drop, uint64_t seed,
                       hipStream_t stream) {
   dim3 grid(B * H * (Ntok / 128));
   if (p_drop > 0.f)
-    hipLaunchKernelGGL((attn_fwd_bx3_kernel<true>), grid, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ld, scale,
+    hipLaunchKernelGGL((attn_fwd_bx3_kernel<true>), grid, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ld, ldo, scale,
                        p_drop, seed, H);
   else
-    hipLaunchKernelGGL((attn_fwd_bx3_kernel<false>), grid, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ld, scale,
+    hipLaunchKernelGGL((attn_fwd_bx3_kernel<false>), grid, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ld, ldo, scale,
                        p_drop, seed, H);
   return 0;
 }
 int focr_attn_bwd_bx3(const float* q, const float* k, const float* v, const float* d_o, const float* lse,
                       const float* dwork, const uint32_t* mask, float* dq, float* dk, float* dv, int B, int H,
-                      int Ntok, int ld, float scale, float p_drop, hipStream_t stream) {
+                      int Ntok, int ld, int ldo, float scale, float p_drop, hipStream_t stream) {
   dim3 grid(B * H * (Ntok / 128));
   if (p_drop > 0.f) {
     hipLaunchKernelGGL((attn_bwd_dkv_bx3_kernel<true>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dk, dv,
-                       mask, Ntok, ld, scale, p_drop, H);
+                       mask, Ntok, ld, ldo, scale, p_drop, H);
     hipLaunchKernelGGL((attn_bwd_dq_bx3_kernel<true>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dq, mask,
-                       Ntok, ld, scale, p_drop, H);
+                       Ntok, ld, ldo, scale, p_drop, H);
   } else {
     hipLaunchKernelGGL((attn_bwd_dkv_bx3_kernel<false>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dk, dv,
-                       mask, Ntok, ld, scale, p_drop, H);
+                       mask, Ntok, ld, ldo, scale, p_drop, H);
     hipLaunchKernelGGL((attn_bwd_dq_bx3_kernel<false>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dq, mask,
-                       Ntok, ld, scale, p_drop, H);
+                       Ntok, ld, ldo, scale, p_drop, H);
   }
   return 0;
 }

@@ -22,6 +22,11 @@ def _p(t):
     return _NULL if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def _po(t, off):
+    """device pointer `off` floats into tensor t"""
+    return ctypes.c_void_p(t.data_ptr() + 4 * off)
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -396,7 +401,7 @@ class _Attention(torch.autograd.Function):
         lse = torch.empty((b, heads, t), device=q.device)
         mask = torch.empty((b, heads, t // 64, t, 2), device=q.device, dtype=torch.int32) if p_drop > 0 else None
         scale = 1.0 / math.sqrt(d // heads)
-        _lib.call("focr_attention_fwd", _p(q), _p(k), _p(v), _p(o), _p(lse), _p(mask), b, heads, t, d, scale,
+        _lib.call("focr_attention_fwd", _p(q), _p(k), _p(v), _p(o), _p(lse), _p(mask), b, heads, t, d, d, scale,
                   float(p_drop), seed, _stream())
         ctx.cfg = (b, heads, t, d, scale, float(p_drop))
         ctx.save_for_backward(q, k, v, o, lse, mask)
@@ -410,8 +415,46 @@ class _Attention(torch.autograd.Function):
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         work = torch.empty((b, heads, t), device=q.device)
         _lib.call("focr_attention_bwd", _p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(mask), _p(dq), _p(dk),
-                  _p(dv), _p(work), b, heads, t, d, scale, p_drop, _stream())
+                  _p(dv), _p(work), b, heads, t, d, d, scale, p_drop, _stream())
         return dq, dk, dv, None, None, None
+
+
+class _AttentionPacked(torch.autograd.Function):
+    """Same attention on a packed projection qkv [B,T,3*D] (q | k | v column blocks): the kernels read the
+    three operands as column slices (row pitch 3*D) and write dq | dk | dv into one packed gradient, so the
+    surrounding projection is ONE GEMM forward, ONE dgrad GEMM (K = 3*D) and ONE wgrad."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, p_drop, seed):
+        b, t, d3 = qkv.shape
+        d = d3 // 3
+        _chk(qkv)
+        o = torch.empty((b, t, d), device=qkv.device)
+        lse = torch.empty((b, heads, t), device=qkv.device)
+        mask = torch.empty((b, heads, t // 64, t, 2), device=qkv.device, dtype=torch.int32) if p_drop > 0 else None
+        scale = 1.0 / math.sqrt(d // heads)
+        _lib.call("focr_attention_fwd", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _p(o), _p(lse), _p(mask), b,
+                  heads, t, d3, d, scale, float(p_drop), seed, _stream())
+        ctx.cfg = (b, heads, t, d, scale, float(p_drop))
+        ctx.save_for_backward(qkv, o, lse, mask)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, lse, mask = ctx.saved_tensors
+        b, heads, t, d, scale, p_drop = ctx.cfg
+        do = do.contiguous()
+        dqkv = torch.empty_like(qkv)
+        work = torch.empty((b, heads, t), device=qkv.device)
+        _lib.call("focr_attention_bwd", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _p(o), _p(do), _p(lse), _p(mask),
+                  _po(dqkv, 0), _po(dqkv, d), _po(dqkv, 2 * d), _p(work), b, heads, t, 3 * d, d, scale, p_drop,
+                  _stream())
+        return dqkv, None, None, None
+
+
+def attention_packed(qkv, heads=4, p_drop=0.0):
+    seed = _new_seed() if p_drop > 0 else 0
+    return _AttentionPacked.apply(qkv, heads, p_drop, seed)
 
 
 def attention(q, k, v, heads=4, p_drop=0.0):
@@ -634,10 +677,6 @@ def lstm_recurrence(gx, whh, bhh, t_len, batch, st_t, st_b):
 # ----------------------------------------------------------------------------------------
 # bidirectional GRU of the TSRN blocks (recurrent part; the input projection is a `linear`)
 # ----------------------------------------------------------------------------------------
-def _po(t, off):
-    return ctypes.c_void_p(t.data_ptr() + 4 * off)
-
-
 class _GRURecur(torch.autograd.Function):
     """gx [rows,192] (= x W_ih^T + b_ih, both directions), whh [2,96,32], bhh [2,96] -> h [rows,64].
     Sequences are addressed in place on the NHWC map: row(n,t) = (n//IC)*OS + (n%IC)*IS + t*TS."""

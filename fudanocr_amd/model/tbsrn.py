@@ -60,9 +60,16 @@ class MultiHeadedAttention(nn.Module):
 
     def forward(self, query, key, value, mask=None, align=None):
         assert mask is None, "the SR nets never pass a mask"
-        q, k, v = (lin(x) for lin, x in zip(self.linears, (query, key, value)))
         p = self.dropout.p if self.dropout.training else 0.0
-        ctx = K.attention(q, k, v, heads=self.h, p_drop=p)
+        if query is key and key is value:
+            # self-attention (the only use in the SR nets): one packed [rows, 3*d] projection -- the tokens are
+            # read once, and the backward is one dgrad GEMM instead of three plus two gradient adds
+            w = torch.cat([self.linears[0].weight, self.linears[1].weight, self.linears[2].weight], 0)
+            b = torch.cat([self.linears[0].bias, self.linears[1].bias, self.linears[2].bias], 0)
+            ctx = K.attention_packed(K.linear(query, w, b), heads=self.h, p_drop=p)
+        else:
+            q, k, v = (lin(x) for lin, x in zip(self.linears, (query, key, value)))
+            ctx = K.attention(q, k, v, heads=self.h, p_drop=p)
         return self.linears[3](ctx), None
 
 

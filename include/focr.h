@@ -70,17 +70,18 @@ int focr_conv9x9_small_cout_wgrad(const float* x, const float* dy, float* dw, fl
                                   int W, int Cin, int Cout, int prezeroed, focr_stream_t stream);
 
 /* ---- fused attention: model/tbsrn.py:132-150 (+ the head split/merge of :116-126) -----------
- * q,k,v,o: [B,Ntok,ld], head h in columns h*32..h*32+31; lse: [B,H,Ntok]; Ntok % 128 == 0.
+ * q,k,v (and dq,dk,dv): row pitch ld; o, d_o: row pitch ldo (0 = ld) -- q,k,v may be column slices of one packed
+ * [B,Ntok,3*128] projection; head h in columns h*32..h*32+31; lse: [B,H,Ntok]; Ntok % 128 == 0.
  * p_drop: dropout on the probabilities (tbsrn.py:147-148); the forward draws the mask from a counter
  * hash of (seed, b,h,q,key) into mask: uint32 [B,H,Ntok/64,Ntok,2], word (kt,q,sub) = keys 64kt+32sub..+31
  * (B*H*Ntok*Ntok/32 words, needed iff p>0). */
 int focr_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse,
-                       uint32_t* mask, int B, int H, int Ntok, int ld, float scale, float p_drop,
+                       uint32_t* mask, int B, int H, int Ntok, int ld, int ldo, float scale, float p_drop,
                        uint64_t seed, focr_stream_t stream);
 /* dwork: B*H*Ntok floats */
 int focr_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o,
                        const float* lse, const uint32_t* mask, float* dq, float* dk, float* dv,
-                       float* dwork, int B, int H, int Ntok, int ld, float scale, float p_drop,
+                       float* dwork, int B, int H, int Ntok, int ld, int ldo, float scale, float p_drop,
                        focr_stream_t stream);
 
 /* ---- BatchNorm2d/1d (+activation, +residual): model/tsrn.py:81-86,35-39, stn_head.py:17-21,45-48,

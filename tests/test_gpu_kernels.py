@@ -511,3 +511,19 @@ def test_conv9x9_output_layer(shape):
     close(xd.grad.permute(0, 3, 1, 2), x.grad, what="conv9x9 dgrad")
     close(wd.grad, wt.grad, 5e-5, what="conv9x9 wgrad")
     close(bd.grad, b.grad, 5e-5, what="conv9x9 bias grad")
+
+
+def test_attention_packed_qkv(precision):
+    """q|k|v as column slices of one [B,T,384] projection (row pitch 384), output pitch 128."""
+    b, t = 2, 256
+    qkv = rnd(b, t, 384, seed=7, scale=1.5).requires_grad_(True)
+    q, k, v = qkv[..., :128], qkv[..., 128:256], qkv[..., 256:]
+    heads = lambda z: z.reshape(b, t, 4, 32).transpose(1, 2)
+    o = (torch.softmax(heads(q) @ heads(k).transpose(-1, -2) / math.sqrt(32), -1) @ heads(v)).transpose(1, 2).reshape(b, t, 128)
+    go = rnd(b, t, 128, seed=8)
+    o.backward(go)
+    qd = dev(qkv).requires_grad_(True)
+    od = K().attention_packed(qd, heads=4, p_drop=0.0)
+    close(od, o, ptol(precision), what="packed attn fwd")
+    od.backward(dev(go))
+    close(qd.grad, qkv.grad, ptol(precision), what="packed attn dqkv")

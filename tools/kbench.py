@@ -43,12 +43,12 @@ if "attn" in what:
         work = torch.empty(B, 4, 1024, device="cuda")
 
         def fwd():
-            _lib.call("focr_attention_fwd", K._p(q), K._p(k), K._p(v), K._p(o), K._p(lse), K._p(mask), B, 4, 1024, 128,
+            _lib.call("focr_attention_fwd", K._p(q), K._p(k), K._p(v), K._p(o), K._p(lse), K._p(mask), B, 4, 1024, 128, 128,
                       1 / math.sqrt(32), p, 1234, K._stream())
 
         def bwd():
             _lib.call("focr_attention_bwd", K._p(q), K._p(k), K._p(v), K._p(o), K._p(do), K._p(lse), K._p(mask),
-                      K._p(dq), K._p(dk), K._p(dv), K._p(work), B, 4, 1024, 128, 1 / math.sqrt(32), p, K._stream())
+                      K._p(dq), K._p(dk), K._p(dv), K._p(work), B, 4, 1024, 128, 128, 1 / math.sqrt(32), p, K._stream())
         m, mn = timeit(fwd)
         print("attn fwd  p=%.1f  median %8.1f us  min %8.1f us  %6.1f TF (algorithmic)" % (p, m, mn, fl / mn / 1e6))
         m, mn = timeit(bwd)
