@@ -22,7 +22,7 @@ SIGNATURES = {
     "focr_attention_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, F, P],
     "focr_bn_train_fwd": [P, P, P, P, P, P, P, P, P, P, P, L, I, F, F, I, P],
     "focr_bn_eval_fwd": [P, P, P, P, P, P, P, P, L, I, F, I, P],
-    "focr_bn_bwd": [P, P, P, P, P, P, P, P, P, L, I, I, I, I, P],
+    "focr_bn_bwd": [P, P, P, P, P, P, P, P, P, P, L, I, I, I, P],
     "focr_layernorm_fwd": [P, P, P, P, P, P, P, L, I, F, P],
     "focr_layernorm_bwd": [P, P, P, P, P, P, P, P, P, L, I, F, I, P],
     "focr_prelu_fwd": [P, P, P, L, P],
@@ -55,6 +55,7 @@ SIGNATURES = {
     "focr_scale_dev": [P, P, P, L, P],
     "focr_grad_sumsq": [P, P, L, F, P],
     "focr_bn_ws_floats": [L, I],
+    "focr_bn_bwd_ws_floats": [L, I],
     "focr_set_precision": [I],
     "focr_get_precision": [],
     "focr_clip_adam": [P, P, P, P, P, L, F, F, F, F, I, F, F, P],
@@ -82,6 +83,7 @@ def load():
     lib.focr_version.restype = ctypes.c_int
     lib.focr_version.argtypes = []
     lib.focr_bn_ws_floats.restype = ctypes.c_long
+    lib.focr_bn_bwd_ws_floats.restype = ctypes.c_long
     _lib = lib
     return lib
 

@@ -152,9 +152,12 @@ int focr_conv_fwd_bx3(const float* x, const float* w, const float* bias, const f
                       int N, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int padH, int padW,
                       int M, int ldy, int ldr, int ldx, float alpha, int relu, hipStream_t stream) {
   ConvGeomX g{N, H, W, Cin, OH, OW, Cout, KH, KW, padH, padW, KH * KW * Cin, M, ldy, ldr, ldx};
-  bool wide = Cout > 32;
-  dim3 grid((M + XBM - 1) / XBM, (Cout + (wide ? 63 : 31)) / (wide ? 64 : 32));
-  if (wide)
+  // widest column tile that does not waste MFMA work: the A (activation) tile is re-read once per column block
+  int nt = Cout > 64 && Cout % 128 == 0 ? 4 : (Cout > 32 ? 2 : 1);
+  dim3 grid((M + XBM - 1) / XBM, (Cout + 32 * nt - 1) / (32 * nt));
+  if (nt == 4)
+    hipLaunchKernelGGL((conv_fwd_bx3_kernel<4>), grid, 256, 0, stream, x, w, bias, residual, y, g, alpha, relu);
+  else if (nt == 2)
     hipLaunchKernelGGL((conv_fwd_bx3_kernel<2>), grid, 256, 0, stream, x, w, bias, residual, y, g, alpha, relu);
   else
     hipLaunchKernelGGL((conv_fwd_bx3_kernel<1>), grid, 256, 0, stream, x, w, bias, residual, y, g, alpha, relu);

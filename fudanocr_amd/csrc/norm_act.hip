@@ -186,10 +186,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
       a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
       b.x += u.x; b.y += u.y; b.z += u.z; b.w += u.w;
     }
-    atomicAdd(&sum_g[col * 4 + 0], a.x); atomicAdd(&sum_g[col * 4 + 1], a.y);
-    atomicAdd(&sum_g[col * 4 + 2], a.z); atomicAdd(&sum_g[col * 4 + 3], a.w);
-    atomicAdd(&sum_gx[col * 4 + 0], b.x); atomicAdd(&sum_gx[col * 4 + 1], b.y);
-    atomicAdd(&sum_gx[col * 4 + 2], b.z); atomicAdd(&sum_gx[col * 4 + 3], b.w);
+    // slab partials (folded in fixed order by bn_fold_kernel): no same-address atomic serialisation
+    *reinterpret_cast<float4*>(sum_g + (size_t)blockIdx.y * C + col * 4) = a;
+    *reinterpret_cast<float4*>(sum_gx + (size_t)blockIdx.y * C + col * 4) = b;
   }
 }
 
@@ -578,25 +577,33 @@ extern "C" int focr_bn_eval_fwd(const float* x, const float* gamma, const float*
   return FOCR_OK;
 }
 
-// train-mode backward.  dgamma/dbeta: C floats each.  They double as the reduction accumulators
-// (sum g*xhat = dgamma, sum g = dbeta): prezeroed = 0 -> cleared here first, 1 -> caller guarantees zeros.
-// train == 0: eval-mode backward (mean = running_mean, no batch-statistics terms, no dgamma/dbeta).
+// train-mode backward.  dgamma/dbeta: C floats each (overwritten); ws: focr_bn_bwd_ws_floats(rows, C) floats.
+// The two channel reductions (sum g*xhat = dgamma, sum g = dbeta) are slab partials + a fixed-order fold.
+// train == 0: eval-mode backward (mean = running_mean, no batch-statistics terms, no dgamma/dbeta, ws unused).
+static inline int bwd_slabs(long rows) {
+  long s = (rows + 63) / 64;
+  if (s > 2048) s = 2048;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+extern "C" long focr_bn_bwd_ws_floats(long rows, int C) { return (long)bwd_slabs(rows) * 2 * C; }
+
 extern "C" int focr_bn_bwd(const float* dz, const float* x, const float* gamma, const float* beta,
                            const float* mean, const float* invstd, float* dx, float* dgamma,
-                           float* dbeta, long rows, int C, int act, int train, int prezeroed,
+                           float* dbeta, float* ws, long rows, int C, int act, int train,
                            hipStream_t stream) {
   FOCR_CHECK_ARG(dz && x && gamma && beta && mean && invstd && dx, "null pointer");
   FOCR_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0, "need C % 4 == 0");
   long total4 = rows * C / 4;
   if (train) {
-    FOCR_CHECK_ARG(dgamma && dbeta, "null pointer");
-    if (!prezeroed) {
-      MEMSET0(dgamma, sizeof(float) * C);
-      MEMSET0(dbeta, sizeof(float) * C);
-    }
-    dim3 g(cdiv(C, 1024), row_slabs(rows));
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, g, 256, 0, stream, dz, x, gamma, beta, mean, invstd, dbeta, dgamma,
-                       rows, C, act);
+    FOCR_CHECK_ARG(dgamma && dbeta && ws, "null pointer");
+    const int slabs = bwd_slabs(rows);
+    float* pg = ws;                       // [slabs][C]
+    float* pgx = ws + (size_t)slabs * C;  // [slabs][C]
+    dim3 g(cdiv(C, 1024), slabs);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, g, 256, 0, stream, dz, x, gamma, beta, mean, invstd, pg, pgx, rows, C, act);
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(C / 4), 256, 0, stream, (const float*)pg, dbeta, slabs, C);
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(C / 4), 256, 0, stream, (const float*)pgx, dgamma, slabs, C);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), 256, 0, stream, dz, x, gamma, beta, mean,
                        invstd, (const float*)dbeta, (const float*)dgamma, dx, total4, rows, C, act);
   } else {

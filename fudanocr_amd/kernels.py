@@ -205,13 +205,14 @@ class _BatchNormAct(torch.autograd.Function):
             tg, tb = ctx.targets
             dg = tg if tg is not None else torch.empty(c, device=x.device)
             db = tb if tb is not None else torch.empty(c, device=x.device)
+            ws = torch.empty(_lib.load().focr_bn_bwd_ws_floats(rows, c), device=x.device)
             _lib.call("focr_bn_bwd", _p(dz), _p(x), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(dx), _p(dg),
-                      _p(db), rows, c, act, 1, int(tg is not None and tb is not None), _stream())
+                      _p(db), _p(ws), rows, c, act, 1, _stream())
             dg = None if tg is not None else dg
             db = None if tb is not None else db
         else:
             _lib.call("focr_bn_bwd", _p(dz), _p(x), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(dx), _NULL,
-                      _NULL, rows, c, act, 0, 0, _stream())
+                      _NULL, _NULL, rows, c, act, 0, _stream())
         return dx, dg, db, None, None, None, (dz if has_res else None), None, None, None, None
 
 

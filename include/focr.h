@@ -95,8 +95,9 @@ int focr_bn_eval_fwd(const float* x, const float* gamma, const float* beta, cons
                      const float* running_var, const float* residual, float* y, float* invstd_out,
                      long rows, int C, float eps, int act, focr_stream_t stream);
 int focr_bn_bwd(const float* dz, const float* x, const float* gamma, const float* beta, const float* mean,
-                const float* invstd, float* dx, float* dgamma, float* dbeta, long rows, int C, int act,
-                int train, int prezeroed, focr_stream_t stream);
+                const float* invstd, float* dx, float* dgamma, float* dbeta, float* ws, long rows, int C,
+                int act, int train, focr_stream_t stream);
+long focr_bn_bwd_ws_floats(long rows, int C); /* workspace size (floats) of focr_bn_bwd (train) */
 
 /* ---- the reference's own LayerNorm (unbiased std, eps on std): model/tbsrn.py:23-36 ---------- */
 int focr_layernorm_fwd(const float* x, const float* residual, const float* a, const float* b, float* y,
