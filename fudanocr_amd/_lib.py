@@ -45,8 +45,8 @@ SIGNATURES = {
     "focr_tps_bwd": [P, P, P, P, P, P, I, I, I, I, I, P],
     "focr_bicubic_gray_fwd": [P, P, I, I, I, I, I, P],
     "focr_bicubic_gray_bwd": [P, P, I, I, I, I, I, P],
-    "focr_lstm_bidir_fwd": [P, P, P, P, P, P, I, I, I, I, I, P],
-    "focr_lstm_bidir_bwd": [P, P, P, P, P, P, I, I, I, I, I, P],
+    "focr_lstm_bidir_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, P],
+    "focr_lstm_bidir_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, P],
     "focr_gru_bidir_fwd": [P, P, P, P, P, I, I, I, I, I, I, P],
     "focr_gru_bidir_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     "focr_conv9x9_small_cout_fwd": [P, P, P, P, I, I, I, I, I, P],
@@ -56,6 +56,7 @@ SIGNATURES = {
     "focr_grad_sumsq": [P, P, L, F, P],
     "focr_bn_ws_floats": [L, I],
     "focr_bn_bwd_ws_floats": [L, I],
+    "focr_lstm_ws_bytes": [I, I, I, I],
     "focr_set_precision": [I],
     "focr_get_precision": [],
     "focr_clip_adam": [P, P, P, P, P, L, F, F, F, F, I, F, F, P],
@@ -84,6 +85,7 @@ def load():
     lib.focr_version.argtypes = []
     lib.focr_bn_ws_floats.restype = ctypes.c_long
     lib.focr_bn_bwd_ws_floats.restype = ctypes.c_long
+    lib.focr_lstm_ws_bytes.restype = ctypes.c_long
     _lib = lib
     return lib
 

@@ -153,7 +153,7 @@ int focr_conv_fwd_bx3(const float* x, const float* w, const float* bias, const f
                       int M, int ldy, int ldr, int ldx, float alpha, int relu, hipStream_t stream) {
   ConvGeomX g{N, H, W, Cin, OH, OW, Cout, KH, KW, padH, padW, KH * KW * Cin, M, ldy, ldr, ldx};
   // widest column tile that does not waste MFMA work: the A (activation) tile is re-read once per column block
-  int nt = Cout > 64 && Cout % 128 == 0 ? 4 : (Cout > 32 ? 2 : 1);
+  int nt = Cout > 32 ? 2 : 1;   // a 128-column tile (NT=4) was measured: no gain, these GEMMs are latency bound
   dim3 grid((M + XBM - 1) / XBM, (Cout + 32 * nt - 1) / (32 * nt));
   if (nt == 4)
     hipLaunchKernelGGL((conv_fwd_bx3_kernel<4>), grid, 256, 0, stream, x, w, bias, residual, y, g, alpha, relu);

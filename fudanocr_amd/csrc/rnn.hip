@@ -142,11 +142,22 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(
 }
 
 // whh: [2][4H][H] (forward direction then reverse), bhh: [2][4H]
+int focr_lstm_fwd_bx3(const float* gx, const float* whh, const float* bhh, float* hseq, float* gates, float* cseq,
+                      void* ws, int T, int B, int H, int st_t, int st_b, hipStream_t stream);
+int focr_lstm_bwd_bx3(const float* dhseq, const float* whh, const float* gates, const float* cseq, float* dgx,
+                      float* dc_carry, void* ws, int T, int B, int H, int st_t, int st_b, hipStream_t stream);
+
+// ws: focr_lstm_ws_bytes(T,B,H,0) bytes (bf16 operand copies; only used in bf16x3 mode, may be null in fp32 mode)
 extern "C" int focr_lstm_bidir_fwd(const float* gx, const float* whh, const float* bhh, float* hseq,
-                                   float* gates, float* cseq, int T, int B, int H, int st_t, int st_b,
-                                   hipStream_t stream) {
+                                   float* gates, float* cseq, void* ws, int T, int B, int H, int st_t,
+                                   int st_b, hipStream_t stream) {
   FOCR_CHECK_ARG(gx && whh && bhh && hseq && gates && cseq, "null pointer");
   FOCR_CHECK_ARG(T > 0 && B > 0 && H % 32 == 0, "need H % 32 == 0");
+  if (focr_get_precision() == 1 && ws && H == 256) {
+    focr_lstm_fwd_bx3(gx, whh, bhh, hseq, gates, cseq, ws, T, B, H, st_t, st_b, stream);
+    FOCR_LAUNCH_CHECK();
+    return FOCR_OK;
+  }
   dim3 grid(H / 32, cdiv(B, 32), 2);
   for (int s = 0; s < T; ++s)
     hipLaunchKernelGGL(lstm_fwd_step_kernel, grid, 256, 0, stream, gx, whh, bhh, hseq, gates, cseq, s, T, B, H,
@@ -157,10 +168,15 @@ extern "C" int focr_lstm_bidir_fwd(const float* gx, const float* whh, const floa
 
 // dc_carry: 2*B*H floats of workspace.  dgx is fully overwritten.
 extern "C" int focr_lstm_bidir_bwd(const float* dhseq, const float* whh, const float* gates,
-                                   const float* cseq, float* dgx, float* dc_carry, int T, int B, int H,
-                                   int st_t, int st_b, hipStream_t stream) {
+                                   const float* cseq, float* dgx, float* dc_carry, void* ws, int T, int B,
+                                   int H, int st_t, int st_b, hipStream_t stream) {
   FOCR_CHECK_ARG(dhseq && whh && gates && cseq && dgx && dc_carry, "null pointer");
   FOCR_CHECK_ARG(T > 0 && B > 0 && H % 32 == 0, "need H % 32 == 0");
+  if (focr_get_precision() == 1 && ws && H == 256) {
+    focr_lstm_bwd_bx3(dhseq, whh, gates, cseq, dgx, dc_carry, ws, T, B, H, st_t, st_b, stream);
+    FOCR_LAUNCH_CHECK();
+    return FOCR_OK;
+  }
   dim3 grid(H / 32, cdiv(B, 32), 2);
   for (int s = 0; s < T; ++s)
     hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, 256, 0, stream, dhseq, whh, gates, cseq, dgx, dc_carry, s, T,
@@ -375,4 +391,219 @@ extern "C" int focr_gru_bidir_bwd(const float* dhseq, const float* whh, const fl
                      hprev, nseq, T, IC, OS, IS, TS);
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
+}
+
+// =======================================================================================
+// bf16x3 variants of the LSTM step kernels (precision mode 1).
+// The recurrent GEMM h_{t-1} W_hh^T (K = 256) runs on v_mfma_f32_32x32x16_bf16 with split operands:
+//   * W_hh (frozen recogniser weights) is split ONCE into bf16 hi/lo: whh2[2(hi,lo)][2][4H][H], and for
+//     the backward also transposed: whhT2[2][2][H][4H];
+//   * every step writes its h (forward) / gate gradients (backward) also as bf16 hi/lo side buffers, so
+//     the next step's A fragments are plain 16-byte loads (no per-step conversion of the operand).
+// 48 MFMAs (1536 cycles) per wave and step instead of 128 f32 MFMAs (8192 cycles).
+// =======================================================================================
+typedef __attribute__((ext_vector_type(8))) __bf16 rbf16x8;
+
+// dst2[0] = hi, dst2[1] = lo of src (n elements); optional transpose of [rows][cols] matrices (count of them = mats)
+__global__ void split_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long n, int rows, int cols,
+                                  int transpose) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long o = i;
+    if (transpose) {
+      long per = (long)rows * cols;
+      long m = i / per, r = (i % per) / cols, c = i % cols;
+      o = m * per + c * rows + r;
+    }
+    float v = src[i];
+    __bf16 h = (__bf16)v;
+    dst[o] = h;
+    dst[n + o] = (__bf16)(v - (float)h);
+  }
+}
+
+// Block = 16 waves: wave (g = wave & 3, kq = wave >> 2) computes gate g's partial product over the K quarter
+// [64 kq, 64 kq + 64) with all 16 operand loads in flight at once (the step is bound by load latency: h was
+// written by other XCDs in the previous launch and comes from MALL/HBM).  Partials are folded in a FIXED order
+// through LDS (bit-deterministic forward); the cell inputs gx / c_{t-1} / bias are prefetched before the GEMM.
+#define LSTM_MFMA3_QUARTER(arow, brow, aoff, boff)                                                      \
+  {                                                                                                     \
+    rbf16x8 ah[4], al[4], wh[4], wl[4];                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
+      ah[i] = *reinterpret_cast<const rbf16x8*>(arow + 16 * i);                                         \
+      al[i] = *reinterpret_cast<const rbf16x8*>(arow + aoff + 16 * i);                                  \
+      wh[i] = *reinterpret_cast<const rbf16x8*>(brow + 16 * i);                                         \
+      wl[i] = *reinterpret_cast<const rbf16x8*>(brow + boff + 16 * i);                                  \
+    }                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], wh[i], acc, 0, 0, 0);                        \
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], wl[i], acc, 0, 0, 0);                        \
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], wh[i], acc, 0, 0, 0);                        \
+    }                                                                                                   \
+  }
+
+__global__ __launch_bounds__(1024) void lstm_fwd_step_bx3_kernel(
+    const float* __restrict__ gx, const __bf16* __restrict__ whh2, const float* __restrict__ bhh,
+    float* __restrict__ hseq, __bf16* __restrict__ hseq2, float* __restrict__ gates, float* __restrict__ cseq,
+    int step, int T, int B, int H, int st_t, int st_b) {
+  __shared__ float part[3][4][32][33];
+  const int tid = threadIdx.x, wave = tid >> 6, g = wave & 3, kq = wave >> 2;
+  const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int dir = blockIdx.z, j0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+  const int t = dir == 0 ? step : T - 1 - step;
+  const int tp = dir == 0 ? t - 1 : t + 1;
+  const long nh = (long)T * B * 2 * H;        // elements of hseq (offset of the lo plane in hseq2)
+  const long nw = (long)2 * 4 * H * H;        // elements of whh
+  // cell element owned by this thread in the epilogue
+  const int ebl = tid >> 5, eu = tid & 31, eb = b0 + ebl, eunit = j0 + eu;
+  float gxv[4] = {0.f, 0.f, 0.f, 0.f}, cp = 0.f;
+  if (eb < B) {
+    const float* gp = gx + ((size_t)t * st_t + (size_t)eb * st_b) * 8 * H + dir * 4 * H + eunit;
+    const float* bp = bhh + (size_t)dir * 4 * H + eunit;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gxv[q] = gp[q * H] + bp[q * H];
+    if (step > 0) cp = cseq[(((size_t)tp * B + eb) * 2 + dir) * H + eunit];
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if (step > 0) {
+    int br = min(b0 + li, B - 1);
+    const __bf16* arow = hseq2 + ((size_t)tp * B + br) * 2 * H + dir * H + 64 * kq + 8 * lh;
+    const __bf16* brow = whh2 + ((size_t)dir * 4 * H + g * H + j0 + li) * H + 64 * kq + 8 * lh;
+    LSTM_MFMA3_QUARTER(arow, brow, nh, nw)
+  }
+  if (kq > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[kq - 1][g][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = acc[r];
+  }
+  __syncthreads();
+  if (kq == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int bl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      part[0][g][bl][li] = ((acc[r] + part[0][g][bl][li]) + part[1][g][bl][li]) + part[2][g][bl][li];
+    }
+  }
+  __syncthreads();
+  if (eb < B) {
+    float ig = sigmoidf_(part[0][0][ebl][eu] + gxv[0]);
+    float fg = sigmoidf_(part[0][1][ebl][eu] + gxv[1]);
+    float gg = tanhf(part[0][2][ebl][eu] + gxv[2]);
+    float og = sigmoidf_(part[0][3][ebl][eu] + gxv[3]);
+    float c = fg * cp + ig * gg;
+    float h = og * tanhf(c);
+    size_t gb = (((size_t)t * B + eb) * 2 + dir) * 4 * H + eunit;
+    gates[gb] = ig;
+    gates[gb + H] = fg;
+    gates[gb + 2 * H] = gg;
+    gates[gb + 3 * H] = og;
+    cseq[(((size_t)t * B + eb) * 2 + dir) * H + eunit] = c;
+    size_t ho = ((size_t)t * B + eb) * 2 * H + dir * H + eunit;
+    hseq[ho] = h;
+    __bf16 hh = (__bf16)h;
+    hseq2[ho] = hh;
+    hseq2[nh + ho] = (__bf16)(h - (float)hh);
+  }
+}
+
+// dgx2: bf16 hi/lo copy of dgx ([rows][2][4H], same row mapping), written here for the next step.
+// wave (nq = wave & 3, kq = wave >> 2) covers the reduction index n in [nq H + 64 kq, + 64) (H == 256).
+__global__ __launch_bounds__(1024) void lstm_bwd_step_bx3_kernel(
+    const float* __restrict__ dhseq, const __bf16* __restrict__ whhT2, const float* __restrict__ gates,
+    const float* __restrict__ cseq, float* __restrict__ dgx, __bf16* __restrict__ dgx2, float* __restrict__ dc_carry,
+    int step, int T, int B, int H, int st_t, int st_b, long ndg) {
+  __shared__ float part[3][4][32][33];
+  const int tid = threadIdx.x, wave = tid >> 6, nq = wave & 3, kq = wave >> 2;
+  const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int dir = blockIdx.z, j0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+  const int t = dir == 0 ? T - 1 - step : step;
+  const int tn = dir == 0 ? t + 1 : t - 1;
+  const int tp = dir == 0 ? t - 1 : t + 1;
+  const long nwt = (long)2 * H * 4 * H;
+  const int ebl = tid >> 5, eu = tid & 31, eb = b0 + ebl, eunit = j0 + eu;
+  const bool first = dir == 0 ? t == 0 : t == T - 1;
+  float dh0 = 0.f, ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, c = 0.f, cp = 0.f, carry = 0.f;
+  const size_t ci = ((size_t)dir * B + eb) * H + eunit;
+  if (eb < B) {
+    dh0 = dhseq[((size_t)t * B + eb) * 2 * H + dir * H + eunit];
+    size_t gb = (((size_t)t * B + eb) * 2 + dir) * 4 * H + eunit;
+    ig = gates[gb], fg = gates[gb + H], gg = gates[gb + 2 * H], og = gates[gb + 3 * H];
+    c = cseq[(((size_t)t * B + eb) * 2 + dir) * H + eunit];
+    cp = first ? 0.f : cseq[(((size_t)tp * B + eb) * 2 + dir) * H + eunit];
+    carry = step > 0 ? dc_carry[ci] : 0.f;
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if (step > 0) {
+    int br = min(b0 + li, B - 1);
+    const __bf16* arow =
+        dgx2 + ((size_t)tn * st_t + (size_t)br * st_b) * 8 * H + dir * 4 * H + nq * H + 64 * kq + 8 * lh;
+    const __bf16* brow = whhT2 + ((size_t)dir * H + j0 + li) * 4 * H + nq * H + 64 * kq + 8 * lh;   // WhhT[unit][n]
+    LSTM_MFMA3_QUARTER(arow, brow, ndg, nwt)
+  }
+  if (kq > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[kq - 1][nq][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = acc[r];
+  }
+  __syncthreads();
+  if (kq == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int bl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      part[0][nq][bl][li] = ((acc[r] + part[0][nq][bl][li]) + part[1][nq][bl][li]) + part[2][nq][bl][li];
+    }
+  }
+  __syncthreads();
+  if (eb < B) {
+    float dh = dh0 + (((part[0][0][ebl][eu] + part[0][1][ebl][eu]) + part[0][2][ebl][eu]) + part[0][3][ebl][eu]);
+    float tc = tanhf(c);
+    float dc = dh * og * (1.f - tc * tc) + carry;
+    dc_carry[ci] = dc * fg;
+    size_t ob = ((size_t)t * st_t + (size_t)eb * st_b) * 8 * H + dir * 4 * H + eunit;
+    float d4[4] = {dc * gg * ig * (1.f - ig), dc * cp * fg * (1.f - fg), dc * ig * (1.f - gg * gg),
+                   dh * tc * og * (1.f - og)};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      dgx[ob + q * H] = d4[q];
+      __bf16 hh = (__bf16)d4[q];
+      dgx2[ob + q * H] = hh;
+      dgx2[ndg + ob + q * H] = (__bf16)(d4[q] - (float)hh);
+    }
+  }
+}
+
+// ws (forward): bf16 elements: 2*2*4H*H (whh hi/lo) + 2*T*B*2H (h hi/lo)          -> bytes = 2 * that
+// ws (backward): bf16 elements: 2*2*H*4H (whh^T hi/lo) + 2*rows*8H (dgx hi/lo)
+extern "C" long focr_lstm_ws_bytes(int T, int B, int H, int backward) {
+  long w = (long)2 * 2 * 4 * H * H;
+  long s = backward ? (long)2 * T * B * 8 * H : (long)2 * T * B * 2 * H;
+  return 2 * (w + s);
+}
+
+int focr_lstm_fwd_bx3(const float* gx, const float* whh, const float* bhh, float* hseq, float* gates, float* cseq,
+                      void* ws, int T, int B, int H, int st_t, int st_b, hipStream_t stream) {
+  __bf16* whh2 = reinterpret_cast<__bf16*>(ws);
+  long nw = (long)2 * 4 * H * H;
+  __bf16* hseq2 = whh2 + 2 * nw;
+  hipLaunchKernelGGL(split_bf16_kernel, dim3(512), 256, 0, stream, whh, whh2, nw, 1, 1, 0);
+  dim3 grid(H / 32, (B + 31) / 32, 2);
+  for (int s = 0; s < T; ++s)
+    hipLaunchKernelGGL(lstm_fwd_step_bx3_kernel, grid, 1024, 0, stream, gx, (const __bf16*)whh2, bhh, hseq, hseq2, gates,
+                       cseq, s, T, B, H, st_t, st_b);
+  return 0;
+}
+int focr_lstm_bwd_bx3(const float* dhseq, const float* whh, const float* gates, const float* cseq, float* dgx,
+                      float* dc_carry, void* ws, int T, int B, int H, int st_t, int st_b, hipStream_t stream) {
+  __bf16* whhT2 = reinterpret_cast<__bf16*>(ws);
+  long nw = (long)2 * 4 * H * H;
+  __bf16* dgx2 = whhT2 + 2 * nw;
+  long ndg = (long)T * B * 8 * H;
+  // whh [2][4H][H] -> whhT [2][H][4H] (hi plane then lo plane)
+  hipLaunchKernelGGL(split_bf16_kernel, dim3(512), 256, 0, stream, whh, whhT2, nw, 4 * H, H, 1);
+  dim3 grid(H / 32, (B + 31) / 32, 2);
+  for (int s = 0; s < T; ++s)
+    hipLaunchKernelGGL(lstm_bwd_step_bx3_kernel, grid, 1024, 0, stream, dhseq, (const __bf16*)whhT2, gates, cseq, dgx,
+                       dgx2, dc_carry, s, T, B, H, st_t, st_b, ndg);
+  return 0;
 }

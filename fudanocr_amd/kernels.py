@@ -653,8 +653,9 @@ class _LSTMRecur(torch.autograd.Function):
         hseq = torch.empty((t_len, batch, 2 * hid), device=gx.device)
         gates = torch.empty((t_len, batch, 2, 4 * hid), device=gx.device)
         cseq = torch.empty((t_len, batch, 2, hid), device=gx.device)
-        _lib.call("focr_lstm_bidir_fwd", _p(gx), _p(whh), _p(bhh), _p(hseq), _p(gates), _p(cseq), t_len, batch,
-                  hid, st_t, st_b, _stream())
+        ws = torch.empty(_lib.load().focr_lstm_ws_bytes(t_len, batch, hid, 0), device=gx.device, dtype=torch.uint8)
+        _lib.call("focr_lstm_bidir_fwd", _p(gx), _p(whh), _p(bhh), _p(hseq), _p(gates), _p(cseq), _p(ws), t_len,
+                  batch, hid, st_t, st_b, _stream())
         ctx.cfg = (t_len, batch, hid, st_t, st_b, tuple(gx.shape))
         ctx.save_for_backward(whh, gates, cseq)
         return hseq
@@ -666,8 +667,9 @@ class _LSTMRecur(torch.autograd.Function):
         dh = dh.contiguous()
         dgx = torch.empty(gshape, device=dh.device)
         carry = torch.empty((2, batch, hid), device=dh.device)
-        _lib.call("focr_lstm_bidir_bwd", _p(dh), _p(whh), _p(gates), _p(cseq), _p(dgx), _p(carry), t_len, batch,
-                  hid, st_t, st_b, _stream())
+        ws = torch.empty(_lib.load().focr_lstm_ws_bytes(t_len, batch, hid, 1), device=dh.device, dtype=torch.uint8)
+        _lib.call("focr_lstm_bidir_bwd", _p(dh), _p(whh), _p(gates), _p(cseq), _p(dgx), _p(carry), _p(ws), t_len,
+                  batch, hid, st_t, st_b, _stream())
         return dgx, None, None, None, None, None, None
 
 

@@ -155,11 +155,12 @@ int focr_bicubic_gray_bwd(const float* dy, float* dx_nchw, int B, int Cx, int H,
 /* ---- recurrences ---------------------------------------------------------------------------
  * nn.LSTM(bidirectional) crnn.py:11,15 : gx [rows][2][4H] (row(t,b) = t*st_t + b*st_b),
  * whh [2][4H][H], bhh [2][4H], hseq [T][B][2H], gates [T][B][2][4H], cseq [T][B][2][H] */
+long focr_lstm_ws_bytes(int T, int B, int H, int backward);  /* bf16 operand-copy workspace (bf16x3 mode) */
 int focr_lstm_bidir_fwd(const float* gx, const float* whh, const float* bhh, float* hseq, float* gates,
-                        float* cseq, int T, int B, int H, int st_t, int st_b, focr_stream_t stream);
+                        float* cseq, void* ws, int T, int B, int H, int st_t, int st_b, focr_stream_t stream);
 int focr_lstm_bidir_bwd(const float* dhseq, const float* whh, const float* gates, const float* cseq,
-                        float* dgx, float* dc_carry /*2*B*H*/, int T, int B, int H, int st_t, int st_b,
-                        focr_stream_t stream);
+                        float* dgx, float* dc_carry /*2*B*H*/, void* ws, int T, int B, int H, int st_t,
+                        int st_b, focr_stream_t stream);
 /* nn.GRU(64, 32, bidirectional, batch_first) tsrn.py:133,141 (gate order r,z,n).  All tensors are
  * indexed by map row: row(seq n, time t) = (n/IC)*OS + (n%IC)*IS + t*TS, so both the horizontal
  * (gru2) and the vertical (gru1, reference transposes the map) scans read the NHWC map in place.

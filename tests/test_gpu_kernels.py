@@ -380,7 +380,7 @@ def test_bicubic_gray():
 
 
 @pytest.mark.parametrize("b", [3, 40])
-def test_lstm(b):
+def test_lstm(b, precision):
     from oracle import sr_oracle as O
     t, nin, hid = 26, 64, 256
     P = {}
@@ -402,16 +402,16 @@ def test_lstm(b):
     xd = dev(x).requires_grad_(True)
     gx = k.linear(xd.view(t * b, nin), wih, bih)
     yd = k.lstm_recurrence(gx, whh, bhh, t, b, b, 1)
-    close(yd, y, 5e-5, what="lstm fwd")
+    close(yd, y, ptol(precision, 5e-5), what="lstm fwd")
     yd.backward(dev(gy))
-    close(xd.grad, x.grad, 1e-4, what="lstm dx")
+    close(xd.grad, x.grad, ptol(precision), what="lstm dx")
     # batch-major rows (b*T + t), the CRNN's first layer
     xb = dev(x.transpose(0, 1)).requires_grad_(True)
     gx = k.linear(xb.view(b * t, nin), wih, bih)
     yb = k.lstm_recurrence(gx, whh, bhh, t, b, 1, t)
-    close(yb, y, 5e-5, what="lstm fwd (batch-major rows)")
+    close(yb, y, ptol(precision, 5e-5), what="lstm fwd (batch-major rows)")
     yb.backward(dev(gy))
-    close(xb.grad.transpose(0, 1), x.grad, 1e-4, what="lstm dx (batch-major rows)")
+    close(xb.grad.transpose(0, 1), x.grad, ptol(precision), what="lstm dx (batch-major rows)")
 
 
 def test_ctc():

@@ -89,12 +89,14 @@ if "lstm" in what:
     cseq = torch.empty(t, B, 2, 256, device="cuda")
     dgx = torch.empty_like(gx)
     carry = torch.empty(2, B, 256, device="cuda")
+    wsf = torch.empty(_lib.load().focr_lstm_ws_bytes(t, B, hid, 0), device="cuda", dtype=torch.uint8)
+    wsb = torch.empty(_lib.load().focr_lstm_ws_bytes(t, B, hid, 1), device="cuda", dtype=torch.uint8)
 
     def fwd():
-        _lib.call("focr_lstm_bidir_fwd", K._p(gx), K._p(whh), K._p(bhh), K._p(hseq), K._p(gates), K._p(cseq), t, B,
+        _lib.call("focr_lstm_bidir_fwd", K._p(gx), K._p(whh), K._p(bhh), K._p(hseq), K._p(gates), K._p(cseq), K._p(wsf), t, B,
                   hid, B, 1, K._stream())
 
     def bwd():
-        _lib.call("focr_lstm_bidir_bwd", K._p(hseq), K._p(whh), K._p(gates), K._p(cseq), K._p(dgx), K._p(carry), t, B,
+        _lib.call("focr_lstm_bidir_bwd", K._p(hseq), K._p(whh), K._p(gates), K._p(cseq), K._p(dgx), K._p(carry), K._p(wsb), t, B,
                   hid, B, 1, K._stream())
     print("lstm fwd (26 steps) median %.1f us" % timeit(fwd)[0], " bwd median %.1f us" % timeit(bwd)[0])
