@@ -92,11 +92,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    # FOCR_BENCH_BACKEND=gloo lets several ranks share one GPU (functional check of the multi-process path
+    # on a 1-GPU box; RCCL refuses two ranks on one device).  The measured configuration is always nccl = RCCL.
+    backend = os.environ.get("FOCR_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from fudanocr_amd import _lib
     from fudanocr_amd.engine import TrainStep
@@ -154,6 +162,7 @@ def main():
             "config": {"workload": "TBSRN + frozen CRNN-CTC train step (BASELINE configs[2]), STN on, "
                                    "dropout on, 16x64->32x128", "per_gpu_batch": args.batch,
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "arch": args.arch,
+                       "collective_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
                        "arithmetic": "split-bf16 MFMA (hi/lo operands, 3 products, fp32 accumulate)" if bx3
                        else "exact fp32 MFMA"},
             "roofline": {"bound": "mfma",

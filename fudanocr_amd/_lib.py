@@ -57,6 +57,7 @@ SIGNATURES = {
     "focr_bn_ws_floats": [L, I],
     "focr_bn_bwd_ws_floats": [L, I],
     "focr_lstm_ws_bytes": [I, I, I, I],
+    "focr_grad_sumsq_ws_floats": [],
     "focr_set_precision": [I],
     "focr_get_precision": [],
     "focr_clip_adam": [P, P, P, P, P, L, F, F, F, F, I, F, F, P],
@@ -86,6 +87,7 @@ def load():
     lib.focr_bn_ws_floats.restype = ctypes.c_long
     lib.focr_bn_bwd_ws_floats.restype = ctypes.c_long
     lib.focr_lstm_ws_bytes.restype = ctypes.c_long
+    lib.focr_grad_sumsq_ws_floats.restype = ctypes.c_long
     _lib = lib
     return lib
 

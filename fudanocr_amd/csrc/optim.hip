@@ -6,9 +6,12 @@
 // HBM-bound: reads g,p,m,v, writes p,m,v = 28 B per parameter.
 #include "focr_common.h"
 
-// out[0] += sum (gscale*g)^2     (gscale = 1/world for data-parallel gradient averaging)
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, float* __restrict__ out, long n4,
-                                                    long n, float gscale) {
+#define SUMSQ_BLOCKS 1024
+
+// part[1 + block] = this block's sum of g^2.  No atomics: the squared norm must be bit-identical on every
+// data-parallel rank (identical all-reduced gradients -> identical clip factor -> replicas never drift apart).
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, float* __restrict__ part, long n4,
+                                                    long n) {
   __shared__ float red[4];
   float acc = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -20,7 +23,18 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1] + red[2] + red[3]) * gscale * gscale);
+  if (threadIdx.x == 0) part[1 + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// part[0] = gscale^2 * sum of the block partials, folded in a fixed order by one block
+__global__ __launch_bounds__(256) void sumsq_fold_kernel(float* __restrict__ part, int nblk, float gscale) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += 256) acc += part[1 + i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[0] = ((red[0] + red[1]) + (red[2] + red[3])) * gscale * gscale;
 }
 
 __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -43,18 +57,17 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
   }
 }
 
-// sumsq: 1 float of workspace, overwritten with the squared (averaged) gradient norm.
+extern "C" long focr_grad_sumsq_ws_floats(void) { return 1 + SUMSQ_BLOCKS; }
+
+// sumsq: focr_grad_sumsq_ws_floats() floats; sumsq[0] is overwritten with the squared (averaged) gradient norm.
 extern "C" int focr_grad_sumsq(const float* g, float* sumsq, long n, float gscale, hipStream_t stream) {
   FOCR_CHECK_ARG(g && sumsq && n > 0, "bad argument");
-  if (hipMemsetAsync(sumsq, 0, sizeof(float), stream) != hipSuccess) {
-    focr_set_error("focr_grad_sumsq: memset failed");
-    return FOCR_EHIP;
-  }
   long n4 = n / 4;
   long gsz = (n4 + 255) / 256;
-  if (gsz > 1024) gsz = 1024;
+  if (gsz > SUMSQ_BLOCKS) gsz = SUMSQ_BLOCKS;
   if (gsz < 1) gsz = 1;
-  hipLaunchKernelGGL(sumsq_kernel, dim3((int)gsz), 256, 0, stream, g, sumsq, n4, n, gscale);
+  hipLaunchKernelGGL(sumsq_kernel, dim3((int)gsz), 256, 0, stream, g, sumsq, n4, n);
+  hipLaunchKernelGGL(sumsq_fold_kernel, dim3(1), 256, 0, stream, sumsq, (int)gsz, gscale);
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }

@@ -68,7 +68,7 @@ class FusedClipAdam:
         self.flat, self.lr, self.betas, self.eps, self.max_norm = flat, lr, betas, eps, max_norm
         self.m = torch.zeros_like(flat.flat_param)
         self.v = torch.zeros_like(flat.flat_param)
-        self.sumsq = torch.zeros(1, device=flat.flat_param.device)
+        self.sumsq = K.sumsq_workspace(flat.flat_param.device)
         self.t = 0
 
     def step(self, world=1):
@@ -79,7 +79,7 @@ class FusedClipAdam:
                     self.betas[0], self.betas[1], self.eps, self.t, self.max_norm, g)
 
     def grad_norm(self):
-        return self.sumsq.sqrt()
+        return self.sumsq[:1].sqrt()
 
 
 class _Boundary(torch.autograd.Function):

@@ -739,6 +739,11 @@ def add(a, b):
 # ----------------------------------------------------------------------------------------
 # optimiser tail
 # ----------------------------------------------------------------------------------------
+def sumsq_workspace(device):
+    """workspace of focr_grad_sumsq: element 0 receives the squared gradient norm"""
+    return torch.zeros(_lib.load().focr_grad_sumsq_ws_floats(), device=device)
+
+
 def grad_sumsq(flat_grad, out, gscale=1.0):
     _lib.call("focr_grad_sumsq", _p(flat_grad), _p(out), flat_grad.numel(), float(gscale), _stream())
 

@@ -181,6 +181,8 @@ int focr_ctc_fwd(const float* logits, const int* targets, const int* target_leng
 
 /* ---- optimiser tail: clip_grad_norm_(0.25) + Adam (interfaces/super_resolution.py:83-84,
  *      interfaces/base.py:194-198) on flat buffers; gscale = 1/world for DP averaging ----------- */
+long focr_grad_sumsq_ws_floats(void);   /* size of the sumsq workspace; sumsq[0] = squared norm (no atomics:
+                                          bit-identical on every data-parallel rank) */
 int focr_grad_sumsq(const float* g, float* sumsq, long n, float gscale, focr_stream_t stream);
 int focr_clip_adam(float* p, const float* g, float* m, float* v, const float* sumsq, long n, float lr,
                    float beta1, float beta2, float eps, int step, float max_norm, float gscale,

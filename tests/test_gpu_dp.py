@@ -1,0 +1,113 @@
+"""Data-parallel engine on the GPU with two ranks sharing the one device over gloo (RCCL refuses two ranks on
+one GPU, and the test box has one): the real TBSRN + CRNN-CTC step with the boundary hooks, the side stream,
+the bucketed all-reduce and the fused clip+Adam.  Checks, per rank:
+  * the boundary buckets are launched DURING backward (overlap path taken);
+  * the all-reduced flat gradient equals the sum of both ranks' locally computed gradients;
+  * after 2 optimizer steps the parameters of both ranks are identical;
+  * bench.py's multi-process path prints its one JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from fudanocr_amd import _lib
+from fudanocr_amd.engine import TrainStep
+from fudanocr_amd.smoke import build_models
+from fudanocr_amd.utils.synth import make_batch
+rank = int(os.environ["RANK"])
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("gloo")
+_lib.load()
+solo = dist.new_group([0]), dist.new_group([1])          # every rank creates both groups
+net, rec, crit = build_models(dev, "tbsrn")
+step = TrainStep(net, crit, dropout=False)
+assert step.world == 2 and step.comm_stream is not None
+lr, hr, labels = make_batch(4, 77 + rank)
+lr, hr = lr.to(dev), hr.to(dev)
+enc = crit.encode(labels, dev)
+
+def local_backward(engine, model):
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.eval()
+    engine.flat.zero_grad()
+    engine._works, engine._sent = [], []
+    sr = model(lr)
+    loss = engine.crit(sr, hr, None, enc)[0]
+    (loss * 100).backward()
+
+# data-parallel backward
+local_backward(step, net)
+assert len(step._sent) >= 2, step._sent                    # boundary buckets went out during backward
+step.allreduce_grads()
+torch.cuda.synchronize()
+dp = step.flat.flat_grad.clone()
+# reference: same weights, world-1 engine, explicit sum over ranks
+net1, _, crit1 = build_models(dev, "tbsrn")
+net1.load_state_dict(net.state_dict())
+one = TrainStep(net1, crit1, dropout=False, process_group=solo[rank])
+assert one.world == 1
+local_backward(one, net1)
+ref = one.flat.flat_grad.clone()
+dist.all_reduce(ref)
+err = (dp - ref).abs().max().item() / ref.abs().max().item()
+assert err < 1e-4, err
+# two full steps, then parameters must agree bit-for-bit across ranks (same reduced gradients, same update)
+for _ in range(2):
+    out = step(lr, hr, encoded=enc)
+assert torch.isfinite(out["loss"]).item()
+mine = step.flat.flat_param.detach().clone()
+other = mine.clone()
+dist.broadcast(other, src=0)
+assert torch.equal(mine, other), (mine - other).abs().max().item()
+dist.destroy_process_group()
+print("rank", rank, "ok", err)
+"""
+
+
+def _run_two(cmds_env, timeout=600):
+    procs = [subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for cmd, env in cmds_env]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=timeout)[0].decode())
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    return procs, outs
+
+
+def test_dp_engine_two_ranks_one_gpu(tmp_path):
+    script = tmp_path / "dp_gpu_worker.py"
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE="2")
+    procs, outs = _run_two([([sys.executable, str(script)], dict(env, RANK=str(r))) for r in range(2)])
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
+
+
+def test_bench_multiprocess_path(tmp_path):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2",
+               FOCR_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "8"]
+    procs, outs = _run_two([(cmd, dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)])
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
+    line = [l for l in outs[0].splitlines() if l.startswith("{")]
+    assert len(line) == 1 and not [l for l in outs[1].splitlines() if l.startswith("{")]
+    res = json.loads(line[0])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 16 and res["value"] > 0
+    assert res["scaling"] == "weak" and "cpu_baseline" not in res

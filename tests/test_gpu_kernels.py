@@ -440,7 +440,7 @@ def test_clip_adam():
     pr = p.clone().requires_grad_(True)
     opt = O.AdamState([pr])
     pd, md, vd = dev(p), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
-    ss = torch.zeros(1, device="cuda")
+    ss = k.sumsq_workspace("cuda")
     for step in range(1, 4):
         g = rnd(n, seed=10 + step, scale=0.01 if step == 2 else 1.0).float()     # step 2: norm < 0.25 (no clip)
         pr.grad = g.clone()
@@ -448,7 +448,7 @@ def test_clip_adam():
         opt.step()
         gd = dev(g)
         k.grad_sumsq(gd, ss)
-        close(ss.sqrt(), norm.reshape(1), 1e-5, what="grad norm")
+        close(ss[:1].sqrt(), norm.reshape(1), 1e-5, what="grad norm")
         k.clip_adam(pd, gd, md, vd, ss, 1e-4, 0.5, 0.999, 1e-8, step, 0.25)
         close(pd, pr, 1e-6, what="adam step %d" % step)
 
