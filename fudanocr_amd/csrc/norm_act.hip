@@ -227,6 +227,14 @@ __global__ void bn_eval_prep_kernel(const float* __restrict__ rvar, float* __res
 // ---------------------------------------------------------------------------------------
 // LayerNorm of the reference (unbiased std, eps on the std), D = 128, one wave per row
 // ---------------------------------------------------------------------------------------
+// Half a wave (32 lanes x float4) owns one row of D = 128: every load/store instruction of a wave moves two
+// full rows (1 KB) and the row statistics are 32-lane butterflies.
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x,
                                                      const float* __restrict__ res,
@@ -234,31 +242,27 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ b, float* __restrict__ y,
                                                      float* __restrict__ save_mean,
                                                      float* __restrict__ save_rinv, long rows, float eps) {
-  constexpr int E = D / 64;
-  const int lane = threadIdx.x & 63;
-  long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  static_assert(D == 128, "half-wave rows need D == 128");
+  const int li = threadIdx.x & 31;
+  long row = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
   if (row >= rows) return;
-  float v[E];
-  float s = 0.f;
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    v[e] = x[row * D + e * 64 + lane];
-    if (res) v[e] += res[row * D + e * 64 + lane];
-    s += v[e];
+  float4 v = reinterpret_cast<const float4*>(x + row * D)[li];
+  if (res) {
+    float4 r = reinterpret_cast<const float4*>(res + row * D)[li];
+    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
   }
-  float mean = wave_sum(s) / D;
-  float q = 0.f;
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    v[e] -= mean;
-    q += v[e] * v[e];
-  }
-  float sd = sqrtf(wave_sum(q) / (D - 1));
+  const float4 av = reinterpret_cast<const float4*>(a)[li], bv = reinterpret_cast<const float4*>(b)[li];
+  float mean = half_sum((v.x + v.y) + (v.z + v.w)) / D;
+  v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+  float sd = sqrtf(half_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)) / (D - 1));
   float rinv = 1.f / (sd + eps);
-#pragma unroll
-  for (int e = 0; e < E; ++e)
-    y[row * D + e * 64 + lane] = a[e * 64 + lane] * v[e] * rinv + b[e * 64 + lane];
-  if (lane == 0) {
+  float4 o;
+  o.x = av.x * v.x * rinv + bv.x;
+  o.y = av.y * v.y * rinv + bv.y;
+  o.z = av.z * v.z * rinv + bv.z;
+  o.w = av.w * v.w * rinv + bv.w;
+  reinterpret_cast<float4*>(y + row * D)[li] = o;
+  if (li == 0) {
     save_mean[row] = mean;
     save_rinv[row] = rinv;
   }
@@ -274,45 +278,44 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ save_rinv,
                                                      float* __restrict__ dx, float* __restrict__ da,
                                                      float* __restrict__ db, long rows, float eps) {
-  constexpr int E = D / 64;
-  __shared__ float red[2][4][D];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float pa[E], pb[E], av[E];
-#pragma unroll
-  for (int e = 0; e < E; ++e) { pa[e] = 0.f; pb[e] = 0.f; av[e] = a[e * 64 + lane]; }
-  for (long row = (long)blockIdx.x * 4 + wv; row < rows; row += (long)gridDim.x * 4) {
+  static_assert(D == 128, "half-wave rows need D == 128");
+  __shared__ float red[2][8][D];
+  const int li = threadIdx.x & 31, hw = threadIdx.x >> 5;
+  const float4 av = reinterpret_cast<const float4*>(a)[li];
+  float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
+  for (long row = (long)blockIdx.x * 8 + hw; row < rows; row += (long)gridDim.x * 8) {
+    float4 xv = reinterpret_cast<const float4*>(x + row * D)[li];
+    float4 g = reinterpret_cast<const float4*>(dy + row * D)[li];
+    if (res) {
+      float4 r = reinterpret_cast<const float4*>(res + row * D)[li];
+      xv.x += r.x; xv.y += r.y; xv.z += r.z; xv.w += r.w;
+    }
     float mean = save_mean[row], rinv = save_rinv[row];
     float sd = 1.f / rinv - eps;
-    float u[E], dn[E];
-    float s_dn = 0.f, s_dnu = 0.f;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      float xv = x[row * D + e * 64 + lane];
-      if (res) xv += res[row * D + e * 64 + lane];
-      u[e] = xv - mean;
-      float g = dy[row * D + e * 64 + lane];
-      pa[e] += g * u[e] * rinv;
-      pb[e] += g;
-      dn[e] = g * av[e];
-      s_dn += dn[e];
-      s_dnu += dn[e] * u[e];
-    }
-    s_dn = wave_sum(s_dn);
-    s_dnu = wave_sum(s_dnu);
+    float4 u = make_float4(xv.x - mean, xv.y - mean, xv.z - mean, xv.w - mean);
+    pa.x += g.x * u.x * rinv; pa.y += g.y * u.y * rinv; pa.z += g.z * u.z * rinv; pa.w += g.w * u.w * rinv;
+    pb.x += g.x; pb.y += g.y; pb.z += g.z; pb.w += g.w;
+    float4 dn = make_float4(g.x * av.x, g.y * av.y, g.z * av.z, g.w * av.w);
+    float s_dn = half_sum((dn.x + dn.y) + (dn.z + dn.w));
+    float s_dnu = half_sum((dn.x * u.x + dn.y * u.y) + (dn.z * u.z + dn.w * u.w));
     float k = rinv * rinv * s_dnu / ((D - 1) * sd);
     float mdn = rinv * s_dn / D;
-#pragma unroll
-    for (int e = 0; e < E; ++e) dx[row * D + e * 64 + lane] = dn[e] * rinv - k * u[e] - mdn;
+    float4 o;
+    o.x = dn.x * rinv - k * u.x - mdn;
+    o.y = dn.y * rinv - k * u.y - mdn;
+    o.z = dn.z * rinv - k * u.z - mdn;
+    o.w = dn.w * rinv - k * u.w - mdn;
+    reinterpret_cast<float4*>(dx + row * D)[li] = o;
   }
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    red[0][wv][e * 64 + lane] = pa[e];
-    red[1][wv][e * 64 + lane] = pb[e];
-  }
+  reinterpret_cast<float4*>(&red[0][hw][0])[li] = pa;
+  reinterpret_cast<float4*>(&red[1][hw][0])[li] = pb;
   __syncthreads();
-  for (int i = threadIdx.x; i < D; i += 256) {
-    atomicAdd(&da[i], red[0][0][i] + red[0][1][i] + red[0][2][i] + red[0][3][i]);
-    atomicAdd(&db[i], red[1][0][i] + red[1][1][i] + red[1][2][i] + red[1][3][i]);
+  {
+    const int which = threadIdx.x >> 7, i = threadIdx.x & 127;      // 256 threads = 2 x D outputs
+    float s = 0.f;
+#pragma unroll
+    for (int h = 0; h < 8; ++h) s += red[which][h][i];
+    atomicAdd(which ? &db[i] : &da[i], s);
   }
 }
 
@@ -619,7 +622,7 @@ extern "C" int focr_layernorm_fwd(const float* x, const float* residual, const f
                                   long rows, int D, float eps, hipStream_t stream) {
   FOCR_CHECK_ARG(x && a && b && y && save_mean && save_rinv, "null pointer");
   FOCR_CHECK_ARG(D == 128 && rows > 0, "only D == 128 is built");
-  hipLaunchKernelGGL((ln_fwd_kernel<128>), dim3(cdiv(rows, 4)), 256, 0, stream, x, residual, a, b, y,
+  hipLaunchKernelGGL((ln_fwd_kernel<128>), dim3(cdiv(rows, 8)), 256, 0, stream, x, residual, a, b, y,
                      save_mean, save_rinv, rows, eps);
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
@@ -635,8 +638,8 @@ extern "C" int focr_layernorm_bwd(const float* dy, const float* x, const float* 
     MEMSET0(da, sizeof(float) * D);
     MEMSET0(db, sizeof(float) * D);
   }
-  long g = cdiv(rows, 4);
-  if (g > 1024) g = 1024;
+  long g = cdiv(rows, 8);
+  if (g > 2048) g = 2048;
   hipLaunchKernelGGL((ln_bwd_kernel<128>), dim3((int)g), 256, 0, stream, dy, x, residual, a, save_mean,
                      save_rinv, dx, da, db, rows, eps);
   FOCR_LAUNCH_CHECK();

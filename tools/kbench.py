@@ -100,3 +100,35 @@ if "lstm" in what:
         _lib.call("focr_lstm_bidir_bwd", K._p(hseq), K._p(whh), K._p(gates), K._p(cseq), K._p(dgx), K._p(carry), K._p(wsb), t, B,
                   hid, B, 1, K._stream())
     print("lstm fwd (26 steps) median %.1f us" % timeit(fwd)[0], " bwd median %.1f us" % timeit(bwd)[0])
+
+if "out9" in what:
+    for (h, w) in ((32, 128), (16, 64)):
+        x = torch.randn(B, h, w, 64, device="cuda", generator=g)
+        wt = torch.randn(3, 9, 9, 64, device="cuda", generator=g)
+        bias = torch.randn(3, device="cuda", generator=g)
+        y = torch.empty(B, h, w, 3, device="cuda")
+
+        def fwd():
+            _lib.call("focr_conv9x9_small_cout_fwd", K._p(x), K._p(wt), K._p(bias), K._p(y), B, h, w, 64, 3, K._stream())
+        m, mn = timeit(fwd)
+        print("conv9x9 64->3 %dx%d fwd median %8.1f us  min %8.1f us" % (h, w, m, mn))
+if "ln" in what:
+    rows = B * 1024
+    x = torch.randn(rows, 128, device="cuda", generator=g)
+    r = torch.randn(rows, 128, device="cuda", generator=g)
+    a, b2 = torch.ones(128, device="cuda"), torch.zeros(128, device="cuda")
+    y, dx = torch.empty_like(x), torch.empty_like(x)
+    mean, rinv = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    da, db = torch.zeros(128, device="cuda"), torch.zeros(128, device="cuda")
+
+    def fwd():
+        _lib.call("focr_layernorm_fwd", K._p(x), K._p(r), K._p(a), K._p(b2), K._p(y), K._p(mean), K._p(rinv), rows, 128,
+                  1e-6, K._stream())
+
+    def bwd():
+        _lib.call("focr_layernorm_bwd", K._p(y), K._p(x), K._p(r), K._p(a), K._p(mean), K._p(rinv), K._p(dx), K._p(da),
+                  K._p(db), rows, 128, 1e-6, 1, K._stream())
+    m, mn = timeit(fwd)
+    print("layernorm fwd median %8.1f us  min %8.1f us" % (m, mn))
+    m, mn = timeit(bwd)
+    print("layernorm bwd median %8.1f us  min %8.1f us" % (m, mn))
