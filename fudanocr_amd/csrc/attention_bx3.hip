@@ -19,6 +19,8 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
 #define RP 40   // row-tile pitch (bf16): 80 B
 #define TP 68   // transposed-tile pitch (bf16): 136 B
 
@@ -112,14 +114,16 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_bx3_kernel(const float* __res
 
   bf16x8 qh[2], ql[2];
 #pragma unroll
-  for (int m = 0; m < 2; ++m) row_frag(Q + base + (size_t)q * ld + 16 * m + 8 * lh, scale, qh[m], ql[m]);
-  f32x16 oacc;
+  for (int m = 0; m < 2; ++m) row_frag(Q + base + (size_t)q * ld + 16 * m + 8 * lh, scale * LOG2E, qh[m], ql[m]);
+  f32x16 oacc;   // scores are kept in log2 units (log2 e folded into the Q scale): p = exp2(s - m) is one v_exp_f32
 #pragma unroll
   for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
   float mrun = -1e30f, l = 0.f;
   const uint32_t thr = DROPOUT ? (uint32_t)(p_drop * 65536.0f + 0.5f) : 0u;
   const float inv_keep = DROPOUT ? 1.f / (1.f - (float)thr / 65536.f) : 1.f;
-  const uint2* mrow = reinterpret_cast<const uint2*>(MASK) + (size_t)(b * H + h) * (Ntok / 64) * Ntok + q;
+  const int NG = Ntok / 32;
+  const int qg = __builtin_amdgcn_readfirstlane(qb_ * 4 + wave);
+  const uint64_t* mgrp = reinterpret_cast<const uint64_t*>(MASK) + ((size_t)bh_ * NG + qg) * NG * 16;
 
   const int rp = tid >> 3, c0 = (tid & 7) * 4;         // key pair, first of 4 d columns
   float4 k0, k1, v0, v1;
@@ -138,10 +142,14 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_bx3_kernel(const float* __res
     put_cols(Vth, Vtl, rp, c0, v0, v1);
     __syncthreads();
     if (kt + 1 < ntiles) LOAD_KV(kt + 1);
-    uint2 mw = make_uint2(0u, 0u);
-    if (DROPOUT) mw = mrow[(size_t)kt * Ntok];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
+      uint64_t mk[16];
+      if (DROPOUT) {
+        const uint64_t* mp = mgrp + (size_t)(kt * 2 + sub) * 16;      // wave-uniform -> scalar loads
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mk[r] = mp[r];
+      }
       f32x16 s;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -156,19 +164,18 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_bx3_kernel(const float* __res
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       float mn = fmaxf(mrun, mx);
-      float alpha = __expf(mrun - mn);
+      float alpha = __builtin_amdgcn_exp2f(mrun - mn);
       mrun = mn;
       float ls = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float p = __expf(s[r] - mn);
+        float p = __builtin_amdgcn_exp2f(s[r] - mn);
         ls += p;
         s[r] = p;
       }
       if (DROPOUT) {
-        const uint32_t w = (sub ? mw.y : mw.x) >> (4 * lh);      // lane-half shift once, then constant bits
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = keep_if_bit(s[r], w, (r & 3) + 8 * (r >> 2));   // 1/(1-p) at the end
+        for (int r = 0; r < 16; ++r) s[r] = keep_lanes(s[r], mk[r]);   // 1/(1-p) at the end
       }
       l = l * alpha + ls;
 #pragma unroll
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_bx3_kernel(const float* __res
   for (int g = 0; g < 4; ++g)
     *reinterpret_cast<float4*>(orow + 8 * g + 4 * lh) =
         make_float4(oacc[4 * g] * inv, oacc[4 * g + 1] * inv, oacc[4 * g + 2] * inv, oacc[4 * g + 3] * inv);
-  if (lh == 0) LSE[(size_t)(b * H + h) * Ntok + q] = mrun + __logf(l);
+  if (lh == 0) LSE[(size_t)(b * H + h) * Ntok + q] = (mrun + __builtin_amdgcn_logf(l)) * LN2;   // natural log
 }
 
 // =======================================================================================
@@ -212,7 +219,6 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
   __shared__ __attribute__((aligned(16))) __bf16 Qh[64 * RP], Ql[64 * RP], Gh[64 * RP], Gl[64 * RP];
   __shared__ __attribute__((aligned(16))) __bf16 Qth[32 * TP], Qtl[32 * TP], Gth[32 * TP], Gtl[32 * TP];
   __shared__ float Ls[64], Ds[64];
-  __shared__ uint32_t Mw[4][64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   int bh_, qb_;
   attn_block_decode(blockIdx.x, gridDim.x / (Ntok / 128), Ntok / 128, bh_, qb_);
@@ -236,7 +242,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
   const int rp = tid >> 3, c0 = (tid & 7) * 4;
   float4 q0, q1, g0, g1;
   float lreg = 0.f, dreg = 0.f;
-  uint32_t mreg = 0u;
+  uint32_t mreg0 = 0u, mreg1 = 0u;     // this lane's key word for the two 32-query groups of the tile
+  const int NG = Ntok / 32;
+  const uint32_t* mkey = MASK + ((size_t)bh_ * NG * NG + (qb_ * 4 + wave)) * 32 + mask_slot(li);
 #define LOAD_QG(qt)                                                                   \
   do {                                                                                \
     size_t o0_ = base + (size_t)((qt) * 64 + 2 * rp) * ld + c0;                       \
@@ -249,21 +257,21 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
       dreg = Dv[sbase + (qt) * 64 + tid];                                             \
     }                                                                                 \
     if (DROPOUT) {                                                                    \
-      int g_ = qb_ * 4 + (tid >> 6);                                                  \
-      mreg = MASK[((sbase / Ntok * (Ntok / 64) + (g_ >> 1)) * Ntok + (qt) * 64 + (tid & 63)) * 2 + (g_ & 1)]; \
+      mreg0 = mkey[(size_t)((qt) * 2) * NG * 32];                                     \
+      mreg1 = mkey[(size_t)((qt) * 2 + 1) * NG * 32];                                 \
     }                                                                                 \
   } while (0)
   const int ntiles = Ntok / 64;
   LOAD_QG(0);
   for (int qt = 0; qt < ntiles; ++qt) {
-    q0 = scale4(q0, scale);
-    q1 = scale4(q1, scale);
+    q0 = scale4(q0, scale * LOG2E);     // log2 units: p = exp2(s - lse*log2e); dK is rescaled by ln2 at the end
+    q1 = scale4(q1, scale * LOG2E);
+    const uint32_t mcur0 = mreg0 >> (4 * lh), mcur1 = mreg1 >> (4 * lh);
     put_rows(Qh, Ql, rp, c0, q0, q1);
     put_cols(Qth, Qtl, rp, c0, q0, q1);
     put_rows(Gh, Gl, rp, c0, g0, g1);
     put_cols(Gth, Gtl, rp, c0, g0, g1);
-    if (tid < 64) { Ls[tid] = lreg; Ds[tid] = dreg; }
-    if (DROPOUT) Mw[tid >> 6][tid & 63] = mreg;
+    if (tid < 64) { Ls[tid] = lreg * LOG2E; Ds[tid] = dreg; }
     __syncthreads();
     if (qt + 1 < ntiles) LOAD_QG(qt + 1);
 #pragma unroll
@@ -282,11 +290,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int qlq = sub * 32 + key_of_b(r, lh);
-        float p = __expf(s[r] - Ls[qlq]);
+        float p = __builtin_amdgcn_exp2f(s[r] - Ls[qlq]);
         float pd = p, dpe = dp[r];
         if (DROPOUT) {
-          uint32_t w = Mw[wave][qlq] << (31 - li);      // this lane's key bit -> sign bit
-          int mk = ((int)w) >> 31;
+          int mk = bit_sext(sub ? mcur1 : mcur0, (r & 3) + 8 * (r >> 2));   // query bit of this lane's key word
           pd = __int_as_float(__float_as_int(p) & mk);              // 1/(1-p) folded into the dV store
           dpe = __int_as_float(__float_as_int(dpe * inv_keep) & mk);
         }
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     *reinterpret_cast<float4*>(dkrow + 8 * g + 4 * lh) =
-        make_float4(dkacc[4 * g], dkacc[4 * g + 1], dkacc[4 * g + 2], dkacc[4 * g + 3]);
+        make_float4(dkacc[4 * g] * LN2, dkacc[4 * g + 1] * LN2, dkacc[4 * g + 2] * LN2, dkacc[4 * g + 3] * LN2);
     *reinterpret_cast<float4*>(dvrow + 8 * g + 4 * lh) =
         make_float4(dvacc[4 * g] * inv_keep, dvacc[4 * g + 1] * inv_keep, dvacc[4 * g + 2] * inv_keep,
                     dvacc[4 * g + 3] * inv_keep);
@@ -350,15 +357,17 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_bx3_kernel(
   bf16x8 qh[2], ql[2], gh[2], gl[2];
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
-    row_frag(Q + base + (size_t)q * ld + 16 * m + 8 * lh, scale, qh[m], ql[m]);
+    row_frag(Q + base + (size_t)q * ld + 16 * m + 8 * lh, scale * LOG2E, qh[m], ql[m]);
     row_frag(dO + baseo + (size_t)q * ldo + 16 * m + 8 * lh, 1.f, gh[m], gl[m]);
   }
-  const float lse = LSE[sbase + q], dd = Dv[sbase + q];
+  const float lse = LSE[sbase + q] * LOG2E, dd = Dv[sbase + q];
   f32x16 dqacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) dqacc[r] = 0.f;
   const float inv_keep = DROPOUT ? 1.f / (1.f - (float)(uint32_t)(p_drop * 65536.0f + 0.5f) / 65536.f) : 1.f;
-  const uint2* mrow = reinterpret_cast<const uint2*>(MASK) + sbase * (size_t)(Ntok / 64) + q;
+  const int NG = Ntok / 32;
+  const int qg = __builtin_amdgcn_readfirstlane(qb_ * 4 + wave);
+  const uint64_t* mgrp = reinterpret_cast<const uint64_t*>(MASK) + ((size_t)bh_ * NG + qg) * NG * 16;
 
   const int rp = tid >> 3, c0 = (tid & 7) * 4;
   float4 k0, k1, v0, v1;
@@ -370,10 +379,14 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_bx3_kernel(
     put_rows(Vh, Vl, rp, c0, v0, v1);
     __syncthreads();
     if (kt + 1 < ntiles) LOAD_KV(kt + 1);
-    uint2 mw = make_uint2(0u, 0u);
-    if (DROPOUT) mw = mrow[(size_t)kt * Ntok];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
+      uint64_t mk[16];
+      if (DROPOUT) {
+        const uint64_t* mp = mgrp + (size_t)(kt * 2 + sub) * 16;      // wave-uniform -> scalar loads
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mk[r] = mp[r];
+      }
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -387,12 +400,9 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_bx3_kernel(
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float p = __expf(s[r] - lse);
+        float p = __builtin_amdgcn_exp2f(s[r] - lse);
         float dpe = dp[r];
-        if (DROPOUT) {
-          uint32_t w = (sub ? mw.y : mw.x) >> (4 * lh);
-          dpe = keep_if_bit(dpe * inv_keep, w, (r & 3) + 8 * (r >> 2));
-        }
+        if (DROPOUT) dpe = keep_lanes(dpe * inv_keep, mk[r]);
         s[r] = p * (dpe - dd);
       }
 #pragma unroll

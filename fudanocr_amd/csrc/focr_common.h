@@ -99,6 +99,20 @@ __device__ __forceinline__ float keep_if_bit(float v, uint32_t w, int bit) {
   return __int_as_float(__float_as_int(v) & m);
 }
 
+// ---- attention dropout keep bits --------------------------------------------------------------------
+// uint32 [B*H][Ntok/32 query groups][Ntok/32 key groups][32 slots]; bit j of a word = query 32*qg + j, the word's
+// key is 32*kg + kk with slot = mask_slot(kk).  Slots are ordered so that the two keys held by accumulator
+// register r of the S^T tile (lanes 0-31: key koff(r), lanes 32-63: key koff(r)+4, lane%32 = query) are the two
+// halves of the 64-bit word r of the group: a ready-made lane mask for v_cndmask (forward / dQ kernels: ONE VALU
+// op per score, the words arrive through scalar loads).  The dK/dV kernel (lane = key) loads its key's word
+// per lane and tests bit (query offset) with v_bfe_i32.
+__device__ __forceinline__ int mask_slot(int kk) { return 2 * ((kk & 3) + 4 * (kk >> 3)) + ((kk >> 2) & 1); }
+// (builtin, not inline asm: the compiler must see the instruction to honour the trans-use / MFMA-read hazards)
+__device__ __forceinline__ float keep_lanes(float x, uint64_t m) {
+  return __builtin_amdgcn_inverse_ballot_w64(m) ? x : 0.f;
+}
+__device__ __forceinline__ int bit_sext(uint32_t w, int bit) { return __builtin_amdgcn_sbfe((int)w, bit, 1); }
+
 // counter-based RNG for dropout masks: one 32-bit draw per (seed, index); the same
 // function regenerates the mask in the backward kernels.
 __device__ __forceinline__ uint32_t rng_hash(uint64_t seed, uint64_t idx) {

@@ -400,7 +400,7 @@ class _Attention(torch.autograd.Function):
         _chk(q, k, v)
         o = torch.empty_like(q)
         lse = torch.empty((b, heads, t), device=q.device)
-        mask = torch.empty((b, heads, t // 64, t, 2), device=q.device, dtype=torch.int32) if p_drop > 0 else None
+        mask = torch.empty((b, heads, t // 32, t // 32, 32), device=q.device, dtype=torch.int32) if p_drop > 0 else None
         scale = 1.0 / math.sqrt(d // heads)
         _lib.call("focr_attention_fwd", _p(q), _p(k), _p(v), _p(o), _p(lse), _p(mask), b, heads, t, d, d, scale,
                   float(p_drop), seed, _stream())
@@ -432,7 +432,7 @@ class _AttentionPacked(torch.autograd.Function):
         _chk(qkv)
         o = torch.empty((b, t, d), device=qkv.device)
         lse = torch.empty((b, heads, t), device=qkv.device)
-        mask = torch.empty((b, heads, t // 64, t, 2), device=qkv.device, dtype=torch.int32) if p_drop > 0 else None
+        mask = torch.empty((b, heads, t // 32, t // 32, 32), device=qkv.device, dtype=torch.int32) if p_drop > 0 else None
         scale = 1.0 / math.sqrt(d // heads)
         _lib.call("focr_attention_fwd", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _p(o), _p(lse), _p(mask), b,
                   heads, t, d3, d, scale, float(p_drop), seed, _stream())

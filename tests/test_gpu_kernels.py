@@ -183,9 +183,15 @@ def test_attention_dropout_exact_against_extracted_mask(precision):
     q, k, v = (rnd(b, t, 128, seed=s, scale=1.5).requires_grad_(True) for s in (1, 2, 3))
     qd, kd, vd = (dev(z).requires_grad_(True) for z in (q, k, v))
     od = _Attention.apply(qd, kd, vd, 4, p, 777)
-    words = od.grad_fn.saved_tensors[5].cpu().to(torch.int64) & 0xFFFFFFFF          # [b,4,t/64,t,2]
-    words = words.permute(0, 1, 3, 2, 4).reshape(b, 4, t, t // 32)                   # -> [b,4,q,key/32]
-    bits = ((words.unsqueeze(-1) >> torch.arange(32)) & 1).reshape(b, 4, t, t).double()
+    ng = t // 32
+    words = od.grad_fn.saved_tensors[5].cpu().to(torch.int64) & 0xFFFFFFFF          # [b,4,qg,kg,slot]
+    assert words.shape == (b, 4, ng, ng, 32)
+    slot = torch.arange(32)
+    key_of_slot = ((slot >> 1) & 3) + 8 * (slot >> 3) + 4 * (slot & 1)             # inverse of mask_slot()
+    bits = (words.unsqueeze(-1) >> torch.arange(32)) & 1                             # [b,4,qg,kg,slot,query bit]
+    dense = torch.zeros(b, 4, ng, ng, 32, 32, dtype=torch.int64)                     # [.., key in group, query]
+    dense[:, :, :, :, key_of_slot, :] = bits
+    bits = dense.permute(0, 1, 2, 5, 3, 4).reshape(b, 4, t, t).double()             # [b,4,q,key]
     keep = bits.mean().item()
     assert abs(keep - 0.9) < 4e-3, keep
     thr = round(p * 65536)

@@ -38,7 +38,7 @@ if "attn" in what:
     for p in (0.1, 0.0):
         o = K._Attention.apply(q, k, v, 4, p, 1234)
         lse = torch.empty(B, 4, 1024, device="cuda")
-        mask = torch.empty(B, 4, 1024, 32, device="cuda", dtype=torch.int32)
+        mask = torch.empty(B, 4, 32, 32, 32, device="cuda", dtype=torch.int32)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
         work = torch.empty(B, 4, 1024, device="cuda")
 
