@@ -2,11 +2,12 @@
 """Kernel micro-benchmarks (on-stream event timing, interleaved rounds) for A/B work.
 usage: [FOCR_LIB=path/to/variant.so] python tools/kbench.py [attn] [conv] [lstm] [--batch 128]"""
 import math
+import os
 import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fudanocr_amd import _lib, kernels as K   # noqa: E402
 
 B = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 128
