@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA = vector f32 peak
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak; the bf16x3 split issues 3 MFMA flops per algorithmic flop
 FLOP_PER_IMG = 18.131e9           # TBSRN fwd+bwd 15.311 + frozen CRNN 2.820
 
@@ -125,15 +126,19 @@ def main():
 
     for _ in range(args.warmup):
         step(lr, hr, encoded=enc)
-    timed = ["focr_attention_fwd", "focr_attention_bwd"]
+    timed = ["focr_attention_fwd", "focr_attention_bwd"]          # 10 launches per step
+    conv_steps = min(2, args.steps)      # the ~107 conv launches/step are event-timed in the last steps only (each
+                                         # event pair costs host time: keeps the perturbation of `value` < 0.5 %)
     sync()
     _lib.start_timing(timed)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if i == args.steps - conv_steps:
+            _lib.add_timing(["focr_conv2d_fwd"])
         out = step(lr, hr, encoded=enc)
     sync()
     dt = time.perf_counter() - t0
-    kt = _lib.stop_timing()
+    kt = _lib.stop_timing_with_args()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -142,18 +147,38 @@ def main():
     if rank == 0:
         imgs = args.batch * world * args.steps
         value = imgs / dt
-        # roofline kernel: fused attention forward (one launch per SRB): 4*B*H*N^2*d algorithmic flops;
-        # on-stream event time of the C-ABI call (a single kernel launch) in the timed region
-        fwd_ms = sum(kt["focr_attention_fwd"]) / max(1, len(kt["focr_attention_fwd"]))
+        bx3 = args.precision == "bf16x3"
+        # ---- roofline of the dominant kernel: conv_fwd_bx3_kernel (implicit-GEMM conv / linear, forward AND
+        # data-gradient launches; 28 % of the step in profiles/r01j).  Every C-ABI call = one kernel launch, timed with
+        # events on its stream inside the timed region; algorithmic bytes = each input / weight / output (and
+        # residual) element once, algorithmic flops = 2*M*K*N (DESIGN.md "Measurement").
+        nbytes = nflops = ms = 0.0
+        ncalls = 0
+        for t_ms, a in kt["focr_conv2d_fwd"]:
+            n, h, w, cin, cout, kh, kw, ph, pw = (int(v) for v in a[5:14])
+            if bx3 and cin % 32:
+                continue                              # tiny-Cin first layers run on the fp32 kernel
+            oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
+            m = n * oh * ow
+            has_res = bool(getattr(a[3], "value", a[3]))
+            nbytes += 4.0 * (n * h * w * cin + cout * kh * kw * cin + m * cout * (2 if has_res else 1))
+            nflops += 2.0 * m * cout * kh * kw * cin
+            ms += t_ms
+            ncalls += 1
+        conv_gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        conv_tf = nflops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        peak = PEAK_BF16_MFMA_TFLOPS if bx3 else PEAK_F32_MFMA_TFLOPS
+        fwd = [t for t, _ in kt["focr_attention_fwd"]]
+        bwd = [t for t, _ in kt["focr_attention_bwd"]]
+        fwd_ms = sum(fwd) / max(1, len(fwd))
+        bwd_ms = sum(bwd) / max(1, len(bwd))
         flops_launch = 4.0 * args.batch * 4 * 1024 * 1024 * 32
         ach = flops_launch / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
-        bx3 = args.precision == "bf16x3"
-        peak = PEAK_BF16_MFMA_TFLOPS if bx3 else PEAK_F32_MFMA_TFLOPS
-        # HBM bytes per launch from the PMC passes (profiles/README.md): (2*FETCH_SIZE + WRITE_SIZE) KB,
-        # measured at per-GPU batch 128 only
+        # HBM bytes per launch from the PMC passes (profiles/README.md, r01k): (2*FETCH_SIZE + WRITE_SIZE) KB averaged
+        # over the 105 launches of a step, measured at per-GPU batch 128 only
         traffic = None
-        if args.batch == 128:
-            traffic = 354.6e6 if bx3 else 1.18e9
+        if args.batch == 128 and bx3:
+            traffic = 187.2e6
         res = {
             "metric": "training images/sec (16x64->32x128 SR+CTC step)", "value": round(value, 2),
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -165,13 +190,25 @@ def main():
                        "collective_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
                        "arithmetic": "split-bf16 MFMA (hi/lo operands, 3 products, fp32 accumulate)" if bx3
                        else "exact fp32 MFMA"},
-            "roofline": {"bound": "mfma",
-                         "kernel": ("attn_fwd_bx3_kernel" if bx3 else "attn_fwd_kernel") +
-                                   " (fused QK^T-softmax-dropout-PV)",
-                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(ach / peak, 4), "traffic": traffic,
-                         "avg_launch_ms": round(fwd_ms, 4),
-                         "executed_mfma_frac": round((3 if bx3 else 1) * ach / peak, 4),
+            "roofline": {"bound": "hbm",
+                         "kernel": ("conv_fwd_bx3_kernel" if bx3 else "conv_fwd_kernel") +
+                                   " (implicit-GEMM conv/linear, forward + data-gradient launches)",
+                         "achieved": round(conv_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(conv_gbs / PEAK_HBM_GBS, 4), "traffic": traffic,
+                         "launches_per_step": ncalls // max(1, conv_steps),
+                         "avg_launch_ms": round(ms / max(1, ncalls), 4),
+                         "algorithmic_bytes_per_launch": round(nbytes / max(1, ncalls), 0),
+                         "mfma_view": {"achieved": round(conv_tf, 2), "peak": peak, "unit": "TFLOP/s",
+                                       "frac": round(conv_tf / peak, 4),
+                                       "executed_frac": round((3 if bx3 else 1) * conv_tf / peak, 4)},
+                         "also": [{"kernel": ("attn_fwd_bx3_kernel" if bx3 else "attn_fwd_kernel") +
+                                             " (fused QK^T-softmax-dropout-PV, incl. keep-bit pre-pass)",
+                                   "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                                   "frac": round(ach / peak, 4), "avg_launch_ms": round(fwd_ms, 4),
+                                   "executed_frac": round((3 if bx3 else 1) * ach / peak, 4)},
+                                  {"kernel": "attention backward (prep + dK/dV + dQ launches)", "bound": "mfma",
+                                   "achieved": round(2.5 * flops_launch / (bwd_ms * 1e-3) / 1e12, 2) if bwd_ms else 0.0,
+                                   "peak": peak, "unit": "TFLOP/s", "avg_launch_ms": round(bwd_ms, 4)}],
                          "step_algorithmic_tflops": round(value * FLOP_PER_IMG / world / 1e12, 2)},
             "final_loss": round(loss, 5),
         }

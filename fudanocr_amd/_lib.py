@@ -102,12 +102,29 @@ def start_timing(names):
     _timed = {n: [] for n in names}
 
 
+def add_timing(names):
+    """start timing more entry points while a timing session is open"""
+    for n in names:
+        _timed.setdefault(n, [])
+
+
 def stop_timing():
-    """Returns {name: [ms, ...]} (synchronises)."""
+    """Returns {name: [ms, ...]} (synchronises); with_args=True -> {name: [(ms, call args), ...]}."""
+    return _stop_timing(False)
+
+
+def stop_timing_with_args():
+    return _stop_timing(True)
+
+
+def _stop_timing(with_args):
     global _timed
     import torch
     torch.cuda.synchronize()
-    out = {n: [a.elapsed_time(b) for a, b in ev] for n, ev in (_timed or {}).items()}
+    if with_args:
+        out = {n: [(a.elapsed_time(b), args) for a, b, args in ev] for n, ev in (_timed or {}).items()}
+    else:
+        out = {n: [a.elapsed_time(b) for a, b, _ in ev] for n, ev in (_timed or {}).items()}
     _timed = None
     return out
 
@@ -129,7 +146,7 @@ def call(name, *args):
         a.record()
         rc = getattr(lib, name)(*args)
         b.record()
-        _timed[name].append((a, b))
+        _timed[name].append((a, b, args))
     else:
         rc = getattr(lib, name)(*args)
     if rc != 0:
