@@ -84,8 +84,10 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--arch", default="tbsrn")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32"],
-                    help="contraction arithmetic: split-bf16 MFMA (default) or exact fp32 MFMA")
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16x3-allsplit", "fp32"],
+                    help="contraction arithmetic: split-bf16 MFMA with single-bf16 gradient accumulations in the "
+                         "attention backward (library default, focr_set_precision(2)); the same with split "
+                         "products everywhere (mode 1); or exact fp32 MFMA (mode 0)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,7 +114,7 @@ def main():
     from fudanocr_amd.smoke import build_models
     from fudanocr_amd.utils.synth import make_batch
     _lib.load()
-    _lib.set_precision(1 if args.precision == "bf16x3" else 0)
+    _lib.set_precision({"bf16x3": 2, "bf16x3-allsplit": 1, "fp32": 0}[args.precision])
     net, rec, crit = build_models(dev, args.arch)
     step = TrainStep(net, crit, dropout=True)
     lr, hr, labels = make_batch(args.batch, 1234 + rank)
@@ -147,7 +149,7 @@ def main():
     if rank == 0:
         imgs = args.batch * world * args.steps
         value = imgs / dt
-        bx3 = args.precision == "bf16x3"
+        bx3 = args.precision != "fp32"
         # ---- roofline of the dominant kernel: conv_fwd_bx3_kernel (implicit-GEMM conv / linear, forward AND
         # data-gradient launches; 28 % of the step in profiles/r01j).  Every C-ABI call = one kernel launch, timed with
         # events on its stream inside the timed region; algorithmic bytes = each input / weight / output (and
@@ -188,7 +190,9 @@ def main():
                                    "dropout on, 16x64->32x128", "per_gpu_batch": args.batch,
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "arch": args.arch,
                        "collective_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
-                       "arithmetic": "split-bf16 MFMA (hi/lo operands, 3 products, fp32 accumulate)" if bx3
+                       "arithmetic": ("split-bf16 MFMA (hi/lo operands, 3 products, fp32 accumulate)" +
+                                      ("; dV/dK/dQ accumulations of the attention backward in single bf16 products"
+                                       if args.precision == "bf16x3" else "")) if bx3
                        else "exact fp32 MFMA"},
             # the bounding roofline of this path is the dense-contraction (MFMA) one; `achieved` is the
             # ALGORITHMIC flop rate of the dominant kernel's launches (bf16x3 executes 3 MFMA flops per algorithmic

@@ -89,6 +89,10 @@ def load():
     lib.focr_lstm_ws_bytes.restype = ctypes.c_long
     lib.focr_grad_sumsq_ws_floats.restype = ctypes.c_long
     _lib = lib
+    if os.environ.get("FOCR_PRECISION"):          # 0 fp32 | 1 bf16x3 (default) | 2 bf16x3 + bf16 gradient accumulation
+        rc = lib.focr_set_precision(int(os.environ["FOCR_PRECISION"]))
+        if rc != 0:
+            raise RuntimeError("FOCR_PRECISION: " + lib.focr_last_error().decode())
     return lib
 
 

@@ -210,7 +210,26 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_bx3_kernel(const float* __res
 //   dV^T[d][key] = sum_q dO[q][d] Pd[q][key] : A = dO^T (LDS transposed), B = split(Pd) regs
 //   dK^T[d][key] = sum_q Qs[q][d] dS[q][key] : A = Qs^T (LDS transposed), B = split(dS) regs
 // =======================================================================================
-template <bool DROPOUT>
+#define MFMA1(acc, ah, bh) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0)
+
+// hi parts only (bf16 gradient accumulation, precision mode 2)
+__device__ __forceinline__ void hi_regs(const f32x16& s, int m, bf16x8& hi) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) hi[e] = (__bf16)s[8 * m + e];
+}
+// transposed staging of the hi plane only
+__device__ __forceinline__ void put_cols_hi(__bf16* Th, int rp, int c0, float4 r0, float4 r1) {
+  const float a[4] = {r0.x, r0.y, r0.z, r0.w}, b[4] = {r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    bf16x2 h;
+    h[0] = (__bf16)a[e];
+    h[1] = (__bf16)b[e];
+    *reinterpret_cast<bf16x2*>(&Th[(c0 + e) * TP + 2 * rp]) = h;
+  }
+}
+
+template <bool DROPOUT, bool FAST>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ Dv,
@@ -268,9 +287,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
     q1 = scale4(q1, scale * LOG2E);
     const uint32_t mcur0 = mreg0 >> (4 * lh), mcur1 = mreg1 >> (4 * lh);
     put_rows(Qh, Ql, rp, c0, q0, q1);
-    put_cols(Qth, Qtl, rp, c0, q0, q1);
     put_rows(Gh, Gl, rp, c0, g0, g1);
-    put_cols(Gth, Gtl, rp, c0, g0, g1);
+    if (FAST) {
+      put_cols_hi(Qth, rp, c0, q0, q1);
+      put_cols_hi(Gth, rp, c0, g0, g1);
+    } else {
+      put_cols(Qth, Qtl, rp, c0, q0, q1);
+      put_cols(Gth, Gtl, rp, c0, g0, g1);
+    }
     if (tid < 64) { Ls[tid] = lreg * LOG2E; Ds[tid] = dreg; }
     __syncthreads();
     if (qt + 1 < ntiles) LOAD_QG(qt + 1);
@@ -302,20 +326,28 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
       }
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        bf16x8 ph, pl, sh, sl;
-        split_regs(s, m, ph, pl);
-        split_regs(dp, m, sh, sl);
         const int qc = sub * 32 + 16 * m + 4 * lh;
         bf16x8 gh = cat44(*reinterpret_cast<const bf16x4*>(&Gth[li * TP + qc]),
                           *reinterpret_cast<const bf16x4*>(&Gth[li * TP + qc + 8]));
-        bf16x8 gl = cat44(*reinterpret_cast<const bf16x4*>(&Gtl[li * TP + qc]),
-                          *reinterpret_cast<const bf16x4*>(&Gtl[li * TP + qc + 8]));
-        MFMA3(dvacc, gh, gl, ph, pl);
         bf16x8 ah = cat44(*reinterpret_cast<const bf16x4*>(&Qth[li * TP + qc]),
                           *reinterpret_cast<const bf16x4*>(&Qth[li * TP + qc + 8]));
-        bf16x8 al = cat44(*reinterpret_cast<const bf16x4*>(&Qtl[li * TP + qc]),
-                          *reinterpret_cast<const bf16x4*>(&Qtl[li * TP + qc + 8]));
-        MFMA3(dkacc, ah, al, sh, sl);
+        if (FAST) {
+          bf16x8 ph, sh;
+          hi_regs(s, m, ph);
+          hi_regs(dp, m, sh);
+          MFMA1(dvacc, gh, ph);
+          MFMA1(dkacc, ah, sh);
+        } else {
+          bf16x8 ph, pl, sh, sl;
+          split_regs(s, m, ph, pl);
+          split_regs(dp, m, sh, sl);
+          bf16x8 gl = cat44(*reinterpret_cast<const bf16x4*>(&Gtl[li * TP + qc]),
+                            *reinterpret_cast<const bf16x4*>(&Gtl[li * TP + qc + 8]));
+          MFMA3(dvacc, gh, gl, ph, pl);
+          bf16x8 al = cat44(*reinterpret_cast<const bf16x4*>(&Qtl[li * TP + qc]),
+                            *reinterpret_cast<const bf16x4*>(&Qtl[li * TP + qc + 8]));
+          MFMA3(dkacc, ah, al, sh, sl);
+        }
       }
     }
     __syncthreads();
@@ -337,7 +369,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
 //   S^T[key][q] : A = K rows (LDS), B = Qs (regs)     dP^T[key][q] : A = V rows (LDS), B = dO (regs)
 //   dQ^T[d][q] = sum_key K[key][d] dS[q][key] : A = K^T (LDS transposed), B = split(dS) regs
 // =======================================================================================
-template <bool DROPOUT>
+template <bool DROPOUT, bool FAST>
 __global__ __launch_bounds__(256, 4) void attn_bwd_dq_bx3_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ Dv,
@@ -375,7 +407,8 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_bx3_kernel(
   LOAD_KV(0);
   for (int kt = 0; kt < ntiles; ++kt) {
     put_rows(Kh, Kl, rp, c0, k0, k1);
-    put_cols(Kth, Ktl, rp, c0, k0, k1);
+    if (FAST) put_cols_hi(Kth, rp, c0, k0, k1);
+    else put_cols(Kth, Ktl, rp, c0, k0, k1);
     put_rows(Vh, Vl, rp, c0, v0, v1);
     __syncthreads();
     if (kt + 1 < ntiles) LOAD_KV(kt + 1);
@@ -407,14 +440,20 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_bx3_kernel(
       }
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        bf16x8 sh, sl;
-        split_regs(s, m, sh, sl);
         const int kc = sub * 32 + 16 * m + 4 * lh;
         bf16x8 ah = cat44(*reinterpret_cast<const bf16x4*>(&Kth[li * TP + kc]),
                           *reinterpret_cast<const bf16x4*>(&Kth[li * TP + kc + 8]));
-        bf16x8 al = cat44(*reinterpret_cast<const bf16x4*>(&Ktl[li * TP + kc]),
-                          *reinterpret_cast<const bf16x4*>(&Ktl[li * TP + kc + 8]));
-        MFMA3(dqacc, ah, al, sh, sl);
+        if (FAST) {
+          bf16x8 sh;
+          hi_regs(s, m, sh);
+          MFMA1(dqacc, ah, sh);
+        } else {
+          bf16x8 sh, sl;
+          split_regs(s, m, sh, sl);
+          bf16x8 al = cat44(*reinterpret_cast<const bf16x4*>(&Ktl[li * TP + kc]),
+                            *reinterpret_cast<const bf16x4*>(&Ktl[li * TP + kc + 8]));
+          MFMA3(dqacc, ah, al, sh, sl);
+        }
       }
     }
     __syncthreads();
@@ -444,16 +483,20 @@ int focr_attn_bwd_bx3(const float* q, const float* k, const float* v, const floa
                       const float* dwork, const uint32_t* mask, float* dq, float* dk, float* dv, int B, int H,
                       int Ntok, int ld, int ldo, float scale, float p_drop, hipStream_t stream) {
   dim3 grid(B * H * (Ntok / 128));
+  const bool fast = focr_get_precision() == 2;
+#define LAUNCH_BWD(DR, FA)                                                                                        \
+  do {                                                                                                            \
+    hipLaunchKernelGGL((attn_bwd_dkv_bx3_kernel<DR, FA>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dk, dv, \
+                       mask, Ntok, ld, ldo, scale, p_drop, H);                                                    \
+    hipLaunchKernelGGL((attn_bwd_dq_bx3_kernel<DR, FA>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dq, mask, \
+                       Ntok, ld, ldo, scale, p_drop, H);                                                          \
+  } while (0)
   if (p_drop > 0.f) {
-    hipLaunchKernelGGL((attn_bwd_dkv_bx3_kernel<true>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dk, dv,
-                       mask, Ntok, ld, ldo, scale, p_drop, H);
-    hipLaunchKernelGGL((attn_bwd_dq_bx3_kernel<true>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dq, mask,
-                       Ntok, ld, ldo, scale, p_drop, H);
+    if (fast) LAUNCH_BWD(true, true);
+    else LAUNCH_BWD(true, false);
   } else {
-    hipLaunchKernelGGL((attn_bwd_dkv_bx3_kernel<false>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dk, dv,
-                       mask, Ntok, ld, ldo, scale, p_drop, H);
-    hipLaunchKernelGGL((attn_bwd_dq_bx3_kernel<false>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dq, mask,
-                       Ntok, ld, ldo, scale, p_drop, H);
+    if (fast) LAUNCH_BWD(false, true);
+    else LAUNCH_BWD(false, false);
   }
   return 0;
 }

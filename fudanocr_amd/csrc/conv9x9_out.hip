@@ -321,7 +321,7 @@ extern "C" int focr_conv9x9_small_cout_fwd(const float* x, const float* w, const
     focr_set_error("focr_conv9x9_small_cout_fwd: needs Cin == 64, Cout <= 3, W <= 152");
     return FOCR_EUNSUPPORTED;
   }
-  if (focr_get_precision() == 1) {
+  if (focr_get_precision() != 0) {
     static const size_t lds = (size_t)2 * 9 * 32 * WBP * sizeof(__bf16) + (size_t)WAVES9 * 32 * ZP * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {

@@ -402,7 +402,7 @@ extern "C" int focr_conv2d_fwd(const float* x, const float* w, const float* bias
   if (ldx > 0) g.ldx = ldx;
   FOCR_CHECK_ARG(g.ldy >= Cout && g.ldr >= Cout && g.ldx >= Cin, "row pitch too small");
   bool vec = (Cin % BK == 0) && (g.ldx % 4 == 0);
-  if (vec && focr_get_precision() == 1) {
+  if (vec && focr_get_precision() != 0) {
     focr_conv_fwd_bx3(x, w, bias, residual, y, N, H, W, Cin, g.OH, g.OW, Cout, KH, KW, padH, padW, g.M, g.ldy,
                       g.ldr, g.ldx, alpha, relu, stream);
     FOCR_LAUNCH_CHECK();
@@ -454,7 +454,7 @@ extern "C" int focr_conv2d_wgrad(const float* x, const float* dy, float* dw, flo
     focr_set_error("focr_conv2d_wgrad: memset failed");
     return FOCR_EHIP;
   }
-  if (vec && focr_get_precision() == 1)
+  if (vec && focr_get_precision() != 0)
     focr_conv_wgrad_bx3(x, dy, dw, dbias, N, H, W, Cin, g.OH, g.OW, Cout, KH, KW, padH, padW, g.M, ldd, g.ldx, splits,
                         pps, stream);
   else if (vec)

@@ -153,7 +153,7 @@ extern "C" int focr_lstm_bidir_fwd(const float* gx, const float* whh, const floa
                                    int st_b, hipStream_t stream) {
   FOCR_CHECK_ARG(gx && whh && bhh && hseq && gates && cseq, "null pointer");
   FOCR_CHECK_ARG(T > 0 && B > 0 && H % 32 == 0, "need H % 32 == 0");
-  if (focr_get_precision() == 1 && ws && H == 256) {
+  if (focr_get_precision() != 0 && ws && H == 256) {
     focr_lstm_fwd_bx3(gx, whh, bhh, hseq, gates, cseq, ws, T, B, H, st_t, st_b, stream);
     FOCR_LAUNCH_CHECK();
     return FOCR_OK;
@@ -172,7 +172,7 @@ extern "C" int focr_lstm_bidir_bwd(const float* dhseq, const float* whh, const f
                                    int H, int st_t, int st_b, hipStream_t stream) {
   FOCR_CHECK_ARG(dhseq && whh && gates && cseq && dgx && dc_carry, "null pointer");
   FOCR_CHECK_ARG(T > 0 && B > 0 && H % 32 == 0, "need H % 32 == 0");
-  if (focr_get_precision() == 1 && ws && H == 256) {
+  if (focr_get_precision() != 0 && ws && H == 256) {
     focr_lstm_bwd_bx3(dhseq, whh, gates, cseq, dgx, dc_carry, ws, T, B, H, st_t, st_b, stream);
     FOCR_LAUNCH_CHECK();
     return FOCR_OK;

@@ -30,7 +30,7 @@ def close(got, ref, tol=2e-5, what=""):
     assert err <= lim, "%s: max abs err %.3e > %.3e (ref max %.3e)" % (what, err, lim, ref.abs().max().item())
 
 
-@pytest.fixture(params=[0, 1], ids=["fp32", "bf16x3"])
+@pytest.fixture(params=[0, 1, 2], ids=["fp32", "bf16x3", "bf16x3-fastgrad"])
 def precision(request):
     """run a test under both contraction precisions of the MFMA kernels that have two paths"""
     from fudanocr_amd import _lib
@@ -43,6 +43,11 @@ def precision(request):
 def ptol(precision, base=2e-5):
     # bf16x3 drops the lo*lo term (~2^-17 per product): still far inside the 1e-3 end-to-end gate
     return base if precision == 0 else max(base, 1e-4)
+
+
+def gtol(precision):
+    """attention input gradients: mode 2 accumulates dV/dK/dQ with single bf16 products (2^-9 per term)"""
+    return 3e-3 if precision == 2 else ptol(precision)
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -140,9 +145,9 @@ def test_attention(b, t, precision):
     od = K().attention(qd, kd, vd, heads=4, p_drop=0.0)
     close(od, o, ptol(precision), what="attn fwd")
     od.backward(dev(go))
-    close(qd.grad, q.grad, ptol(precision), what="attn dq")
-    close(kd.grad, k.grad, ptol(precision), what="attn dk")
-    close(vd.grad, v.grad, ptol(precision), what="attn dv")
+    close(qd.grad, q.grad, gtol(precision), what="attn dq")
+    close(kd.grad, k.grad, gtol(precision), what="attn dk")
+    close(vd.grad, v.grad, gtol(precision), what="attn dv")
 
 
 def test_attention_spiked_scores(precision):
@@ -202,9 +207,9 @@ def test_attention_dropout_exact_against_extracted_mask(precision):
     o.backward(go)
     close(od, o, ptol(precision), what="attn dropout fwd")
     od.backward(dev(go))
-    close(qd.grad, q.grad, ptol(precision), what="attn dropout dq")
-    close(kd.grad, k.grad, ptol(precision), what="attn dropout dk")
-    close(vd.grad, v.grad, ptol(precision), what="attn dropout dv")
+    close(qd.grad, q.grad, gtol(precision), what="attn dropout dq")
+    close(kd.grad, k.grad, gtol(precision), what="attn dropout dk")
+    close(vd.grad, v.grad, gtol(precision), what="attn dropout dv")
 
 
 @pytest.mark.parametrize("act", [0, 1, 4])
@@ -533,4 +538,4 @@ def test_attention_packed_qkv(precision):
     od = K().attention_packed(qd, heads=4, p_drop=0.0)
     close(od, o, ptol(precision), what="packed attn fwd")
     od.backward(dev(go))
-    close(qd.grad, qkv.grad, ptol(precision), what="packed attn dqkv")
+    close(qd.grad, qkv.grad, gtol(precision), what="packed attn dqkv")

@@ -30,6 +30,8 @@ def timeit(fn, iters=8, warm=2):
 
 if "--fp32" in sys.argv:
     _lib.set_precision(0)
+if "--prec" in sys.argv:
+    _lib.set_precision(int(sys.argv[sys.argv.index("--prec") + 1]))
 print("lib:", _lib.LIB_PATH, " batch", B, " precision", _lib.get_precision())
 g = torch.Generator(device="cuda").manual_seed(0)
 if "attn" in what:
