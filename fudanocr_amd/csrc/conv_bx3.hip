@@ -293,10 +293,152 @@ __global__ __launch_bounds__(256) void conv_wgrad_bx3_kernel(const float* __rest
   }
 }
 
+// 128 co x 128 k tile (4 waves x (64 x 64) = 4 accumulator tiles each): every dY / X element of the pixel range is
+// fetched ONCE (the 64 x 64 kernel re-reads each operand once per tile of the other), twice the MFMA work per barrier
+// and a quarter of the atomics per pixel.  For layers with Cin % 128 == 0 and Cout % 128 == 0 (the transformer
+// linears): the k block stays inside one tap.
+__global__ __launch_bounds__(256) void conv_wgrad_bx3_wide_kernel(const float* __restrict__ X,
+                                                                  const float* __restrict__ dY, float* __restrict__ dW,
+                                                                  float* __restrict__ dbias, ConvGeomX g, int ldd,
+                                                                  int pix_per_split) {
+  __shared__ __attribute__((aligned(16))) __bf16 Dth[128 * WTP], Dtl[128 * WTP], Xth[128 * WTP], Xtl[128 * WTP];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int k0 = blockIdx.x * 128, co0 = blockIdx.y * 128;
+  const int pbeg = blockIdx.z * pix_per_split;
+  const int pend = min(g.M, pbeg + pix_per_split);
+  if (pbeg >= pend) return;
+  const int tap = k0 / g.Cin, ci0 = k0 - tap * g.Cin;
+  const int tkh = tap / g.KW, tkw = tap - tkh * g.KW;
+  const int pq = tid & 15, c4 = (tid >> 4) * 4;
+  const bool do_bias = dbias != nullptr && blockIdx.x == 0;
+  float bsum[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+
+  float4 dv0[4], dv1[4], xv0[4], xv1[4];
+  auto load_chunk = [&](int pc) {
+    int p = pc + 4 * pq;
+    int n = 0, oy = 0, ox = 0;
+    if (p < pend) {
+      n = p / (g.OH * g.OW);
+      int rem = p - n * (g.OH * g.OW);
+      oy = rem / g.OW;
+      ox = rem - oy * g.OW;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 d0 = z, d1 = z, x0 = z, x1 = z;
+      if (p + j < pend) {
+        const float* dp = dY + (size_t)(p + j) * ldd + co0 + c4;
+        d0 = *reinterpret_cast<const float4*>(dp);
+        d1 = *reinterpret_cast<const float4*>(dp + 64);
+        int iy = oy - g.padH + tkh, ix = ox - g.padW + tkw;
+        if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W) {
+          const float* xp = X + ((size_t)((n * g.H + iy) * g.W + ix) * g.ldx + ci0 + c4);
+          x0 = *reinterpret_cast<const float4*>(xp);
+          x1 = *reinterpret_cast<const float4*>(xp + 64);
+        }
+      }
+      dv0[j] = d0; dv1[j] = d1; xv0[j] = x0; xv1[j] = x1;
+      if (++ox == g.OW) {
+        ox = 0;
+        if (++oy == g.OH) { oy = 0; ++n; }
+      }
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int wi = wave >> 1, wj = wave & 1;
+  const int aoff = (wi * 64 + li) * WTP + 8 * lh, boff = (wj * 64 + li) * WTP + 8 * lh;
+
+  load_chunk(pbeg);
+  for (int pc = pbeg; pc < pend; pc += 64) {
+    put_quad(Dth, Dtl, c4, 4 * pq, dv0);
+    put_quad(Dth, Dtl, c4 + 64, 4 * pq, dv1);
+    put_quad(Xth, Xtl, c4, 4 * pq, xv0);
+    put_quad(Xth, Xtl, c4 + 64, 4 * pq, xv1);
+    if (do_bias) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bsum[0][0] += dv0[j].x; bsum[0][1] += dv0[j].y; bsum[0][2] += dv0[j].z; bsum[0][3] += dv0[j].w;
+        bsum[1][0] += dv1[j].x; bsum[1][1] += dv1[j].y; bsum[1][2] += dv1[j].z; bsum[1][3] += dv1[j].w;
+      }
+    }
+    __syncthreads();
+    if (pc + 64 < pend) load_chunk(pc + 64);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        ah[t] = *reinterpret_cast<const bf16x8*>(&Dth[aoff + t * 32 * WTP + 16 * m]);
+        al[t] = *reinterpret_cast<const bf16x8*>(&Dtl[aoff + t * 32 * WTP + 16 * m]);
+        bh[t] = *reinterpret_cast<const bf16x8*>(&Xth[boff + t * 32 * WTP + 16 * m]);
+        bl[t] = *reinterpret_cast<const bf16x8*>(&Xtl[boff + t * 32 * WTP + 16 * m]);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+  if (do_bias) {   // fold the 16 pixel-quad lanes of each column in LDS: 128 atomics per block
+    float* red = reinterpret_cast<float*>(Dth);          // 16 x 128 floats = 8 KB of the 18 KB tile
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[pq * 128 + c4 + e] = bsum[0][e];
+      red[pq * 128 + 64 + c4 + e] = bsum[1][e];
+    }
+    __syncthreads();
+    if (tid < 128) {
+      float s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s2 += red[r * 128 + tid];
+      atomicAdd(&dbias[co0 + tid], s2);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      int k = k0 + wj * 64 + b * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int co = co0 + wi * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        atomicAdd(&dW[(size_t)co * g.Ktot + k], acc[a][b][r]);
+      }
+    }
+}
+
+#ifndef WGRADW_BLOCKS
+#define WGRADW_BLOCKS 512
+#endif
+
 int focr_conv_wgrad_bx3(const float* x, const float* dy, float* dw, float* dbias, int N, int H, int W, int Cin,
                         int OH, int OW, int Cout, int KH, int KW, int padH, int padW, int M, int ldd, int ldx,
                         int splits, int pps, hipStream_t stream) {
   ConvGeomX g{N, H, W, Cin, OH, OW, Cout, KH, KW, padH, padW, KH * KW * Cin, M, Cout, Cout, ldx};
+  if (Cin % 128 == 0 && Cout % 128 == 0) {
+    const int tiles = (g.Ktot / 128) * (Cout / 128);
+    int sp = WGRADW_BLOCKS / tiles;
+    const int maxsp = (M + 511) / 512;                 // >= 8 reduction chunks per block
+    if (sp > maxsp) sp = maxsp;
+    if (sp < 1) sp = 1;
+    const int pp = (((M + sp - 1) / sp + 63) / 64) * 64;
+    sp = (M + pp - 1) / pp;
+    dim3 gridw(g.Ktot / 128, Cout / 128, sp);
+    hipLaunchKernelGGL(conv_wgrad_bx3_wide_kernel, gridw, 256, 0, stream, x, dy, dw, dbias, g, ldd, pp);
+    return 0;
+  }
   dim3 grid(g.Ktot / 64, (Cout + 63) / 64, splits);
   hipLaunchKernelGGL(conv_wgrad_bx3_kernel, grid, 256, 0, stream, x, dy, dw, dbias, g, ldd, pps);
   return 0;
