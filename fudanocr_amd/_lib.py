@@ -15,7 +15,8 @@ P, I, L, F, U = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ct
 # name -> argument types (every entry point returns int and takes the stream last)
 SIGNATURES = {
     "focr_conv2d_fwd": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, I, I, P],
-    "focr_conv2d_wgrad": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
+    "focr_conv2d_wgrad": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, L, P],
+    "focr_conv2d_wgrad_ws_floats": [I, I, I, I, I, I, I, I, I],
     "focr_weight_flip_transpose": [P, P, I, I, I, I, P],
     "focr_colsum": [P, P, L, I, I, P],
     "focr_attention_fwd": [P, P, P, P, P, P, I, I, I, I, I, F, F, U, P],
@@ -88,6 +89,7 @@ def load():
     lib.focr_bn_bwd_ws_floats.restype = ctypes.c_long
     lib.focr_lstm_ws_bytes.restype = ctypes.c_long
     lib.focr_grad_sumsq_ws_floats.restype = ctypes.c_long
+    lib.focr_conv2d_wgrad_ws_floats.restype = ctypes.c_long
     _lib = lib
     if os.environ.get("FOCR_PRECISION"):          # 0 fp32 | 1 bf16x3 (default) | 2 bf16x3 + bf16 gradient accumulation
         rc = lib.focr_set_precision(int(os.environ["FOCR_PRECISION"]))

@@ -1,0 +1,282 @@
+// Weight gradient of the 3x3 / pad 1 / Cin = 64 layers (SRB conv1/conv2, block7, upsample conv; tsrn.py:89-98,110-114,
+// tbsrn.py:246-257), bf16x3, streaming over image rows.
+//
+// The generic wgrad kernel (conv_bx3.hip) launches one block per (tap, pixel range): every dY and X element is fetched
+// nine times through L2, and that traffic IS its run time (106 us with, 51 us without the global loads at B = 128).
+// Here one block owns a 64-channel output slice and ALL nine taps for a range of input rows:
+//   * accumulators of the nine 64x64 tap tiles stay in registers (4 waves x 9 x 32x32);
+//   * per input row iy the X row is fetched once and staged TRANSPOSED (Xt[ci][px], bf16 hi/lo) three times, shifted
+//     by kw - 1 pixels -- the shifted 4-pixel quads are assembled with DPP row shifts (lane = pixel quad), so every
+//     LDS store and every MFMA fragment read stays 8/16-byte aligned; the zero halo falls out of bound_ctrl;
+//   * tap row kh pairs input row iy with dY row iy + 1 - kh: the three dY rows live in a rolling 3-slot LDS window,
+//     one new row per step;
+//   * next step's X / dY rows are prefetched into registers during the 108 MFMAs of the current one.
+// HBM/L2 traffic: X once, dY (1 + 2/rows_per_block) times.
+#include "focr_common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 wbf16x8;
+
+#define GP 72            // LDS pitch (bf16) of a transposed tile row: 64 pixels + 8
+#define TILE_E (64 * GP) // elements of one [64][GP] plane
+
+// thread (pq = pixel quad, c4 = first of 4 channels) holds a 4 px x 4 ch patch; for channel e returns the packed
+// bf16 pixels (w0 = px0 | px1 << 16, w1 = px2 | px3 << 16) of the hi and lo planes
+__device__ __forceinline__ void pack_quad(const float4 (&r)[4], int e, uint32_t& h0, uint32_t& h1, uint32_t& l0,
+                                          uint32_t& l1) {
+  const float v[4] = {e == 0 ? r[0].x : e == 1 ? r[0].y : e == 2 ? r[0].z : r[0].w,
+                      e == 0 ? r[1].x : e == 1 ? r[1].y : e == 2 ? r[1].z : r[1].w,
+                      e == 0 ? r[2].x : e == 1 ? r[2].y : e == 2 ? r[2].z : r[2].w,
+                      e == 0 ? r[3].x : e == 1 ? r[3].y : e == 2 ? r[3].z : r[3].w};
+  uint32_t hb[4], lb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    __bf16 h = (__bf16)v[j];
+    __bf16 l = (__bf16)(v[j] - (float)h);
+    hb[j] = (uint32_t)__builtin_bit_cast(unsigned short, h);
+    lb[j] = (uint32_t)__builtin_bit_cast(unsigned short, l);
+  }
+  h0 = hb[0] | (hb[1] << 16);
+  h1 = hb[2] | (hb[3] << 16);
+  l0 = lb[0] | (lb[1] << 16);
+  l1 = lb[2] | (lb[3] << 16);
+}
+__device__ __forceinline__ void st2(__bf16* p, uint32_t a, uint32_t b) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(a, b);
+}
+// value of the previous / next lane of the 16-lane row (0 at the row ends): the 1-pixel halo of a 64-pixel image row
+__device__ __forceinline__ uint32_t from_prev(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint32_t from_next(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101 /*row_shl:1*/, 0xf, 0xf, true);
+}
+
+// plain transposed staging of a dY row: Dt[co][px]
+__device__ __forceinline__ void stage_d(__bf16* Dh, __bf16* Dl, int c4, int pq, const float4 (&r)[4]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    uint32_t h0, h1, l0, l1;
+    pack_quad(r, e, h0, h1, l0, l1);
+    st2(&Dh[(c4 + e) * GP + 4 * pq], h0, h1);
+    st2(&Dl[(c4 + e) * GP + 4 * pq], l0, l1);
+  }
+}
+// X row: three copies, copy kw holds X[px + kw - 1] at position px
+__device__ __forceinline__ void stage_x(__bf16* Xh, __bf16* Xl, int c4, int pq, const float4 (&r)[4]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    uint32_t h0, h1, l0, l1;
+    pack_quad(r, e, h0, h1, l0, l1);
+    const int o = (c4 + e) * GP + 4 * pq;
+    st2(&Xh[TILE_E + o], h0, h1);
+    st2(&Xl[TILE_E + o], l0, l1);
+    st2(&Xh[o], __builtin_amdgcn_alignbit(h0, from_prev(h1), 16), __builtin_amdgcn_alignbit(h1, h0, 16));
+    st2(&Xl[o], __builtin_amdgcn_alignbit(l0, from_prev(l1), 16), __builtin_amdgcn_alignbit(l1, l0, 16));
+    st2(&Xh[2 * TILE_E + o], __builtin_amdgcn_alignbit(h1, h0, 16), __builtin_amdgcn_alignbit(from_next(h0), h1, 16));
+    st2(&Xl[2 * TILE_E + o], __builtin_amdgcn_alignbit(l1, l0, 16), __builtin_amdgcn_alignbit(from_next(l0), l1, 16));
+  }
+}
+
+// PART != nullptr: the block writes its 9 x 64 x 64 partial tile to PART[blockIdx.y][co tile] with plain stores (no
+// same-address atomics: 256 blocks adding into one 147 KB array cost as much as the rest of the kernel) and
+// conv3x3_c64_reduce_kernel folds them.  PART == nullptr: fp32 atomics into dW.
+__global__ __launch_bounds__(256) void conv3x3_c64_wgrad_kernel(const float* __restrict__ X,
+                                                                const float* __restrict__ dY, float* __restrict__ dW,
+                                                                float* __restrict__ dbias, float* __restrict__ PART,
+                                                                int N, int H, int W, int Cout, int ldx, int ldd,
+                                                                int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+  __bf16* Xh = reinterpret_cast<__bf16*>(smem3);       // [3 kw copies][64 ci][GP]
+  __bf16* Xl = Xh + 3 * TILE_E;
+  __bf16* Dh = Xl + 3 * TILE_E;                        // [3 slots][64 co][GP]
+  __bf16* Dl = Dh + 3 * TILE_E;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int co0 = blockIdx.x * 64;
+  const int R0 = blockIdx.y * rows_per_block, R1 = min(N * H, R0 + rows_per_block);
+  if (R0 >= R1) return;
+  const int pq = tid & 15, c4 = (tid >> 4) * 4;
+  const bool pxok = 4 * pq < W;                        // W % 4 == 0
+  const int wi = wave >> 1, wj = wave & 1;
+  const int aoff = (wi * 32 + li) * GP + 8 * lh, boff = (wj * 32 + li) * GP + 8 * lh;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  float4 xr[4], dr[4];
+#define LOAD_X(G)                                                                                        \
+  {                                                                                                      \
+    const float* p_ = X + ((size_t)(G) * W + 4 * pq) * ldx + c4;                                         \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) xr[j] =                                                \
+        pxok ? *reinterpret_cast<const float4*>(p_ + (size_t)j * ldx) : make_float4(0.f, 0.f, 0.f, 0.f); \
+  }
+#define LOAD_D(G)                                                                                        \
+  {                                                                                                      \
+    const float* p_ = dY + ((size_t)(G) * W + 4 * pq) * ldd + co0 + c4;                                  \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) dr[j] =                                                \
+        pxok ? *reinterpret_cast<const float4*>(p_ + (size_t)j * ldd) : make_float4(0.f, 0.f, 0.f, 0.f); \
+  }
+#define STAGE_D(G)                                                                                       \
+  {                                                                                                      \
+    const int s_ = (G) % 3;                                                                              \
+    stage_d(Dh + s_ * TILE_E, Dl + s_ * TILE_E, c4, pq, dr);                                             \
+    if (dbias && (G) >= R0 && (G) < R1) {                                                                \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                    \
+        bsum[0] += dr[j].x; bsum[1] += dr[j].y; bsum[2] += dr[j].z; bsum[3] += dr[j].w;                  \
+      }                                                                                                  \
+    }                                                                                                    \
+  }
+
+  bool have_x = false, have_d = false;                 // registers hold X row g / dY row g + 1 of the coming step
+  for (int g = R0; g < R1; ++g) {
+    const int iy = g % H;
+    const bool first = g == R0;
+    // dY rows of this step: g + 1 - kh, valid while inside the image
+    const bool v0 = iy + 1 < H, v1 = true, v2 = iy > 0;
+    if (first || iy == 0) {                            // window not primed (block start / new image): rows g-1, g
+      if (v2 && first) { LOAD_D(g - 1) STAGE_D(g - 1) }
+      LOAD_D(g) STAGE_D(g)
+    }
+    if (v0) {
+      if (!have_d) LOAD_D(g + 1)
+      STAGE_D(g + 1)
+    }
+    if (!have_x) LOAD_X(g)
+    stage_x(Xh, Xl, c4, pq, xr);
+    __syncthreads();
+    have_x = g + 1 < R1;
+    if (have_x) LOAD_X(g + 1)
+    have_d = g + 1 < R1 && (g + 1) % H + 1 < H && (g + 1) % H != 0;   // next step stages row g + 2 from registers
+    if (have_d) LOAD_D(g + 2)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      wbf16x8 bh[3], bl[3];
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        bh[kw] = *reinterpret_cast<const wbf16x8*>(&Xh[kw * TILE_E + boff + 16 * m]);
+        bl[kw] = *reinterpret_cast<const wbf16x8*>(&Xl[kw * TILE_E + boff + 16 * m]);
+      }
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const bool ok = kh == 0 ? v0 : kh == 1 ? v1 : v2;
+        if (ok) {
+          const int s = (g + 1 - kh) % 3;
+          wbf16x8 ah = *reinterpret_cast<const wbf16x8*>(&Dh[s * TILE_E + aoff + 16 * m]);
+          wbf16x8 al = *reinterpret_cast<const wbf16x8*>(&Dl[s * TILE_E + aoff + 16 * m]);
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[kw], acc[kh * 3 + kw], 0, 0, 0);
+            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[kw], acc[kh * 3 + kw], 0, 0, 0);
+            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[kw], acc[kh * 3 + kw], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (dbias) {     // fold the 16 pixel-quad lanes of each column: 64 atomics per block
+    float* red = reinterpret_cast<float*>(Xh);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[pq * 64 + c4 + e] = bsum[e];
+    __syncthreads();
+    if (tid < 64) {
+      float s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s2 += red[r * 64 + tid];
+      atomicAdd(&dbias[co0 + tid], s2);
+    }
+  }
+  const int ci = wj * 32 + li;
+  if (PART) {
+    // slot layout = the dW slice of this co tile: [64 co][9][64 ci]
+    float* slot = PART + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (64 * 9 * 64);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int col = wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        slot[((size_t)col * 9 + t) * 64 + ci] = acc[t][r];
+      }
+    return;
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      atomicAdd(&dW[((size_t)co * 9 + t) * 64 + ci], acc[t][r]);
+    }
+}
+
+// dW[co tile][i] += sum over row blocks of PART[row block][co tile][i].  grid.y = RG groups of row blocks (enough
+// blocks in flight to stream the partials at HBM rate); each group adds its sum with one atomic per element
+// (RG-way contention instead of nb-way).
+#define C3_RG 8
+__global__ __launch_bounds__(256) void conv3x3_c64_reduce_kernel(const float* __restrict__ PART, float* __restrict__ dW,
+                                                                 int ntile, int nb) {
+  const int per = 64 * 9 * 64 / 4;                       // float4 per co tile
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= ntile * per) return;
+  const int tile = i / per, e = i - tile * per;
+  const int b0 = (int)((long)nb * blockIdx.y / C3_RG), b1 = (int)((long)nb * (blockIdx.y + 1) / C3_RG);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+  for (int b = b0; b < b1; ++b) {
+    float4 v = reinterpret_cast<const float4*>(PART)[((size_t)b * ntile + tile) * per + e];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  float* o = dW + ((size_t)tile * per + e) * 4;
+  atomicAdd(o, s.x);
+  atomicAdd(o + 1, s.y);
+  atomicAdd(o + 2, s.z);
+  atomicAdd(o + 3, s.w);
+}
+
+static bool c3_applicable(int W, int Cin, int Cout, int KH, int KW, int padH, int padW, int ldd, int ldx) {
+  return KH == 3 && KW == 3 && padH == 1 && padW == 1 && Cin == 64 && Cout % 64 == 0 && W <= 64 && W % 4 == 0 &&
+         ldx % 4 == 0 && ldd % 4 == 0;
+}
+static void c3_blocks(int N, int H, int Cout, int& nb, int& rpb) {
+  const int rows = N * H;
+  nb = 256 / (Cout / 64);                         // one block per CU (110 KB of LDS each)
+  if (nb < 1) nb = 1;
+  if (nb > rows) nb = rows;
+  rpb = cdiv(rows, nb);
+  nb = cdiv(rows, rpb);
+}
+
+// floats of workspace that make the 3x3 / Cin 64 weight gradient atomic-free (0: layer not handled by this file)
+long focr_conv3x3_c64_ws_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW) {
+  if (!c3_applicable(W, Cin, Cout, KH, KW, padH, padW, 4, 4)) return 0;
+  int nb, rpb;
+  c3_blocks(N, H, Cout, nb, rpb);
+  return (long)nb * (Cout / 64) * (64 * 9 * 64);
+}
+
+// launcher used by focr_conv2d_wgrad (conv_igemm.hip); returns 1 if the layer was handled here
+int focr_conv3x3_c64_wgrad(const float* x, const float* dy, float* dw, float* dbias, float* ws, long ws_floats, int N,
+                           int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW, int ldd, int ldx,
+                           hipStream_t stream) {
+  if (!c3_applicable(W, Cin, Cout, KH, KW, padH, padW, ldd, ldx)) return 0;
+  static const size_t lds = (size_t)12 * TILE_E * sizeof(__bf16);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_wgrad_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return 0;
+    attr_set = true;
+  }
+  int nb, rpb;
+  c3_blocks(N, H, Cout, nb, rpb);
+  const int ntile = Cout / 64;
+  float* part = (ws && ws_floats >= (long)nb * ntile * (64 * 9 * 64)) ? ws : nullptr;
+  hipLaunchKernelGGL(conv3x3_c64_wgrad_kernel, dim3(ntile, nb), 256, lds, stream, x, dy, dw, dbias, part, N, H, W,
+                     Cout, ldx, ldd, rpb);
+  if (part)
+    hipLaunchKernelGGL(conv3x3_c64_reduce_kernel, dim3(cdiv(ntile * 64 * 9 * 64 / 4, 256), C3_RG), 256, 0, stream, part, dw,
+                       ntile, nb);
+  return 1;
+}

@@ -389,6 +389,10 @@ int focr_conv_fwd_bx3(const float* x, const float* w, const float* bias, const f
 int focr_conv_wgrad_bx3(const float* x, const float* dy, float* dw, float* dbias, int N, int H, int W, int Cin,
                         int OH, int OW, int Cout, int KH, int KW, int padH, int padW, int M, int ldd, int ldx,
                         int splits, int pps, hipStream_t stream);
+int focr_conv3x3_c64_wgrad(const float* x, const float* dy, float* dw, float* dbias, float* ws, long ws_floats, int N,
+                           int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW, int ldd, int ldx,
+                           hipStream_t stream);
+long focr_conv3x3_c64_ws_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW);
 
 extern "C" int focr_conv2d_fwd(const float* x, const float* w, const float* bias,
                                const float* residual, float* y, int N, int H, int W, int Cin,
@@ -425,9 +429,18 @@ extern "C" int focr_conv2d_fwd(const float* x, const float* w, const float* bias
 // dw must hold Cout*KH*KW*Cin floats, dbias (nullable) Cout floats.  The kernel ACCUMULATES with fp32
 // atomics: prezeroed = 0 -> the buffers are cleared here first (overwrite semantics); prezeroed = 1 ->
 // the caller guarantees they are zero (e.g. slices of a gradient buffer zeroed once per step).
+// ws / ws_floats (optional): focr_conv2d_wgrad_ws_floats() floats of scratch; with it the layers that have a
+// partial-tile path (3x3, Cin = 64, bf16x3 modes) use no atomics at all.
+extern "C" long focr_conv2d_wgrad_ws_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int padH,
+                                            int padW) {
+  if (focr_get_precision() == 0) return 0;
+  return focr_conv3x3_c64_ws_floats(N, H, W, Cin, Cout, KH, KW, padH, padW);
+}
+
 extern "C" int focr_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N,
                                  int H, int W, int Cin, int Cout, int KH, int KW, int padH,
-                                 int padW, int ldd, int ldx, int prezeroed, hipStream_t stream) {
+                                 int padW, int ldd, int ldx, int prezeroed, float* ws, long ws_floats,
+                                 hipStream_t stream) {
   ConvGeom g;
   FOCR_CHECK_ARG(x && dy && dw, "null pointer");
   FOCR_CHECK_ARG(fill_geom(g, N, H, W, Cin, Cout, KH, KW, padH, padW) == 0, "bad geometry");
@@ -453,6 +466,12 @@ extern "C" int focr_conv2d_wgrad(const float* x, const float* dy, float* dw, flo
   if (dbias && !prezeroed && hipMemsetAsync(dbias, 0, sizeof(float) * Cout, stream) != hipSuccess) {
     focr_set_error("focr_conv2d_wgrad: memset failed");
     return FOCR_EHIP;
+  }
+  if (vec && focr_get_precision() != 0 &&
+      focr_conv3x3_c64_wgrad(x, dy, dw, dbias, ws, ws_floats, N, H, W, Cin, Cout, KH, KW, padH, padW, ldd, g.ldx,
+                             stream)) {
+    FOCR_LAUNCH_CHECK();
+    return FOCR_OK;
   }
   if (vec && focr_get_precision() != 0)
     focr_conv_wgrad_bx3(x, dy, dw, dbias, N, H, W, Cin, g.OH, g.OW, Cout, KH, KW, padH, padW, g.M, ldd, g.ldx, splits,

@@ -144,8 +144,10 @@ class _Conv2d(torch.autograd.Function):
                 _lib.call("focr_conv9x9_small_cout_wgrad", _p(x4), _p(dy4), _p(dw), _p(db), n, h, w, cin,
                           cout, pz, _stream())
             else:
+                nws = _lib.load().focr_conv2d_wgrad_ws_floats(n, h, w, cin, cout, kh, kw, ph, pw)
+                ws = torch.empty(nws, device=dy.device, dtype=torch.float32) if nws > 0 else None
                 _lib.call("focr_conv2d_wgrad", _p(x4), _p(dy4), _p(dw), _p(db), n, h, w, cin, cout, kh, kw,
-                          ph, pw, 0, 0, pz, _stream())
+                          ph, pw, 0, 0, pz, _p(ws), nws, _stream())
             if alpha != 1.0:
                 _lib.call("focr_axpy", _p(dw), _NULL, _p(dw), dw.numel(), alpha, _stream())
         elif has_bias and ctx.needs_input_grad[2]:
@@ -711,7 +713,7 @@ class _GRURecur(torch.autograd.Function):
         dbhh = torch.empty((2, 96), device=dh.device)
         for d in (0, 1):     # dW_hh[d] = dgh[:, d]^T hprev[:, d]  -- the generic wgrad on strided views
             _lib.call("focr_conv2d_wgrad", _po(hprev, 32 * d), _po(dgh, 96 * d), _po(dwhh, 96 * 32 * d),
-                      _po(dbhh, 96 * d), rows, 1, 1, 32, 96, 1, 1, 0, 0, 192, 64, 0, _stream())
+                      _po(dbhh, 96 * d), rows, 1, 1, 32, 96, 1, 1, 0, 0, 192, 64, 0, _NULL, 0, _stream())
         return dgx, dwhh, dbhh, None, None, None, None, None, None
 
 

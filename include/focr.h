@@ -54,9 +54,13 @@ int focr_conv2d_fwd(const float* x, const float* w, const float* bias, const flo
 /* dw[Cout][KH][KW][Cin], dbias[Cout] (nullable); ldd = row pitch of dy (0: Cout).  Gradient outputs of
  * every *_wgrad/_bwd entry are accumulated with atomics: prezeroed=0 clears them first (overwrite),
  * prezeroed=1 means the caller guarantees zeros (slices of a gradient buffer cleared once per step). */
+/* ws (nullable) / ws_floats: focr_conv2d_wgrad_ws_floats() floats of scratch; with it the layers that have a
+ * partial-tile path (3x3, Cin = 64 in the bf16x3 modes) write per-block partial tiles and fold them in a second
+ * kernel instead of sending every block's tile through same-address atomics. */
+long focr_conv2d_wgrad_ws_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW);
 int focr_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N, int H, int W,
                       int Cin, int Cout, int KH, int KW, int padH, int padW, int ldd, int ldx,
-                      int prezeroed, focr_stream_t stream);
+                      int prezeroed, float* ws, long ws_floats, focr_stream_t stream);
 /* w[Cout][KH][KW][Cin] -> wd[Cin][KH][KW][Cout] with both spatial axes flipped */
 int focr_weight_flip_transpose(const float* w, float* wd, int Cout, int KH, int KW, int Cin,
                                focr_stream_t stream);

@@ -70,6 +70,8 @@ if "conv" in what:
         dw = torch.empty_like(wt)
         db = torch.empty(cout, device="cuda")
         fl = 2.0 * n * h * w * cout * ks * ks * cin
+        nws = _lib.load().focr_conv2d_wgrad_ws_floats(n, h, w, cin, cout, ks, ks, pad, pad)
+        wsw = torch.empty(nws, device="cuda") if nws > 0 else None
 
         def fwd():
             _lib.call("focr_conv2d_fwd", K._p(x), K._p(wt), K._p(bias), K._NULL, K._p(y), n, h, w, cin, cout, ks, ks,
@@ -77,7 +79,7 @@ if "conv" in what:
 
         def wg():
             _lib.call("focr_conv2d_wgrad", K._p(x), K._p(y), K._p(dw), K._p(db), n, h, w, cin, cout, ks, ks, pad, pad,
-                      0, 0, 0, K._stream())
+                      0, 0, 0, K._p(wsw), nws, K._stream())
         m, mn = timeit(fwd)
         m2, mn2 = timeit(wg)
         print("%-26s fwd median %7.1f us min %7.1f us %6.1f TF | wgrad median %7.1f us min %7.1f %6.1f TF"
