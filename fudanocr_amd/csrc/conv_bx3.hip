@@ -297,10 +297,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_bx3_kernel(const float* __rest
 // fetched ONCE (the 64 x 64 kernel re-reads each operand once per tile of the other), twice the MFMA work per barrier
 // and a quarter of the atomics per pixel.  For layers with Cin % 128 == 0 and Cout % 128 == 0 (the transformer
 // linears): the k block stays inside one tap.
+// PART != nullptr: split z writes its tile into its own full-size slot PART[z][Cout][Ktot] with plain stores and
+// partial_sum_kernel folds the slots (no same-address atomics, which cost as much as the rest of this kernel).
 __global__ __launch_bounds__(256) void conv_wgrad_bx3_wide_kernel(const float* __restrict__ X,
                                                                   const float* __restrict__ dY, float* __restrict__ dW,
-                                                                  float* __restrict__ dbias, ConvGeomX g, int ldd,
-                                                                  int pix_per_split) {
+                                                                  float* __restrict__ dbias, float* __restrict__ PART,
+                                                                  ConvGeomX g, int ldd, int pix_per_split) {
   __shared__ __attribute__((aligned(16))) __bf16 Dth[128 * WTP], Dtl[128 * WTP], Xth[128 * WTP], Xtl[128 * WTP];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int k0 = blockIdx.x * 128, co0 = blockIdx.y * 128;
@@ -406,6 +408,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bx3_wide_kernel(const float* _
       atomicAdd(&dbias[co0 + tid], s2);
     }
   }
+  float* out = PART ? PART + (size_t)blockIdx.z * g.Cout * g.Ktot : dW;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -414,29 +417,71 @@ __global__ __launch_bounds__(256) void conv_wgrad_bx3_wide_kernel(const float* _
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int co = co0 + wi * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        atomicAdd(&dW[(size_t)co * g.Ktot + k], acc[a][b][r]);
+        if (PART) out[(size_t)co * g.Ktot + k] = acc[a][b][r];
+        else atomicAdd(&out[(size_t)co * g.Ktot + k], acc[a][b][r]);
       }
     }
+}
+
+// dst[i] += sum_s PART[s][i], i < n4 float4; grid.y groups of slots, one atomic per element and group
+#define PS_RG 8
+__global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restrict__ PART, float* __restrict__ dst,
+                                                          long n4, int nslots) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int s0 = (int)((long)nslots * blockIdx.y / PS_RG), s1 = (int)((long)nslots * (blockIdx.y + 1) / PS_RG);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+  for (int b = s0; b < s1; ++b) {
+    float4 v = reinterpret_cast<const float4*>(PART)[(size_t)b * n4 + i];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  float* o = dst + i * 4;
+  atomicAdd(o, s.x);
+  atomicAdd(o + 1, s.y);
+  atomicAdd(o + 2, s.z);
+  atomicAdd(o + 3, s.w);
 }
 
 #ifndef WGRADW_BLOCKS
 #define WGRADW_BLOCKS 512
 #endif
 
-int focr_conv_wgrad_bx3(const float* x, const float* dy, float* dw, float* dbias, int N, int H, int W, int Cin,
-                        int OH, int OW, int Cout, int KH, int KW, int padH, int padW, int M, int ldd, int ldx,
-                        int splits, int pps, hipStream_t stream) {
+static void wide_splits(int M, int Ktot, int Cout, int& sp, int& pp) {
+  const int tiles = (Ktot / 128) * (Cout / 128);
+  sp = WGRADW_BLOCKS / tiles;
+  const int maxsp = (M + 511) / 512;                 // >= 8 reduction chunks per block
+  if (sp > maxsp) sp = maxsp;
+  if (sp < 1) sp = 1;
+  pp = (((M + sp - 1) / sp + 63) / 64) * 64;
+  sp = (M + pp - 1) / pp;
+}
+// workspace floats of the partial-slot path of the 128 x 128 kernel (0: not applicable / too large to be worth it)
+long focr_conv_wgrad_bx3_ws_floats(int M, int Cin, int Cout, int Ktot) {
+  if (!(Cin % 128 == 0 && Cout % 128 == 0)) return 0;
+  int sp, pp;
+  wide_splits(M, Ktot, Cout, sp, pp);
+  const long n = (long)sp * Cout * Ktot;
+  // small weight matrices only (transformer linears): with MB-sized slots the extra write + read costs more than the
+  // atomics (measured on the 512 x 2304 CRNN layer: 162 -> 275 us)
+  return (sp > 1 && (long)Cout * Ktot <= 65536) ? n : 0;
+}
+
+int focr_conv_wgrad_bx3(const float* x, const float* dy, float* dw, float* dbias, float* ws, long ws_floats, int N,
+                        int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int padH, int padW, int M,
+                        int ldd, int ldx, int splits, int pps, hipStream_t stream) {
   ConvGeomX g{N, H, W, Cin, OH, OW, Cout, KH, KW, padH, padW, KH * KW * Cin, M, Cout, Cout, ldx};
   if (Cin % 128 == 0 && Cout % 128 == 0) {
-    const int tiles = (g.Ktot / 128) * (Cout / 128);
-    int sp = WGRADW_BLOCKS / tiles;
-    const int maxsp = (M + 511) / 512;                 // >= 8 reduction chunks per block
-    if (sp > maxsp) sp = maxsp;
-    if (sp < 1) sp = 1;
-    const int pp = (((M + sp - 1) / sp + 63) / 64) * 64;
-    sp = (M + pp - 1) / pp;
+    int sp, pp;
+    wide_splits(M, g.Ktot, Cout, sp, pp);
+    const long need = focr_conv_wgrad_bx3_ws_floats(M, Cin, Cout, g.Ktot);
+    float* part = (ws && need > 0 && ws_floats >= need) ? ws : nullptr;
     dim3 gridw(g.Ktot / 128, Cout / 128, sp);
-    hipLaunchKernelGGL(conv_wgrad_bx3_wide_kernel, gridw, 256, 0, stream, x, dy, dw, dbias, g, ldd, pp);
+    hipLaunchKernelGGL(conv_wgrad_bx3_wide_kernel, gridw, 256, 0, stream, x, dy, dw, dbias, part, g, ldd, pp);
+    if (part) {
+      const long n4 = (long)Cout * g.Ktot / 4;
+      hipLaunchKernelGGL(partial_sum_kernel, dim3((int)((n4 + 255) / 256), PS_RG), 256, 0, stream, part, dw, n4, sp);
+    }
     return 0;
   }
   dim3 grid(g.Ktot / 64, (Cout + 63) / 64, splits);

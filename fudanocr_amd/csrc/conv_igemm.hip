@@ -386,9 +386,10 @@ int focr_conv_fwd_bx3(const float* x, const float* w, const float* bias, const f
                       int N, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int padH, int padW,
                       int M, int ldy, int ldr, int ldx, float alpha, int relu, hipStream_t stream);
 
-int focr_conv_wgrad_bx3(const float* x, const float* dy, float* dw, float* dbias, int N, int H, int W, int Cin,
-                        int OH, int OW, int Cout, int KH, int KW, int padH, int padW, int M, int ldd, int ldx,
-                        int splits, int pps, hipStream_t stream);
+int focr_conv_wgrad_bx3(const float* x, const float* dy, float* dw, float* dbias, float* ws, long ws_floats, int N,
+                        int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int padH, int padW, int M,
+                        int ldd, int ldx, int splits, int pps, hipStream_t stream);
+long focr_conv_wgrad_bx3_ws_floats(int M, int Cin, int Cout, int Ktot);
 int focr_conv3x3_c64_wgrad(const float* x, const float* dy, float* dw, float* dbias, float* ws, long ws_floats, int N,
                            int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW, int ldd, int ldx,
                            hipStream_t stream);
@@ -434,7 +435,11 @@ extern "C" int focr_conv2d_fwd(const float* x, const float* w, const float* bias
 extern "C" long focr_conv2d_wgrad_ws_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int padH,
                                             int padW) {
   if (focr_get_precision() == 0) return 0;
-  return focr_conv3x3_c64_ws_floats(N, H, W, Cin, Cout, KH, KW, padH, padW);
+  long n = focr_conv3x3_c64_ws_floats(N, H, W, Cin, Cout, KH, KW, padH, padW);
+  if (n > 0) return n;
+  ConvGeom g;
+  if (fill_geom(g, N, H, W, Cin, Cout, KH, KW, padH, padW) != 0) return 0;
+  return focr_conv_wgrad_bx3_ws_floats(g.M, Cin, Cout, g.Ktot);
 }
 
 extern "C" int focr_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N,
@@ -474,8 +479,8 @@ extern "C" int focr_conv2d_wgrad(const float* x, const float* dy, float* dw, flo
     return FOCR_OK;
   }
   if (vec && focr_get_precision() != 0)
-    focr_conv_wgrad_bx3(x, dy, dw, dbias, N, H, W, Cin, g.OH, g.OW, Cout, KH, KW, padH, padW, g.M, ldd, g.ldx, splits,
-                        pps, stream);
+    focr_conv_wgrad_bx3(x, dy, dw, dbias, ws, ws_floats, N, H, W, Cin, g.OH, g.OW, Cout, KH, KW, padH, padW, g.M, ldd,
+                        g.ldx, splits, pps, stream);
   else if (vec)
     hipLaunchKernelGGL((conv_wgrad_kernel<true>), grid, 256, 0, stream, x, dy, dw, dbias, g, ldd, pps);
   else
