@@ -199,8 +199,9 @@ def main():
             # flop: executed_frac).  hbm_view: the same launches against HBM -- the roof that is actually closer
             # for these layers.
             "roofline": {"bound": "mfma",
-                         "kernel": ("conv_fwd_bx3_kernel" if bx3 else "conv_fwd_kernel") +
-                                   " (implicit-GEMM conv/linear, forward + data-gradient launches)",
+                         "kernel": ("conv_fwd_bx3_kernel / linear_stream_bx3_kernel" if bx3 else "conv_fwd_kernel") +
+                                   " (focr_conv2d_fwd: implicit-GEMM conv + streaming linear, forward and "
+                                   "data-gradient launches)",
                          "achieved": round(conv_tf, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(conv_tf / peak, 4), "traffic": traffic,
                          "executed_frac": round((3 if bx3 else 1) * conv_tf / peak, 4),

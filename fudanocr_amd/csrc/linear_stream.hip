@@ -1,0 +1,178 @@
+// Streaming 1x1 conv / Linear for short contractions (K = 64 or 128), bf16x3: the transformer linears of the TBSRN
+// FeatureEnhancer (tbsrn.py:74,91,109-130,162-163: Q/K/V/O projections, FFN, 128->64) and their data gradients.
+//
+// These layers are HBM-bound (read [M,K], write [M,N], M = B*1024 rows, a 64 KB weight matrix), but the tiled
+// implicit-GEMM kernel runs them at ~1.6x the streaming time: every block walks load -> barrier -> MFMA -> barrier
+// -> store in lockstep and re-stages the weights per 32-deep chunk.  Here
+//   * the block splits its [32*NT][K] weight slice to bf16 hi/lo ONCE and keeps it in LDS;
+//   * each wave independently streams 32-row tiles: the A fragments come straight from global memory in MFMA layout
+//     (the loads of the next tile are in flight while the current one is multiplied: K/16 * NT * 3 MFMAs), so the
+//     main loop has no barrier and no LDS traffic besides the weight fragments; two blocks (8 waves) per CU
+//     (a first version staged A through wave-private LDS tiles with one wave per SIMD: the exposed ds_read latency
+//     made it no faster than the tiled kernel);
+//   * epilogue (alpha, bias, residual, relu) as in conv_fwd_bx3_kernel.
+#include "focr_common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 lbf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 lbf16x4;
+
+__device__ __forceinline__ void lsplit4(float4 v, lbf16x4& hi, lbf16x4& lo) {
+  const float a[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    __bf16 h = (__bf16)a[e];
+    hi[e] = h;
+    lo[e] = (__bf16)(a[e] - (float)h);
+  }
+}
+
+__device__ __forceinline__ void lsplit8(const float4 a, const float4 b, lbf16x8& hi, lbf16x8& lo) {
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    __bf16 h = (__bf16)v[e];
+    hi[e] = h;
+    lo[e] = (__bf16)(v[e] - (float)h);
+  }
+}
+
+template <int K, int NT>
+__global__ __launch_bounds__(256, 2) void linear_stream_bx3_kernel(const float* __restrict__ X,
+                                                                   const float* __restrict__ Wt,   // [Cout][K]
+                                                                   const float* __restrict__ bias,
+                                                                   const float* __restrict__ R, float* __restrict__ Y,
+                                                                   int M, int Cout, int ldx, int ldy, int ldr,
+                                                                   float alpha, int relu) {
+  constexpr int KP = K + 8;            // bf16 pitch: conflict-free ds_read_b128 fragment reads
+  constexpr int Q = K / 4;             // float4 per weight row
+  constexpr int KS = K / 16;           // MFMA k-steps
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_ls[];
+  __bf16* Wh = reinterpret_cast<__bf16*>(smem_ls);         // [32*NT][KP]
+  __bf16* Wl = Wh + 32 * NT * KP;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.y * 32 * NT;
+  for (int i = tid; i < 32 * NT * Q; i += 256) {
+    const int row = i / Q, c4 = i - row * Q;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n0 + row < Cout) v = *reinterpret_cast<const float4*>(Wt + (size_t)(n0 + row) * K + 4 * c4);
+    lbf16x4 h, l;
+    lsplit4(v, h, l);
+    *reinterpret_cast<lbf16x4*>(&Wh[row * KP + 4 * c4]) = h;
+    *reinterpret_cast<lbf16x4*>(&Wl[row * KP + 4 * c4]) = l;
+  }
+  __syncthreads();
+  const int ntiles = (M + 31) / 32;
+  const int stride = gridDim.x * 4;
+  // A fragments straight from global in MFMA layout: lane (li, lh) owns row li, k = 16 s + 8 lh .. + 7 (32 bytes per
+  // k-step); the 2*KS loads of the NEXT tile are issued as one batch right after the current tile was split, so they
+  // cover each 512-byte row completely while its lines are still in the vector L1
+  float4 rg[2 * KS];
+#define LS_LOAD(T)                                                                              \
+  {                                                                                             \
+    const int p_ = (T) * 32 + li;                                                               \
+    const float* xp_ = X + (size_t)(p_ < M ? p_ : 0) * ldx + 8 * lh;                            \
+    _Pragma("unroll") for (int s_ = 0; s_ < KS; ++s_) {                                         \
+      rg[2 * s_] = *reinterpret_cast<const float4*>(xp_ + 16 * s_);                             \
+      rg[2 * s_ + 1] = *reinterpret_cast<const float4*>(xp_ + 16 * s_ + 4);                     \
+    }                                                                                           \
+  }
+  int t = blockIdx.x * 4 + wave;
+  if (t < ntiles) LS_LOAD(t)
+  float bv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int co = n0 + nt * 32 + li;
+    bv[nt] = (bias && co < Cout) ? bias[co] : 0.f;
+  }
+  for (; t < ntiles; t += stride) {
+    lbf16x8 ah[KS], al[KS];
+    const bool rowok = t * 32 + li < M;          // rows past the end were loaded from row 0: zero them
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      lsplit8(rowok ? rg[2 * s] : z4, rowok ? rg[2 * s + 1] : z4, ah[s], al[s]);
+    }
+    const int tn = t + stride;
+    if (tn < ntiles) LS_LOAD(tn)
+    // The weight fragments are the same for every tile: left alone, the compiler hoists all 2*NT*KS ds_reads out of
+    // the tile loop (256 VGPRs, spills).  An opaque per-iteration zero in the address keeps them inside.
+    int zofs;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zofs));
+    const __bf16* whp = Wh + zofs;
+    const __bf16* wlp = Wl + zofs;
+    // two column tiles at a time (32 accumulator registers live): the A fragments are reused for every pair
+#pragma unroll
+    for (int ng = 0; ng < NT; ng += 2) {
+      f32x16 acc[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          lbf16x8 bh = *reinterpret_cast<const lbf16x8*>(&whp[((ng + u) * 32 + li) * KP + 16 * s + 8 * lh]);
+          lbf16x8 bl = *reinterpret_cast<const lbf16x8*>(&wlp[((ng + u) * 32 + li) * KP + 16 * s + 8 * lh]);
+          acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bh, acc[u], 0, 0, 0);
+          acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bl, acc[u], 0, 0, 0);
+          acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], bh, acc[u], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int co = n0 + (ng + u) * 32 + li;
+        if (co >= Cout) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int p = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (p < M) {
+            float v = alpha * acc[u][r] + bv[ng + u];
+            if (R) v += R[(size_t)p * ldr + co];
+            if (relu) v = fmaxf(v, 0.f);
+            Y[(size_t)p * ldy + co] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int K, int NT>
+static int launch_ls(const float* x, const float* w, const float* bias, const float* r, float* y, int M, int Cout,
+                     int ldx, int ldy, int ldr, float alpha, int relu, hipStream_t stream) {
+  const size_t lds = (size_t)2 * 32 * NT * (K + 8) * sizeof(__bf16);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_stream_bx3_kernel<K, NT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return 0;
+    attr_set = true;
+  }
+  const int ny = cdiv(Cout, 32 * NT);
+  const int ntiles = cdiv(M, 32);
+  int nb = 2 * 256;                                    // two blocks (8 waves) per CU: launch_bounds(256, 2)
+  if (nb > cdiv(ntiles, 4)) nb = cdiv(ntiles, 4);
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL((linear_stream_bx3_kernel<K, NT>), dim3(nb, ny), 256, lds, stream, x, w, bias, r, y, M, Cout,
+                     ldx, ldy, ldr, alpha, relu);
+  return 1;
+}
+
+#ifndef LS_MIN_ROWS
+#define LS_MIN_ROWS 16384
+#endif
+
+// used by focr_conv2d_fwd (conv_igemm.hip) for 1x1 layers; returns 1 if the layer was handled here
+int focr_linear_stream_bx3(const float* x, const float* w, const float* bias, const float* residual, float* y, int M,
+                           int Cin, int Cout, int ldx, int ldy, int ldr, float alpha, int relu, hipStream_t stream) {
+  if (M < LS_MIN_ROWS || ldx % 4 || Cout % 32) return 0;
+  if (Cin == 128) {
+    if (Cout % 128 == 0) return launch_ls<128, 4>(x, w, bias, residual, y, M, Cout, ldx, ldy, ldr, alpha, relu, stream);
+    if (Cout % 64 == 0) return launch_ls<128, 2>(x, w, bias, residual, y, M, Cout, ldx, ldy, ldr, alpha, relu, stream);
+  } else if (Cin == 64) {
+    if (Cout % 128 == 0) return launch_ls<64, 4>(x, w, bias, residual, y, M, Cout, ldx, ldy, ldr, alpha, relu, stream);
+    if (Cout % 64 == 0) return launch_ls<64, 2>(x, w, bias, residual, y, M, Cout, ldx, ldy, ldr, alpha, relu, stream);
+  }
+  return 0;
+}

@@ -134,6 +134,29 @@ def test_linear(rows, nin, nout, alpha, precision):
     close(bd.grad, b.grad, 5e-5, what="linear db")
 
 
+@pytest.mark.parametrize("rows,nin,nout", [(20011, 128, 128), (16500, 128, 64), (16390, 64, 128), (17000, 128, 384),
+                                           (16384, 64, 64)])
+def test_linear_streaming(rows, nin, nout, precision):
+    """large-M short-K linears take the streaming kernel (linear_stream.hip) in the bf16x3 modes: ragged row count,
+    residual + alpha epilogue, data gradient through the same kernel on transposed weights.  (No relu here: with
+    millions of outputs some pre-activation lies within rounding distance of 0 and its mask bit legitimately flips.)"""
+    x = rnd(rows, nin, seed=1).requires_grad_(True)
+    wt = rnd(nout, nin, seed=2, scale=1 / math.sqrt(nin)).requires_grad_(True)
+    b = rnd(nout, seed=3).requires_grad_(True)
+    res = rnd(rows, nout, seed=5).requires_grad_(True)
+    y = (0.5 * x) @ wt.t() + b + res
+    gy = rnd(rows, nout, seed=4)
+    y.backward(gy)
+    xd, wd, bd, rd = (dev(t).requires_grad_(True) for t in (x, wt, b, res))
+    yd = K().linear(xd, wd, bd, residual=rd, alpha=0.5)
+    close(yd, y, ptol(precision), what="stream linear fwd")
+    yd.backward(dev(gy))
+    close(xd.grad, x.grad, ptol(precision), what="stream linear dx")
+    close(rd.grad, res.grad, ptol(precision), what="stream linear dres")
+    close(wd.grad, wt.grad, ptol(precision, 5e-5), what="stream linear dw")
+    close(bd.grad, b.grad, 5e-5, what="stream linear db")
+
+
 @pytest.mark.parametrize("b,t", [(2, 1024), (3, 256)])
 def test_attention(b, t, precision):
     q, k, v = (rnd(b, t, 128, seed=s, scale=2.0).requires_grad_(True) for s in (1, 2, 3))
