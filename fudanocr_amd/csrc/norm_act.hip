@@ -200,19 +200,45 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ sum_g, const float* __restrict__ sum_gx, float* __restrict__ dx, long total4,
     long rows, int C, int act) {
   const float inv_rows = 1.f / (float)rows;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
-       i += (long)gridDim.x * blockDim.x) {
-    int c = (int)((i * 4) % C);
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x, step = (long)gridDim.x * blockDim.x;
+  // the grid stride is a multiple of C (ew_grid() hands out multiples of 256 threads = 1024 floats): every thread
+  // keeps its four channels for the whole loop, so the per-channel coefficients are loaded once
+  //   xh = (x - mo)*is ; y = ga*xh + be ; g = dz*act'(y) ; dx = gi*(g - sg - xh*sgx)
+  const bool fixed_c = (step * 4) % C == 0;
+  int c = (int)((i0 * 4) % C);
+  float is[4], mo[4], ga[4], be[4], gi[4], sg[4], sgx[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    is[e] = invstd[c + e];
+    mo[e] = mean[c + e];
+    ga[e] = gamma[c + e];
+    be[e] = beta[c + e];
+    gi[e] = ga[e] * is[e];
+    sg[e] = sum_g ? sum_g[c + e] * inv_rows : 0.f;
+    sgx[e] = sum_g ? sum_gx[c + e] * inv_rows : 0.f;
+  }
+  for (long i = i0; i < total4; i += step) {
+    if (!fixed_c) {
+      c = (int)((i * 4) % C);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        is[e] = invstd[c + e];
+        mo[e] = mean[c + e];
+        ga[e] = gamma[c + e];
+        be[e] = beta[c + e];
+        gi[e] = ga[e] * is[e];
+        sg[e] = sum_g ? sum_g[c + e] * inv_rows : 0.f;
+        sgx[e] = sum_g ? sum_gx[c + e] * inv_rows : 0.f;
+      }
+    }
     float4 v = reinterpret_cast<const float4*>(x)[i];
     float4 d = reinterpret_cast<const float4*>(dz)[i];
     float vv[4] = {v.x, v.y, v.z, v.w}, dd[4] = {d.x, d.y, d.z, d.w}, oo[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float g_ = gamma[c + e], is = invstd[c + e];
-      float xh = (vv[e] - mean[c + e]) * is;
-      float g = dd[e] * act_grad(g_ * xh + beta[c + e], act);
-      if (sum_g) g = g - sum_g[c + e] * inv_rows - xh * sum_gx[c + e] * inv_rows;
-      oo[e] = g_ * is * g;
+      float xh = (vv[e] - mo[e]) * is[e];
+      float g = dd[e] * act_grad(ga[e] * xh + be[e], act);
+      oo[e] = gi[e] * (g - sg[e] - xh * sgx[e]);
     }
     reinterpret_cast<float4*>(dx)[i] = make_float4(oo[0], oo[1], oo[2], oo[3]);
   }
