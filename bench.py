@@ -116,7 +116,7 @@ def main():
     _lib.load()
     _lib.set_precision({"bf16x3": 2, "bf16x3-allsplit": 1, "fp32": 0}[args.precision])
     net, rec, crit = build_models(dev, args.arch)
-    step = TrainStep(net, crit, dropout=True)
+    step = TrainStep(net, crit, dropout=True, wgrad_side_stream=os.environ.get("FOCR_WGRAD_SIDE", "1") != "0")
     lr, hr, labels = make_batch(args.batch, 1234 + rank)
     lr, hr = lr.to(dev), hr.to(dev)
     enc = crit.encode(labels, dev)

@@ -107,12 +107,14 @@ class TrainStep:
     stream, so these collectives overlap the remaining backward kernels."""
 
     def __init__(self, model, crit, lr=1e-4, betas=(0.5, 0.999), max_norm=0.25, process_group=None,
-                 n_buckets=4, dropout=True, boundaries=("block3", "block6"), tail=("stn_head",)):
+                 wgrad_side_stream=True, n_buckets=4, dropout=True, boundaries=("block3", "block6"),
+                 tail=("stn_head",)):
         self.model, self.crit = model, crit
         self.dropout = dropout        # False: nn.Dropout slots stay in eval (parity runs)
         self.flat = FlatBuffers(list(model.parameters()))
         self.opt = FusedClipAdam(self.flat, lr, betas, 1e-8, max_norm)
         self.pg = process_group
+        self.wgrad_side_stream = bool(wgrad_side_stream)
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         n = self.flat.numel
         edges = [n * i // n_buckets // 4 * 4 for i in range(n_buckets)] + [n]
@@ -159,9 +161,10 @@ class TrainStep:
         view = self.flat.flat_grad[lo:hi]
         if self.comm_stream is not None:
             ev = torch.cuda.Event()
-            ev.record()                                    # gradients of this range are complete here
+            ev.record()                                    # gradients of this range are complete here ...
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
+                K.join_side_stream(self.comm_stream)       # ... once the side-stream weight gradients are in too
                 self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         else:
             self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
@@ -194,7 +197,17 @@ class TrainStep:
         self._works, self._sent = [], []
         sr = self.model(images_lr)
         loss, mse, _, ctc = self.crit(sr, images_hr, label_strs, encoded)
-        (loss * 100).backward()
+        on_gpu = self.flat.flat_grad.is_cuda
+        if on_gpu and self.wgrad_side_stream:
+            # the zeroed flat gradient must be visible to the side stream before its kernels accumulate into it
+            K._SIDE["enabled"] = True
+            K.side_stream().wait_stream(torch.cuda.current_stream())
+        try:
+            (loss * 100).backward()
+        finally:
+            K._SIDE["enabled"] = False
+        if on_gpu:
+            K.join_side_stream()                           # weight gradients complete before all-reduce / optimiser
         self.allreduce_grads()
         self.opt.step(self.world)
         return {"loss": loss.detach(), "mse": mse.detach(),

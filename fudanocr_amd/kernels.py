@@ -7,6 +7,7 @@ Convolution weights are `[Cout,Cin,KH,KW]` tensors held in channels_last memory 
 i.e. physically [Cout][KH][KW][Cin] -- exactly the K-contiguous operand the implicit-GEMM
 kernel wants, with the reference's state_dict shapes unchanged.
 """
+import contextlib
 import ctypes
 import math
 
@@ -63,6 +64,25 @@ def _new_seed():
 # ----------------------------------------------------------------------------------------
 # convolution / linear
 # ----------------------------------------------------------------------------------------
+# side stream for engine-owned weight gradients (see _Conv2d.backward); the engine enables it and joins it
+_SIDE = {"enabled": False, "stream": None, "used": False}
+
+
+def side_stream():
+    if not _SIDE["enabled"]:
+        return None
+    if _SIDE["stream"] is None:
+        _SIDE["stream"] = torch.cuda.Stream()
+    _SIDE["used"] = True
+    return _SIDE["stream"]
+
+
+def join_side_stream(stream=None):
+    """make `stream` (default: current) wait for everything queued on the weight-gradient side stream"""
+    if _SIDE["used"] and _SIDE["stream"] is not None:
+        (stream or torch.cuda.current_stream()).wait_stream(_SIDE["stream"])
+
+
 def _is_out_layer(cin, cout, kh, kw, ph, pw, w, residual, alpha, relu):
     """SR output layer shape handled by csrc/conv9x9_out.hip (taps folded into the MFMA N dim)."""
     return (kh == 9 and kw == 9 and ph == 4 and pw == 4 and cin == 64 and cout <= 3 and w % 32 == 0
@@ -122,11 +142,6 @@ class _Conv2d(torch.autograd.Function):
         dres = dy4.reshape(dy.shape) if has_res else None
         wk = _ohwi(weight)
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            wd = torch.empty(wk.numel(), device=dy.device, dtype=torch.float32)
-            _lib.call("focr_weight_flip_transpose", _p(wk), _p(wd), cout, kh, kw, cin, _stream())
-            dx4 = _conv_fwd_raw(dy4, wd, None, None, cin, kh, kw, kh - 1 - ph, kw - 1 - pw, alpha, False)
-            dx = dx4 if len(ctx.x_shape) == 4 else dx4.reshape(ctx.x_shape)
         tw, tb = ctx.targets
         if ctx.needs_input_grad[1]:
             if tw is not None:
@@ -140,16 +155,34 @@ class _Conv2d(torch.autograd.Function):
                 db = tb if tb is not None else torch.empty(cout, device=dy.device, dtype=torch.float32)
             # targets handed out by the engine are slices of the flat gradient buffer, zeroed once per step
             pz = int(tw is not None and (db is None or tb is not None))
-            if _is_out_layer(cin, cout, kh, kw, ph, pw, w, None, alpha, relu) and not has_res:
-                _lib.call("focr_conv9x9_small_cout_wgrad", _p(x4), _p(dy4), _p(dw), _p(db), n, h, w, cin,
-                          cout, pz, _stream())
-            else:
-                nws = _lib.load().focr_conv2d_wgrad_ws_floats(n, h, w, cin, cout, kh, kw, ph, pw)
-                ws = torch.empty(nws, device=dy.device, dtype=torch.float32) if nws > 0 else None
-                _lib.call("focr_conv2d_wgrad", _p(x4), _p(dy4), _p(dw), _p(db), n, h, w, cin, cout, kh, kw,
-                          ph, pw, 0, 0, pz, _p(ws), nws, _stream())
-            if alpha != 1.0:
-                _lib.call("focr_axpy", _p(dw), _NULL, _p(dw), dw.numel(), alpha, _stream())
+            # Weight gradients that land in the engine's flat buffer feed nothing inside backward: they run on the
+            # side stream, concurrently with the data-gradient chain on the main stream (both kinds of kernels are
+            # latency/occupancy bound, not throughput bound).  The engine joins the streams before the optimiser.
+            side = side_stream() if (tw is not None and (db is None or tb is not None)) else None
+            if side is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                side.wait_event(ev)
+                x4.record_stream(side)
+                dy4.record_stream(side)
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                if _is_out_layer(cin, cout, kh, kw, ph, pw, w, None, alpha, relu) and not has_res:
+                    _lib.call("focr_conv9x9_small_cout_wgrad", _p(x4), _p(dy4), _p(dw), _p(db), n, h, w, cin,
+                              cout, pz, _stream())
+                else:
+                    nws = _lib.load().focr_conv2d_wgrad_ws_floats(n, h, w, cin, cout, kh, kw, ph, pw)
+                    ws = torch.empty(nws, device=dy.device, dtype=torch.float32) if nws > 0 else None
+                    _lib.call("focr_conv2d_wgrad", _p(x4), _p(dy4), _p(dw), _p(db), n, h, w, cin, cout, kh, kw,
+                              ph, pw, 0, 0, pz, _p(ws), nws, _stream())
+                if alpha != 1.0:
+                    _lib.call("focr_axpy", _p(dw), _NULL, _p(dw), dw.numel(), alpha, _stream())
+        if ctx.needs_input_grad[0]:
+            wd = torch.empty(wk.numel(), device=dy.device, dtype=torch.float32)
+            _lib.call("focr_weight_flip_transpose", _p(wk), _p(wd), cout, kh, kw, cin, _stream())
+            dx4 = _conv_fwd_raw(dy4, wd, None, None, cin, kh, kw, kh - 1 - ph, kw - 1 - pw, alpha, False)
+            dx = dx4 if len(ctx.x_shape) == 4 else dx4.reshape(ctx.x_shape)
+        if ctx.needs_input_grad[1]:
+            pass
         elif has_bias and ctx.needs_input_grad[2]:
             db = tb if tb is not None else torch.empty(cout, device=dy.device, dtype=torch.float32)
             _lib.call("focr_colsum", _p(dy4), _p(db), dy4.numel() // cout, cout, cout, _stream())
