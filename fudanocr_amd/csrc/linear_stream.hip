@@ -36,7 +36,7 @@ __device__ __forceinline__ void lsplit8(const float4 a, const float4 b, lbf16x8&
   }
 }
 
-template <int K, int NT>
+template <int K, int NT, bool HAS_RES>
 __global__ __launch_bounds__(256, 2) void linear_stream_bx3_kernel(const float* __restrict__ X,
                                                                    const float* __restrict__ Wt,   // [Cout][K]
                                                                    const float* __restrict__ bias,
@@ -108,6 +108,19 @@ __global__ __launch_bounds__(256, 2) void linear_stream_bx3_kernel(const float* 
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+      // residual values of this column pair: in flight during the MFMAs instead of exposed in the epilogue
+      float rv[2][16];
+      if (HAS_RES) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int co = n0 + (ng + u) * 32 + li;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int p = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            rv[u][r] = (p < M && co < Cout) ? R[(size_t)p * ldr + co] : 0.f;
+          }
+        }
+      }
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
 #pragma unroll
@@ -128,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void linear_stream_bx3_kernel(const float* 
           const int p = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           if (p < M) {
             float v = alpha * acc[u][r] + bv[ng + u];
-            if (R) v += R[(size_t)p * ldr + co];
+            if (HAS_RES) v += rv[u][r];
             if (relu) v = fmaxf(v, 0.f);
             Y[(size_t)p * ldy + co] = v;
           }
@@ -138,13 +151,13 @@ __global__ __launch_bounds__(256, 2) void linear_stream_bx3_kernel(const float* 
   }
 }
 
-template <int K, int NT>
-static int launch_ls(const float* x, const float* w, const float* bias, const float* r, float* y, int M, int Cout,
+template <int K, int NT, bool HAS_RES>
+static int launch_ls_(const float* x, const float* w, const float* bias, const float* r, float* y, int M, int Cout,
                      int ldx, int ldy, int ldr, float alpha, int relu, hipStream_t stream) {
   const size_t lds = (size_t)2 * 32 * NT * (K + 8) * sizeof(__bf16);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_stream_bx3_kernel<K, NT>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_stream_bx3_kernel<K, NT, HAS_RES>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return 0;
     attr_set = true;
@@ -154,9 +167,16 @@ static int launch_ls(const float* x, const float* w, const float* bias, const fl
   int nb = 2 * 256;                                    // two blocks (8 waves) per CU: launch_bounds(256, 2)
   if (nb > cdiv(ntiles, 4)) nb = cdiv(ntiles, 4);
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL((linear_stream_bx3_kernel<K, NT>), dim3(nb, ny), 256, lds, stream, x, w, bias, r, y, M, Cout,
+  hipLaunchKernelGGL((linear_stream_bx3_kernel<K, NT, HAS_RES>), dim3(nb, ny), 256, lds, stream, x, w, bias, r, y, M, Cout,
                      ldx, ldy, ldr, alpha, relu);
   return 1;
+}
+
+template <int K, int NT>
+static int launch_ls(const float* x, const float* w, const float* bias, const float* r, float* y, int M, int Cout,
+                     int ldx, int ldy, int ldr, float alpha, int relu, hipStream_t stream) {
+  return r ? launch_ls_<K, NT, true>(x, w, bias, r, y, M, Cout, ldx, ldy, ldr, alpha, relu, stream)
+           : launch_ls_<K, NT, false>(x, w, bias, r, y, M, Cout, ldx, ldy, ldr, alpha, relu, stream);
 }
 
 #ifndef LS_MIN_ROWS
