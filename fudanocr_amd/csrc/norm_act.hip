@@ -95,14 +95,61 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) *reinterpret_cast<float4*>(out + c4 * 4) = red[0];
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sq,
-                                   float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                   float* __restrict__ rmean, float* __restrict__ rvar,
-                                   long long* nbt, long rows, int C, float momentum, float eps) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < C) {
+// fold of two partial arrays in one launch (backward: dbeta and dgamma): blockIdx.y selects the array
+__global__ __launch_bounds__(256) void bn_fold2_kernel(const float* __restrict__ pa, float* __restrict__ oa,
+                                                       const float* __restrict__ pb, float* __restrict__ ob,
+                                                       int slabs, int C) {
+  __shared__ float4 red[256];
+  const float* part = blockIdx.y ? pb : pa;
+  float* out = blockIdx.y ? ob : oa;
+  const int c4 = blockIdx.x;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j = threadIdx.x; j < slabs; j += 256) {
+    float4 v = *reinterpret_cast<const float4*>(part + (size_t)j * C + c4 * 4);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+#pragma unroll
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) {
+      float4 a = red[threadIdx.x], b = red[threadIdx.x + w];
+      red[threadIdx.x] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *reinterpret_cast<float4*>(out + c4 * 4) = red[0];
+}
+
+// fold of the centred sum-of-squares partials (same tree as bn_fold_kernel) + the finalize step, one launch
+__global__ __launch_bounds__(256) void bn_fold_finalize_kernel(
+    const float* __restrict__ part, const float* __restrict__ sum, float* __restrict__ sq,
+    float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ rmean,
+    float* __restrict__ rvar, long long* nbt, long rows, int slabs, int C, float momentum, float eps) {
+  __shared__ float4 red[256];
+  const int c4 = blockIdx.x;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j = threadIdx.x; j < slabs; j += 256) {
+    float4 v = *reinterpret_cast<const float4*>(part + (size_t)j * C + c4 * 4);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+#pragma unroll
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) {
+      float4 a = red[threadIdx.x], b = red[threadIdx.x + w];
+      red[threadIdx.x] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) {
+    const int c = c4 * 4 + threadIdx.x;
+    const float4 r = red[0];
+    const float q = threadIdx.x == 0 ? r.x : threadIdx.x == 1 ? r.y : threadIdx.x == 2 ? r.z : r.w;
+    sq[c] = q;
     float mean = sum[c] / (float)rows;
-    float var = sq[c] / (float)rows;
+    float var = q / (float)rows;
     save_mean[c] = mean;
     save_invstd[c] = rsqrtf(var + eps);
     if (rmean) {
@@ -110,9 +157,10 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* _
       rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
       rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
     }
+    if (c == 0 && nbt) *nbt += 1;
   }
-  if (c == 0 && nbt) *nbt += 1;
 }
+
 
 // y = act(gamma * (x - mean) * invstd + beta) + residual       (total = rows*C elements)
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x,
@@ -581,9 +629,8 @@ extern "C" int focr_bn_train_fwd(const float* x, const float* gamma, const float
   hipLaunchKernelGGL(bn_colstat_kernel, g, 256, 0, stream, x, (const float*)nullptr, part, rows, C, 0);
   hipLaunchKernelGGL(bn_fold_kernel, dim3(C / 4), 256, 0, stream, (const float*)part, sum, slabs, C);
   hipLaunchKernelGGL(bn_colstat_kernel, g, 256, 0, stream, x, (const float*)sum, part, rows, C, 1);
-  hipLaunchKernelGGL(bn_fold_kernel, dim3(C / 4), 256, 0, stream, (const float*)part, sq, slabs, C);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), 64, 0, stream, (const float*)sum, (const float*)sq,
-                     save_mean, save_invstd, running_mean, running_var, nbt, rows, C, momentum, eps);
+  hipLaunchKernelGGL(bn_fold_finalize_kernel, dim3(C / 4), 256, 0, stream, (const float*)part, (const float*)sum, sq,
+                     save_mean, save_invstd, running_mean, running_var, nbt, rows, slabs, C, momentum, eps);
   long total4 = rows * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total4)), 256, 0, stream, x, gamma, beta,
                      (const float*)save_mean, (const float*)save_invstd, residual, y, total4, C, act);
@@ -631,8 +678,8 @@ extern "C" int focr_bn_bwd(const float* dz, const float* x, const float* gamma, 
     float* pgx = ws + (size_t)slabs * C;  // [slabs][C]
     dim3 g(cdiv(C, 1024), slabs);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, g, 256, 0, stream, dz, x, gamma, beta, mean, invstd, pg, pgx, rows, C, act);
-    hipLaunchKernelGGL(bn_fold_kernel, dim3(C / 4), 256, 0, stream, (const float*)pg, dbeta, slabs, C);
-    hipLaunchKernelGGL(bn_fold_kernel, dim3(C / 4), 256, 0, stream, (const float*)pgx, dgamma, slabs, C);
+    hipLaunchKernelGGL(bn_fold2_kernel, dim3(C / 4, 2), 256, 0, stream, (const float*)pg, dbeta, (const float*)pgx,
+                       dgamma, slabs, C);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), 256, 0, stream, dz, x, gamma, beta, mean,
                        invstd, (const float*)dbeta, (const float*)dgamma, dx, total4, rows, C, act);
   } else {
