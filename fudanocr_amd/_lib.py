@@ -40,6 +40,8 @@ SIGNATURES = {
     "focr_mse_bwd": [P, P, P, P, L, P],
     "focr_axpy": [P, P, P, L, F, P],
     "focr_relu_bwd": [P, P, P, L, P],
+    "focr_relu_bwd_scaled": [P, P, P, L, F, P],
+    "focr_linear_relu_dropout_fwd": [P, P, P, P, L, I, I, F, F, U, P, P],
     "focr_maxpool_fwd": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "focr_maxpool_bwd": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "focr_tps_fwd": [P, P, P, P, P, P, I, I, I, I, I, P],

@@ -396,7 +396,9 @@ int focr_conv3x3_c64_wgrad(const float* x, const float* dy, float* dw, float* db
 long focr_conv3x3_c64_ws_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW);
 
 int focr_linear_stream_bx3(const float* x, const float* w, const float* bias, const float* residual, float* y, int M,
-                           int Cin, int Cout, int ldx, int ldy, int ldr, float alpha, int relu, hipStream_t stream);
+                           int Cin, int Cout, int ldx, int ldy, int ldr, float alpha, int relu, uint32_t drop_k,
+                           float drop_scale, uint32_t drop_seed, hipStream_t stream);
+extern "C" int focr_dropout(const float* x, float* y, long n, float p, uint64_t seed, hipStream_t stream);
 
 extern "C" int focr_conv2d_fwd(const float* x, const float* w, const float* bias,
                                const float* residual, float* y, int N, int H, int W, int Cin,
@@ -411,7 +413,8 @@ extern "C" int focr_conv2d_fwd(const float* x, const float* w, const float* bias
   FOCR_CHECK_ARG(g.ldy >= Cout && g.ldr >= Cout && g.ldx >= Cin, "row pitch too small");
   bool vec = (Cin % BK == 0) && (g.ldx % 4 == 0);
   if (vec && focr_get_precision() != 0 && KH == 1 && KW == 1 && padH == 0 && padW == 0 &&
-      focr_linear_stream_bx3(x, w, bias, residual, y, g.M, Cin, Cout, g.ldx, g.ldy, g.ldr, alpha, relu, stream)) {
+      focr_linear_stream_bx3(x, w, bias, residual, y, g.M, Cin, Cout, g.ldx, g.ldy, g.ldr, alpha, relu, 0u, 1.f, 0u,
+                             stream)) {
     FOCR_LAUNCH_CHECK();
     return FOCR_OK;
   }
@@ -433,6 +436,29 @@ extern "C" int focr_conv2d_fwd(const float* x, const float* w, const float* bias
     hipLaunchKernelGGL((conv_fwd_kernel<1, false>), grid, 256, 0, stream, x, w, bias, residual, y, g, alpha, relu);
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
+}
+
+// y = Dropout_p(relu(alpha * x W^T + b)) for a Linear (rows x Cin -> rows x Cout), the FFN front half
+// (PositionwiseFeedForward, tbsrn.py:162-163).  P(keep) is quantised to 1/65536; *keep_scale receives 1/P(keep),
+// the factor relu_bwd_scaled needs (dropped elements are exactly the zeros of y, so the backward needs no mask).
+// Fused into the streaming kernel's epilogue when the layer qualifies, otherwise linear + in-place dropout.
+extern "C" int focr_linear_relu_dropout_fwd(const float* x, const float* w, const float* bias, float* y, long rows,
+                                            int Cin, int Cout, float alpha, float p_drop, uint64_t seed,
+                                            float* keep_scale, hipStream_t stream) {
+  FOCR_CHECK_ARG(x && w && y && rows > 0 && Cin > 0 && Cout > 0 && keep_scale, "bad argument");
+  FOCR_CHECK_ARG(p_drop > 0.f && p_drop < 1.f, "bad dropout probability");
+  const uint32_t kq = 65536u - (uint32_t)(p_drop * 65536.0f + 0.5f);
+  FOCR_CHECK_ARG(kq > 0u, "dropout probability rounds to 1");
+  *keep_scale = 65536.f / (float)kq;
+  if (focr_get_precision() != 0 && rows < (1l << 31) &&
+      focr_linear_stream_bx3(x, w, bias, nullptr, y, (int)rows, Cin, Cout, Cin, Cout, Cout, alpha, 1, kq, *keep_scale,
+                             (uint32_t)(seed ^ (seed >> 32)), stream)) {
+    FOCR_LAUNCH_CHECK();
+    return FOCR_OK;
+  }
+  int rc = focr_conv2d_fwd(x, w, bias, nullptr, y, (int)rows, 1, 1, Cin, Cout, 1, 1, 0, 0, alpha, 1, 0, 0, 0, stream);
+  if (rc != FOCR_OK) return rc;
+  return focr_dropout(y, y, rows * Cout, 1.f - (float)kq / 65536.f, seed, stream);
 }
 
 // dw must hold Cout*KH*KW*Cin floats, dbias (nullable) Cout floats.  The kernel ACCUMULATES with fp32

@@ -36,13 +36,14 @@ __device__ __forceinline__ void lsplit8(const float4 a, const float4 b, lbf16x8&
   }
 }
 
-template <int K, int NT, bool HAS_RES>
+template <int K, int NT, bool HAS_RES, bool HAS_DROP>
 __global__ __launch_bounds__(256, 2) void linear_stream_bx3_kernel(const float* __restrict__ X,
                                                                    const float* __restrict__ Wt,   // [Cout][K]
                                                                    const float* __restrict__ bias,
                                                                    const float* __restrict__ R, float* __restrict__ Y,
                                                                    int M, int Cout, int ldx, int ldy, int ldr,
-                                                                   float alpha, int relu) {
+                                                                   float alpha, int relu, uint32_t drop_k,
+                                                                   float drop_scale, uint32_t drop_seed) {
   constexpr int KP = K + 8;            // bf16 pitch: conflict-free ds_read_b128 fragment reads
   constexpr int Q = K / 4;             // float4 per weight row
   constexpr int KS = K / 16;           // MFMA k-steps
@@ -132,6 +133,20 @@ __global__ __launch_bounds__(256, 2) void linear_stream_bx3_kernel(const float* 
           acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], bh, acc[u], 0, 0, 0);
         }
       }
+      // fused dropout (FFN: Dropout(relu(w_1 x)), tbsrn.py:162-163): 32 Bernoulli keep bits per lane and column pair,
+      // bit-sliced from a xorshift stream (P(keep) = drop_k / 65536).  The backward never needs these bits: a dropped
+      // element IS a zero of y, so relu_bwd_scaled on (y > 0) with scale 1/P(keep) is exact.
+      uint32_t keep = 0xffffffffu;
+      if (HAS_DROP) {
+        uint32_t x = hash32(drop_seed ^ hash32((uint32_t)(t * (NT / 2) + (ng >> 1)) * 0x9E3779B1U + blockIdx.y) ^
+                            (uint32_t)lane * 0x85EBCA6BU) | 1u;
+        keep = 0u;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+          x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+          keep = ((drop_k >> b) & 1u) ? (keep | x) : (keep & x);
+        }
+      }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int co = n0 + (ng + u) * 32 + li;
@@ -143,6 +158,7 @@ __global__ __launch_bounds__(256, 2) void linear_stream_bx3_kernel(const float* 
             float v = alpha * acc[u][r] + bv[ng + u];
             if (HAS_RES) v += rv[u][r];
             if (relu) v = fmaxf(v, 0.f);
+            if (HAS_DROP) v = ((keep >> (u * 16 + r)) & 1u) ? v * drop_scale : 0.f;
             Y[(size_t)p * ldy + co] = v;
           }
         }
@@ -151,13 +167,14 @@ __global__ __launch_bounds__(256, 2) void linear_stream_bx3_kernel(const float* 
   }
 }
 
-template <int K, int NT, bool HAS_RES>
+template <int K, int NT, bool HAS_RES, bool HAS_DROP>
 static int launch_ls_(const float* x, const float* w, const float* bias, const float* r, float* y, int M, int Cout,
-                     int ldx, int ldy, int ldr, float alpha, int relu, hipStream_t stream) {
+                      int ldx, int ldy, int ldr, float alpha, int relu, uint32_t drop_k, float drop_scale,
+                      uint32_t drop_seed, hipStream_t stream) {
   const size_t lds = (size_t)2 * 32 * NT * (K + 8) * sizeof(__bf16);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_stream_bx3_kernel<K, NT, HAS_RES>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_stream_bx3_kernel<K, NT, HAS_RES, HAS_DROP>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return 0;
     attr_set = true;
@@ -167,16 +184,22 @@ static int launch_ls_(const float* x, const float* w, const float* bias, const f
   int nb = 2 * 256;                                    // two blocks (8 waves) per CU: launch_bounds(256, 2)
   if (nb > cdiv(ntiles, 4)) nb = cdiv(ntiles, 4);
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL((linear_stream_bx3_kernel<K, NT, HAS_RES>), dim3(nb, ny), 256, lds, stream, x, w, bias, r, y, M, Cout,
-                     ldx, ldy, ldr, alpha, relu);
+  hipLaunchKernelGGL((linear_stream_bx3_kernel<K, NT, HAS_RES, HAS_DROP>), dim3(nb, ny), 256, lds, stream, x, w, bias,
+                     r, y, M, Cout, ldx, ldy, ldr, alpha, relu, drop_k, drop_scale, drop_seed);
   return 1;
 }
 
 template <int K, int NT>
 static int launch_ls(const float* x, const float* w, const float* bias, const float* r, float* y, int M, int Cout,
-                     int ldx, int ldy, int ldr, float alpha, int relu, hipStream_t stream) {
-  return r ? launch_ls_<K, NT, true>(x, w, bias, r, y, M, Cout, ldx, ldy, ldr, alpha, relu, stream)
-           : launch_ls_<K, NT, false>(x, w, bias, r, y, M, Cout, ldx, ldy, ldr, alpha, relu, stream);
+                     int ldx, int ldy, int ldr, float alpha, int relu, uint32_t drop_k, float drop_scale,
+                     uint32_t drop_seed, hipStream_t stream) {
+  if (drop_k) {
+    if (r) return 0;                                   // dropout + residual: not built
+    return launch_ls_<K, NT, false, true>(x, w, bias, r, y, M, Cout, ldx, ldy, ldr, alpha, relu, drop_k, drop_scale,
+                                          drop_seed, stream);
+  }
+  return r ? launch_ls_<K, NT, true, false>(x, w, bias, r, y, M, Cout, ldx, ldy, ldr, alpha, relu, 0u, 1.f, 0u, stream)
+           : launch_ls_<K, NT, false, false>(x, w, bias, r, y, M, Cout, ldx, ldy, ldr, alpha, relu, 0u, 1.f, 0u, stream);
 }
 
 #ifndef LS_MIN_ROWS
@@ -185,14 +208,19 @@ static int launch_ls(const float* x, const float* w, const float* bias, const fl
 
 // used by focr_conv2d_fwd (conv_igemm.hip) for 1x1 layers; returns 1 if the layer was handled here
 int focr_linear_stream_bx3(const float* x, const float* w, const float* bias, const float* residual, float* y, int M,
-                           int Cin, int Cout, int ldx, int ldy, int ldr, float alpha, int relu, hipStream_t stream) {
+                           int Cin, int Cout, int ldx, int ldy, int ldr, float alpha, int relu, uint32_t drop_k,
+                           float drop_scale, uint32_t drop_seed, hipStream_t stream) {
   if (M < LS_MIN_ROWS || ldx % 4 || Cout % 32) return 0;
   if (Cin == 128) {
-    if (Cout % 128 == 0) return launch_ls<128, 4>(x, w, bias, residual, y, M, Cout, ldx, ldy, ldr, alpha, relu, stream);
-    if (Cout % 64 == 0) return launch_ls<128, 2>(x, w, bias, residual, y, M, Cout, ldx, ldy, ldr, alpha, relu, stream);
+    if (Cout % 128 == 0) return launch_ls<128, 4>(x, w, bias, residual, y, M, Cout, ldx, ldy, ldr, alpha, relu, drop_k, drop_scale,
+                                                 drop_seed, stream);
+    if (Cout % 64 == 0) return launch_ls<128, 2>(x, w, bias, residual, y, M, Cout, ldx, ldy, ldr, alpha, relu, drop_k, drop_scale,
+                                                 drop_seed, stream);
   } else if (Cin == 64) {
-    if (Cout % 128 == 0) return launch_ls<64, 4>(x, w, bias, residual, y, M, Cout, ldx, ldy, ldr, alpha, relu, stream);
-    if (Cout % 64 == 0) return launch_ls<64, 2>(x, w, bias, residual, y, M, Cout, ldx, ldy, ldr, alpha, relu, stream);
+    if (Cout % 128 == 0) return launch_ls<64, 4>(x, w, bias, residual, y, M, Cout, ldx, ldy, ldr, alpha, relu, drop_k, drop_scale,
+                                                 drop_seed, stream);
+    if (Cout % 64 == 0) return launch_ls<64, 2>(x, w, bias, residual, y, M, Cout, ldx, ldy, ldr, alpha, relu, drop_k, drop_scale,
+                                                 drop_seed, stream);
   }
   return 0;
 }

@@ -831,6 +831,19 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     dx[i] = y[i] > 0.f ? dy[i] : 0.f;
 }
+// dx = scale * dy * (y > 0): backward of relu followed by a fused dropout whose kept elements were scaled by `scale`
+__global__ __launch_bounds__(256) void relu_bwd_scaled_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                              float* __restrict__ dx, long n, float scale) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dx[i] = y[i] > 0.f ? dy[i] * scale : 0.f;
+}
+extern "C" int focr_relu_bwd_scaled(const float* dy, const float* y, float* dx, long n, float scale,
+                                    hipStream_t stream) {
+  FOCR_CHECK_ARG(dy && y && dx && n > 0, "bad argument");
+  hipLaunchKernelGGL(relu_bwd_scaled_kernel, dim3(ew_grid(n)), 256, 0, stream, dy, y, dx, n, scale);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
 extern "C" int focr_relu_bwd(const float* dy, const float* y, float* dx, long n, hipStream_t stream) {
   FOCR_CHECK_ARG(dy && y && dx && n > 0, "bad argument");
   hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n)), 256, 0, stream, dy, y, dx, n);

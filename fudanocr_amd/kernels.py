@@ -107,7 +107,7 @@ class _Conv2d(torch.autograd.Function):
     nn.Linear call sites listed in csrc/conv_igemm.hip."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, pad, alpha, relu):
+    def forward(ctx, x, weight, bias, residual, pad, alpha, relu, drop_p=0.0):
         cout = weight.shape[0]
         if weight.dim() == 2:
             kh = kw = 1
@@ -121,7 +121,19 @@ class _Conv2d(torch.autograd.Function):
         res4 = None if residual is None else residual.reshape(-1, cout)
         wk = _ohwi(weight)
         _chk(x4, wk, bias, res4)
-        y = _conv_fwd_raw(x4, wk, bias, res4, cout, kh, kw, ph, pw, alpha, relu)
+        ctx.drop_scale = 0.0
+        if drop_p > 0.0:
+            # Dropout(relu(linear)) with the dropout fused into the GEMM epilogue (FFN, tbsrn.py:162-163)
+            if not (relu and residual is None and kh == 1 and kw == 1):
+                raise RuntimeError("fused dropout is only defined for relu(linear(x)) without residual")
+            rows = x4.shape[0] * x4.shape[1] * x4.shape[2]
+            y = torch.empty((x4.shape[0], x4.shape[1], x4.shape[2], cout), device=x4.device, dtype=torch.float32)
+            ks = ctypes.c_float(0.0)
+            _lib.call("focr_linear_relu_dropout_fwd", _p(x4), _p(wk), _p(bias), _p(y), rows, x4.shape[3], cout,
+                      float(alpha), float(drop_p), _new_seed(), ctypes.byref(ks), _stream())
+            ctx.drop_scale = float(ks.value)
+        else:
+            y = _conv_fwd_raw(x4, wk, bias, res4, cout, kh, kw, ph, pw, alpha, relu)
         ctx.geom = (kh, kw, ph, pw, float(alpha), bool(relu), bias is not None, residual is not None)
         ctx.targets = (_target(weight), _target(bias))
         ctx.save_for_backward(x4, weight, y if relu else None)
@@ -137,7 +149,10 @@ class _Conv2d(torch.autograd.Function):
         dy4 = dy.contiguous().reshape(n, oh, ow, cout)
         if relu:
             g = torch.empty_like(dy4)
-            _lib.call("focr_relu_bwd", _p(dy4), _p(y), _p(g), dy4.numel(), _stream())
+            if ctx.drop_scale:        # relu + fused dropout: the dropped elements are the zeros of y
+                _lib.call("focr_relu_bwd_scaled", _p(dy4), _p(y), _p(g), dy4.numel(), ctx.drop_scale, _stream())
+            else:
+                _lib.call("focr_relu_bwd", _p(dy4), _p(y), _p(g), dy4.numel(), _stream())
             dy4 = g
         dres = dy4.reshape(dy.shape) if has_res else None
         wk = _ohwi(weight)
@@ -190,16 +205,16 @@ class _Conv2d(torch.autograd.Function):
             dw = None
         if tb is not None:
             db = None
-        return dx, dw, db, dres, None, None, None
+        return dx, dw, db, dres, None, None, None, None
 
 
 def conv2d(x, weight, bias=None, pad=(0, 0), residual=None, alpha=1.0, relu=False):
     return _Conv2d.apply(x, weight, bias, residual, pad, alpha, relu)
 
 
-def linear(x, weight, bias=None, residual=None, alpha=1.0, relu=False):
-    """x [..., In] @ weight[Out, In]^T (+bias) (+residual) -- the same implicit-GEMM kernel."""
-    return _Conv2d.apply(x, weight, bias, residual, (0, 0), alpha, relu)
+def linear(x, weight, bias=None, residual=None, alpha=1.0, relu=False, dropout=0.0):
+    """x [..., In] @ weight[Out, In]^T (+bias) (+residual) (relu) (dropout with probability `dropout`, relu only)."""
+    return _Conv2d.apply(x, weight, bias, residual, (0, 0), alpha, relu, float(dropout))
 
 
 # ----------------------------------------------------------------------------------------

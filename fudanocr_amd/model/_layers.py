@@ -27,8 +27,8 @@ class Conv2d(nn.Conv2d):
 
 
 class Linear(nn.Linear):
-    def forward(self, x, residual=None, relu=False, alpha=1.0):
-        return K.linear(x, self.weight, self.bias, residual=residual, relu=relu, alpha=alpha)
+    def forward(self, x, residual=None, relu=False, alpha=1.0, dropout=0.0):
+        return K.linear(x, self.weight, self.bias, residual=residual, relu=relu, alpha=alpha, dropout=dropout)
 
 
 class _BNMixin:

@@ -81,9 +81,9 @@ class PositionwiseFeedForward(nn.Module):
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, x):
-        h = self.w_1(x, relu=True)
-        h = K.dropout(h, self.dropout.p, self.dropout.training)
-        return self.w_2(h)
+        # Dropout(relu(w_1 x)) in one kernel: the dropout is part of the GEMM epilogue (and of its relu backward)
+        p = self.dropout.p if self.dropout.training else 0.0
+        return self.w_2(self.w_1(x, relu=True, dropout=p))
 
 
 class FeatureEnhancer(nn.Module):

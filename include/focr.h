@@ -51,6 +51,12 @@ int focr_get_precision(void);
 int focr_conv2d_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
                     int N, int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW,
                     float alpha, int relu, int ldy, int ldr, int ldx, focr_stream_t stream);
+/* y = Dropout_p(relu(alpha * x W^T + b)) for a Linear [rows,Cin] -> [rows,Cout] (PositionwiseFeedForward,
+ * tbsrn.py:162-163), dropout fused into the GEMM epilogue.  *keep_scale (host) receives 1/P(keep) (P quantised to
+ * 1/65536): dropped elements are exactly the zeros of y, so the backward is focr_relu_bwd_scaled(dy, y, ., keep_scale). */
+int focr_linear_relu_dropout_fwd(const float* x, const float* w, const float* bias, float* y, long rows, int Cin,
+                                 int Cout, float alpha, float p_drop, uint64_t seed, float* keep_scale,
+                                 focr_stream_t stream);
 /* dw[Cout][KH][KW][Cin], dbias[Cout] (nullable); ldd = row pitch of dy (0: Cout).  Gradient outputs of
  * every *_wgrad/_bwd entry are accumulated with atomics: prezeroed=0 clears them first (overwrite),
  * prezeroed=1 means the caller guarantees zeros (slices of a gradient buffer cleared once per step). */
@@ -125,6 +131,7 @@ int focr_nhwc_to_nchw(const float* x, float* y, int N, int C, int HW, int do_tan
 int focr_tanh_bwd_to_nhwc(const float* dy_nchw, const float* y_nchw, float* dx_nhwc, int N, int C, int HW,
                           focr_stream_t stream);
 int focr_relu_bwd(const float* dy, const float* y, float* dx, long n, focr_stream_t stream);
+int focr_relu_bwd_scaled(const float* dy, const float* y, float* dx, long n, float scale, focr_stream_t stream);
 /* tokens = [feat | positional encoding] tbsrn.py:83-86 ; column slice (+add) for its backward */
 int focr_concat_pe(const float* feat, const float* pe, float* tok, long rows, int Cf, int Cp, int T,
                    focr_stream_t stream);

@@ -157,6 +157,35 @@ def test_linear_streaming(rows, nin, nout, precision):
     close(bd.grad, b.grad, 5e-5, what="stream linear db")
 
 
+@pytest.mark.parametrize("rows", [300, 20000])
+def test_linear_relu_dropout_fused(rows, precision):
+    """Dropout(relu(linear)) with the dropout in the GEMM epilogue (streaming kernel for large row counts, linear +
+    in-place dropout otherwise): every output is 0 or relu(ref)/(1-p'), the keep rate is 1-p, and the backward (which
+    only looks at y > 0) equals the gradient through the very mask the forward drew."""
+    nin, nout, p = 128, 128, 0.1
+    x = rnd(rows, nin, seed=1).requires_grad_(True)
+    wt = rnd(nout, nin, seed=2, scale=1 / math.sqrt(nin)).requires_grad_(True)
+    b = rnd(nout, seed=3).requires_grad_(True)
+    ref = torch.relu(x @ wt.t() + b)
+    xd, wd, bd = (dev(t).requires_grad_(True) for t in (x, wt, b))
+    yd = K().linear(xd, wd, bd, relu=True, dropout=p)
+    y = yd.detach().cpu()
+    scale = 65536.0 / (65536 - round(p * 65536))
+    kept = y != 0
+    pos = ref.detach() > 1e-4                              # away from the relu kink
+    assert abs(kept[pos].double().mean().item() - (1 - p)) < (0.02 if rows < 1000 else 0.004)
+    close(y[kept], (ref.detach() * scale)[kept], ptol(precision), what="fused dropout kept values")
+    assert not (kept & (ref.detach() < -1e-4)).any()
+    # gradients through the same mask
+    mask = kept.to(ref.dtype) * scale
+    gy = rnd(rows, nout, seed=4)
+    (ref * mask).backward(gy)
+    yd.backward(dev(gy))
+    close(xd.grad, x.grad, ptol(precision), what="fused dropout dx")
+    close(wd.grad, wt.grad, ptol(precision, 5e-5), what="fused dropout dw")
+    close(bd.grad, b.grad, 5e-5, what="fused dropout db")
+
+
 @pytest.mark.parametrize("b,t", [(2, 1024), (3, 256)])
 def test_attention(b, t, precision):
     q, k, v = (rnd(b, t, 128, seed=s, scale=2.0).requires_grad_(True) for s in (1, 2, 3))
