@@ -825,28 +825,28 @@ extern "C" int focr_axpy(const float* x, const float* add, float* y, long n, flo
   return FOCR_OK;
 }
 
-// dx = dy * (y > 0)      (backward of a ReLU fused into a GEMM/conv epilogue)
-__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                       float* __restrict__ dx, long n) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    dx[i] = y[i] > 0.f ? dy[i] : 0.f;
-}
 // dx = scale * dy * (y > 0): backward of relu followed by a fused dropout whose kept elements were scaled by `scale`
 __global__ __launch_bounds__(256) void relu_bwd_scaled_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                               float* __restrict__ dx, long n, float scale) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    dx[i] = y[i] > 0.f ? dy[i] * scale : 0.f;
+  const long n4 = n >> 2;                                   // 16-byte accesses; the (< 4 element) tail below
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 g = reinterpret_cast<const float4*>(dy)[i], v = reinterpret_cast<const float4*>(y)[i];
+    reinterpret_cast<float4*>(dx)[i] = make_float4(v.x > 0.f ? g.x * scale : 0.f, v.y > 0.f ? g.y * scale : 0.f,
+                                                   v.z > 0.f ? g.z * scale : 0.f, v.w > 0.f ? g.w * scale : 0.f);
+  }
+  if (blockIdx.x == 0)
+    for (long i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) dx[i] = y[i] > 0.f ? dy[i] * scale : 0.f;
 }
 extern "C" int focr_relu_bwd_scaled(const float* dy, const float* y, float* dx, long n, float scale,
                                     hipStream_t stream) {
   FOCR_CHECK_ARG(dy && y && dx && n > 0, "bad argument");
-  hipLaunchKernelGGL(relu_bwd_scaled_kernel, dim3(ew_grid(n)), 256, 0, stream, dy, y, dx, n, scale);
+  hipLaunchKernelGGL(relu_bwd_scaled_kernel, dim3(ew_grid(n / 4 + 1)), 256, 0, stream, dy, y, dx, n, scale);
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }
 extern "C" int focr_relu_bwd(const float* dy, const float* y, float* dx, long n, hipStream_t stream) {
   FOCR_CHECK_ARG(dy && y && dx && n > 0, "bad argument");
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n)), 256, 0, stream, dy, y, dx, n);
+  hipLaunchKernelGGL(relu_bwd_scaled_kernel, dim3(ew_grid(n / 4 + 1)), 256, 0, stream, dy, y, dx, n, 1.f);
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }

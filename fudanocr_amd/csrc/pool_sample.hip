@@ -66,6 +66,45 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     dx[i] = acc;
   }
 }
+// one thread = 4 consecutive channels of one input pixel (C % 4 == 0: float4 / uchar4 accesses, 32-bit index math)
+__global__ __launch_bounds__(256) void maxpool_bwd_vec4_kernel(const float* __restrict__ dy,
+                                                               const uint8_t* __restrict__ idx,
+                                                               float* __restrict__ dx, long total4, int H, int W,
+                                                               int C, int OH, int OW, int kh, int kw, int sh,
+                                                               int sw, int ph, int pw) {
+  const int C4 = C >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const long t0 = i / C4;
+    const int ix = (int)(t0 % W);
+    const long t1 = t0 / W;
+    const int iy = (int)(t1 % H);
+    const long n = t1 / H;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int a = 0; a < kh; ++a) {
+      const int ny = iy + ph - a;
+      if (ny < 0 || ny % sh) continue;
+      const int oy = ny / sh;
+      if (oy >= OH) continue;
+      for (int b = 0; b < kw; ++b) {
+        const int nx = ix + pw - b;
+        if (nx < 0 || nx % sw) continue;
+        const int ox = nx / sw;
+        if (ox >= OW) continue;
+        const size_t o = (((size_t)n * OH + oy) * OW + ox) * C4 + c4;
+        const uchar4 k = reinterpret_cast<const uchar4*>(idx)[o];
+        const float4 g = reinterpret_cast<const float4*>(dy)[o];
+        const int tap = a * kw + b;
+        acc.x += k.x == tap ? g.x : 0.f;
+        acc.y += k.y == tap ? g.y : 0.f;
+        acc.z += k.z == tap ? g.z : 0.f;
+        acc.w += k.w == tap ? g.w : 0.f;
+      }
+    }
+    reinterpret_cast<float4*>(dx)[i] = acc;
+  }
+}
+
 
 // ---------------------------------------------------------------------------------------
 // TPS warp: one block per sample.  NP = H*W output pixels, NC control points (+3 affine rows)
@@ -286,8 +325,12 @@ extern "C" int focr_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, 
   int OH = (H + 2 * ph - kh) / sh + 1, OW = (W + 2 * pw - kw) / sw + 1;
   FOCR_CHECK_ARG(OH > 0 && OW > 0, "bad geometry");
   long total = (long)N * H * W * C;
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total)), 256, 0, stream, dy, idx, dx, total, H, W, C, OH, OW,
-                     kh, kw, sh, sw, ph, pw);
+  if (C % 4 == 0)
+    hipLaunchKernelGGL(maxpool_bwd_vec4_kernel, dim3(ew_grid(total / 4)), 256, 0, stream, dy, idx, dx, total / 4, H, W, C,
+                       OH, OW, kh, kw, sh, sw, ph, pw);
+  else
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total)), 256, 0, stream, dy, idx, dx, total, H, W, C, OH, OW,
+                       kh, kw, sh, sw, ph, pw);
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }
