@@ -176,11 +176,12 @@ def main():
         bwd_ms = sum(bwd) / max(1, len(bwd))
         flops_launch = 4.0 * args.batch * 4 * 1024 * 1024 * 32
         ach = flops_launch / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
-        # HBM bytes per launch from the PMC passes (profiles/README.md, r01k): (2*FETCH_SIZE + WRITE_SIZE) KB averaged
-        # over the 105 launches of a step, measured at per-GPU batch 128 only
+        # HBM bytes per launch from the PMC passes (profiles/README.md, r01p): (2*FETCH_SIZE + WRITE_SIZE) KB averaged
+        # over the 107 focr_conv2d_fwd launches of a step (conv_fwd_bx3<1|2> + linear_stream kernels), measured at
+        # per-GPU batch 128 only
         traffic = None
         if args.batch == 128 and bx3:
-            traffic = 187.2e6
+            traffic = 167.6e6
         res = {
             "metric": "training images/sec (16x64->32x128 SR+CTC step)", "value": round(value, 2),
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
