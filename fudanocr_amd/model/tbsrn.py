@@ -55,6 +55,7 @@ class MultiHeadedAttention(nn.Module):
         self.linears = nn.ModuleList([Linear(d_model, d_model) for _ in range(4)])
         self.attn = None
         self.dropout = nn.Dropout(p=dropout)          # p and train/eval flag only
+        self._packed_qkv = None                        # (weight, bias) views set by the training engine
         self.compress_attention = compress_attention
         self.compress_attention_linear = nn.Linear(h, 1)   # dead in the reference too (tbsrn.py:107)
 
@@ -64,8 +65,11 @@ class MultiHeadedAttention(nn.Module):
         if query is key and key is value:
             # self-attention (the only use in the SR nets): one packed [rows, 3*d] projection -- the tokens are
             # read once, and the backward is one dgrad GEMM instead of three plus two gradient adds
-            w = torch.cat([self.linears[0].weight, self.linears[1].weight, self.linears[2].weight], 0)
-            b = torch.cat([self.linears[0].bias, self.linears[1].bias, self.linears[2].bias], 0)
+            if self._packed_qkv is not None and self._packed_qkv[0].data_ptr() == self.linears[0].weight.data_ptr():
+                w, b = self._packed_qkv       # views of the engine's flat buffers (engine.TrainStep._attach_packed_qkv)
+            else:
+                w = torch.cat([self.linears[0].weight, self.linears[1].weight, self.linears[2].weight], 0)
+                b = torch.cat([self.linears[0].bias, self.linears[1].bias, self.linears[2].bias], 0)
             ctx = K.attention_packed(K.linear(query, w, b), heads=self.h, p_drop=p)
         else:
             q, k, v = (lin(x) for lin, x in zip(self.linears, (query, key, value)))
