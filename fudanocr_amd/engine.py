@@ -255,6 +255,7 @@ class TrainStep:
             (loss * 100).backward()
         finally:
             K._SIDE["enabled"] = False
+        K.check_deferred()                                 # every parked residual gradient was picked up
         if on_gpu:
             K.join_side_stream()                           # weight gradients complete before all-reduce / optimiser
         self.allreduce_grads()

@@ -64,6 +64,40 @@ def _new_seed():
 # ----------------------------------------------------------------------------------------
 # convolution / linear
 # ----------------------------------------------------------------------------------------
+# ----------------------------------------------------------------------------------------
+# Deferred residual gradients.  When a tensor t feeds BOTH a conv/linear (as its input) and a residual slot of a
+# later op, autograd would add the two gradients of t with a separate elementwise kernel (three 67 MB passes).  The
+# residual consumer always runs its backward first (it is downstream of the GEMM), so it can park its gradient here
+# and return None; the GEMM's data-gradient kernel then adds it in its epilogue (`residual` operand) and returns the
+# complete gradient.  The model code opts in on both sides (defer=True / take_deferred=True) -- it knows the wiring.
+# A parked gradient that is never picked up would be a silent error: check_deferred() raises at the next forward.
+# ----------------------------------------------------------------------------------------
+_DEFERRED = {}
+
+
+def _dkey(t):
+    return (t.data_ptr(), t.numel())
+
+
+def _defer_grad(t, g):
+    k = _dkey(t)
+    if k in _DEFERRED:
+        raise RuntimeError("two deferred gradients for the same tensor")
+    _DEFERRED[k] = g
+
+
+def _take_deferred(t):
+    return _DEFERRED.pop(_dkey(t), None)
+
+
+def check_deferred():
+    """raise if a deferred residual gradient was never consumed (called at the start of a model forward and by the
+    engine after backward)"""
+    if _DEFERRED:
+        _DEFERRED.clear()
+        raise RuntimeError("fudanocr_amd: a deferred residual gradient was never consumed by its GEMM backward")
+
+
 # side stream for engine-owned weight gradients (see _Conv2d.backward); the engine enables it and joins it
 _SIDE = {"enabled": False, "stream": None, "used": False}
 
@@ -107,8 +141,11 @@ class _Conv2d(torch.autograd.Function):
     nn.Linear call sites listed in csrc/conv_igemm.hip."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, pad, alpha, relu, drop_p=0.0):
+    def forward(ctx, x, weight, bias, residual, pad, alpha, relu, drop_p=0.0, take_deferred=False,
+                defer_residual=False):
         cout = weight.shape[0]
+        ctx.take_deferred, ctx.defer_residual = bool(take_deferred), bool(defer_residual)
+        ctx.res_key = _dkey(residual) if (residual is not None and defer_residual) else None
         if weight.dim() == 2:
             kh = kw = 1
             ph = pw = 0
@@ -155,6 +192,11 @@ class _Conv2d(torch.autograd.Function):
                 _lib.call("focr_relu_bwd", _p(dy4), _p(y), _p(g), dy4.numel(), _stream())
             dy4 = g
         dres = dy4.reshape(dy.shape) if has_res else None
+        if has_res and ctx.defer_residual and ctx.needs_input_grad[3]:
+            if ctx.res_key in _DEFERRED:
+                raise RuntimeError("two deferred gradients for the same tensor")
+            _DEFERRED[ctx.res_key] = dy4          # picked up by the data-gradient kernel of the tensor's other consumer
+            dres = None
         wk = _ohwi(weight)
         dx = dw = db = None
         tw, tb = ctx.targets
@@ -194,7 +236,10 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wd = torch.empty(wk.numel(), device=dy.device, dtype=torch.float32)
             _lib.call("focr_weight_flip_transpose", _p(wk), _p(wd), cout, kh, kw, cin, _stream())
-            dx4 = _conv_fwd_raw(dy4, wd, None, None, cin, kh, kw, kh - 1 - ph, kw - 1 - pw, alpha, False)
+            radd = _take_deferred(x4) if ctx.take_deferred else None     # parked residual gradient of x: + in the epilogue
+            if radd is not None:
+                radd = radd.reshape(-1, cin)
+            dx4 = _conv_fwd_raw(dy4, wd, None, radd, cin, kh, kw, kh - 1 - ph, kw - 1 - pw, alpha, False)
             dx = dx4 if len(ctx.x_shape) == 4 else dx4.reshape(ctx.x_shape)
         if ctx.needs_input_grad[1]:
             pass
@@ -205,16 +250,19 @@ class _Conv2d(torch.autograd.Function):
             dw = None
         if tb is not None:
             db = None
-        return dx, dw, db, dres, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, pad=(0, 0), residual=None, alpha=1.0, relu=False):
-    return _Conv2d.apply(x, weight, bias, residual, pad, alpha, relu)
+def conv2d(x, weight, bias=None, pad=(0, 0), residual=None, alpha=1.0, relu=False, take_deferred=False):
+    return _Conv2d.apply(x, weight, bias, residual, pad, alpha, relu, 0.0, take_deferred, False)
 
 
-def linear(x, weight, bias=None, residual=None, alpha=1.0, relu=False, dropout=0.0):
-    """x [..., In] @ weight[Out, In]^T (+bias) (+residual) (relu) (dropout with probability `dropout`, relu only)."""
-    return _Conv2d.apply(x, weight, bias, residual, (0, 0), alpha, relu, float(dropout))
+def linear(x, weight, bias=None, residual=None, alpha=1.0, relu=False, dropout=0.0, take_deferred=False,
+           defer_residual=False):
+    """x [..., In] @ weight[Out, In]^T (+bias) (+residual) (relu) (dropout with probability `dropout`, relu only).
+    take_deferred / defer_residual: see the deferred residual gradients note above."""
+    return _Conv2d.apply(x, weight, bias, residual, (0, 0), alpha, relu, float(dropout), take_deferred,
+                         defer_residual)
 
 
 # ----------------------------------------------------------------------------------------
@@ -276,7 +324,8 @@ def batchnorm_act(x, gamma, beta, rmean, rvar, nbt, training, act=ACT_NONE, resi
 # ----------------------------------------------------------------------------------------
 class _LayerNormStd(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, a, b, eps):
+    def forward(ctx, x, residual, a, b, eps, defer=False):
+        ctx.defer = bool(defer) and residual is not None
         d = x.shape[-1]
         rows = x.numel() // d
         _chk(x, residual, a, b)
@@ -301,11 +350,15 @@ class _LayerNormStd(torch.autograd.Function):
         db = tb if tb is not None else torch.empty(d, device=x.device)
         _lib.call("focr_layernorm_bwd", _p(dy), _p(x), _p(residual), _p(a), _p(mean), _p(rinv), _p(dx), _p(da),
                   _p(db), rows, d, eps, int(ta is not None and tb is not None), _stream())
-        return dx, (dx if has_res else None), (None if ta is not None else da), (None if tb is not None else db), None
+        dres = dx if has_res else None
+        if ctx.defer and ctx.needs_input_grad[1]:
+            _defer_grad(residual, dx)             # added by the data-gradient kernel of the residual's other consumer
+            dres = None
+        return dx, dres, (None if ta is not None else da), (None if tb is not None else db), None, None
 
 
-def layernorm_std(x, a, b, residual=None, eps=1e-6):
-    return _LayerNormStd.apply(x, residual, a, b, eps)
+def layernorm_std(x, a, b, residual=None, eps=1e-6, defer=False):
+    return _LayerNormStd.apply(x, residual, a, b, eps, defer)
 
 
 # ----------------------------------------------------------------------------------------

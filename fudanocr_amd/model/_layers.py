@@ -22,13 +22,15 @@ class Conv2d(nn.Conv2d):
         assert self.stride == (1, 1) and self.dilation == (1, 1) and self.groups == 1
         _channels_last_(self)
 
-    def forward(self, x, residual=None, relu=False):
-        return K.conv2d(x, self.weight, self.bias, pad=self.padding, residual=residual, relu=relu)
+    def forward(self, x, residual=None, relu=False, take_deferred=False):
+        return K.conv2d(x, self.weight, self.bias, pad=self.padding, residual=residual, relu=relu,
+                        take_deferred=take_deferred)
 
 
 class Linear(nn.Linear):
-    def forward(self, x, residual=None, relu=False, alpha=1.0, dropout=0.0):
-        return K.linear(x, self.weight, self.bias, residual=residual, relu=relu, alpha=alpha, dropout=dropout)
+    def forward(self, x, residual=None, relu=False, alpha=1.0, dropout=0.0, take_deferred=False, defer_residual=False):
+        return K.linear(x, self.weight, self.bias, residual=residual, relu=relu, alpha=alpha, dropout=dropout,
+                        take_deferred=take_deferred, defer_residual=defer_residual)
 
 
 class _BNMixin:

@@ -43,8 +43,8 @@ class LayerNorm(nn.Module):
         self.b_2 = nn.Parameter(torch.zeros(features))
         self.eps = eps
 
-    def forward(self, x, residual=None):
-        return K.layernorm_std(x, self.a_2, self.b_2, residual=residual, eps=self.eps)
+    def forward(self, x, residual=None, defer=False):
+        return K.layernorm_std(x, self.a_2, self.b_2, residual=residual, eps=self.eps, defer=defer)
 
 
 class MultiHeadedAttention(nn.Module):
@@ -59,7 +59,7 @@ class MultiHeadedAttention(nn.Module):
         self.compress_attention = compress_attention
         self.compress_attention_linear = nn.Linear(h, 1)   # dead in the reference too (tbsrn.py:107)
 
-    def forward(self, query, key, value, mask=None, align=None):
+    def forward(self, query, key, value, mask=None, align=None, take_deferred=False):
         assert mask is None, "the SR nets never pass a mask"
         p = self.dropout.p if self.dropout.training else 0.0
         if query is key and key is value:
@@ -70,7 +70,7 @@ class MultiHeadedAttention(nn.Module):
             else:
                 w = torch.cat([self.linears[0].weight, self.linears[1].weight, self.linears[2].weight], 0)
                 b = torch.cat([self.linears[0].bias, self.linears[1].bias, self.linears[2].bias], 0)
-            ctx = K.attention_packed(K.linear(query, w, b), heads=self.h, p_drop=p)
+            ctx = K.attention_packed(K.linear(query, w, b, take_deferred=take_deferred), heads=self.h, p_drop=p)
         else:
             q, k, v = (lin(x) for lin, x in zip(self.linears, (query, key, value)))
             ctx = K.attention(q, k, v, heads=self.h, p_drop=p)
@@ -84,10 +84,10 @@ class PositionwiseFeedForward(nn.Module):
         self.w_2 = Linear(d_ff, d_model)
         self.dropout = nn.Dropout(dropout)
 
-    def forward(self, x):
+    def forward(self, x, take_deferred=False):
         # Dropout(relu(w_1 x)) in one kernel: the dropout is part of the GEMM epilogue (and of its relu backward)
         p = self.dropout.p if self.dropout.training else 0.0
-        return self.w_2(self.w_1(x, relu=True, dropout=p))
+        return self.w_2(self.w_1(x, relu=True, dropout=p, take_deferred=take_deferred))
 
 
 class FeatureEnhancer(nn.Module):
@@ -106,13 +106,17 @@ class FeatureEnhancer(nn.Module):
             self._pe = positionalencoding2d(64, 16, 64).reshape(64, 1024).t().contiguous().to(device)
         return self._pe
 
-    def forward(self, conv_feature, residual=None):
+    def forward(self, conv_feature, residual=None, defer_block_input=False):
         """conv_feature: [B, 1024, 64] tokens (channel-last) -> [B, 1024, 64] (+ residual)."""
+        # Each of tok / r / the block input feeds a GEMM AND a later residual slot: the residual consumer parks its
+        # gradient (defer) and the GEMM's data-gradient kernel adds it in its epilogue (take_deferred) -- see
+        # kernels.py "Deferred residual gradients"; three 67 MB gradient-add passes per block disappear.
+        g = torch.is_grad_enabled() and conv_feature.requires_grad
         tok = K.concat_pe(conv_feature, self._pe_table(conv_feature.device))
-        att, _ = self.multihead(tok, tok, tok, mask=None)
-        r = self.mul_layernorm1(att, residual=tok)
-        r = self.mul_layernorm3(self.pff(r), residual=r)
-        return self.linear(r, residual=residual)
+        att, _ = self.multihead(tok, tok, tok, mask=None, take_deferred=g)
+        r = self.mul_layernorm1(att, residual=tok, defer=g)
+        r = self.mul_layernorm3(self.pff(r, take_deferred=g), residual=r, defer=g)
+        return self.linear(r, residual=residual, defer_residual=g and residual is not None and defer_block_input)
 
 
 class mish(nn.Module):
@@ -146,10 +150,11 @@ class RecurrentResidualBlock(nn.Module):
                 nn.init.xavier_uniform_(p)
 
     def forward(self, x):
-        r = self.bn1(self.conv1(x), act=K.ACT_MISH)
+        g = torch.is_grad_enabled() and x.requires_grad
+        r = self.bn1(self.conv1(x, take_deferred=g), act=K.ACT_MISH)
         r = self.bn2(self.conv2(r))
         n, h, w, c = r.shape
-        out = self.feature_enhancer(r.view(n, h * w, c), residual=x.view(n, h * w, c))
+        out = self.feature_enhancer(r.view(n, h * w, c), residual=x.view(n, h * w, c), defer_block_input=g)
         return out.view(n, h, w, c)
 
 
@@ -194,6 +199,7 @@ class TBSRN(nn.Module):
 
     def forward(self, x):
         """x: [B, Cin, 16, 64] NCHW in [0,1] -> SR image [B, Cin, 32, 128] NCHW in (-1,1)."""
+        K.check_deferred()             # a parked residual gradient of an earlier backward must have been consumed
         x = K.to_nhwc(x)
         if self.stn and self.training:
             _, ctrl = self.stn_head(x)
