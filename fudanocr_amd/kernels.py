@@ -241,9 +241,7 @@ class _Conv2d(torch.autograd.Function):
                 radd = radd.reshape(-1, cin)
             dx4 = _conv_fwd_raw(dy4, wd, None, radd, cin, kh, kw, kh - 1 - ph, kw - 1 - pw, alpha, False)
             dx = dx4 if len(ctx.x_shape) == 4 else dx4.reshape(ctx.x_shape)
-        if ctx.needs_input_grad[1]:
-            pass
-        elif has_bias and ctx.needs_input_grad[2]:
+        if not ctx.needs_input_grad[1] and has_bias and ctx.needs_input_grad[2]:      # bias gradient alone
             db = tb if tb is not None else torch.empty(cout, device=dy.device, dtype=torch.float32)
             _lib.call("focr_colsum", _p(dy4), _p(db), dy4.numel() // cout, cout, cout, _stream())
         if tw is not None:
