@@ -395,6 +395,9 @@ int focr_conv3x3_c64_wgrad(const float* x, const float* dy, float* dw, float* db
                            hipStream_t stream);
 long focr_conv3x3_c64_ws_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW);
 
+int focr_conv9x9_cin3_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y, int N,
+                          int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW, int ldx, int ldy,
+                          float alpha, int relu, hipStream_t stream);
 int focr_linear_stream_bx3(const float* x, const float* w, const float* bias, const float* residual, float* y, int M,
                            int Cin, int Cout, int ldx, int ldy, int ldr, float alpha, int relu, uint32_t drop_k,
                            float drop_scale, uint32_t drop_seed, hipStream_t stream);
@@ -412,6 +415,12 @@ extern "C" int focr_conv2d_fwd(const float* x, const float* w, const float* bias
   if (ldx > 0) g.ldx = ldx;
   FOCR_CHECK_ARG(g.ldy >= Cout && g.ldr >= Cout && g.ldx >= Cin, "row pitch too small");
   bool vec = (Cin % BK == 0) && (g.ldx % 4 == 0);
+  if (focr_get_precision() != 0 &&
+      focr_conv9x9_cin3_fwd(x, w, bias, residual, y, N, H, W, Cin, Cout, KH, KW, padH, padW, g.ldx, g.ldy, alpha, relu,
+                            stream)) {
+    FOCR_LAUNCH_CHECK();
+    return FOCR_OK;
+  }
   if (vec && focr_get_precision() != 0 && KH == 1 && KW == 1 && padH == 0 && padW == 0 &&
       focr_linear_stream_bx3(x, w, bias, residual, y, g.M, Cin, Cout, g.ldx, g.ldy, g.ldr, alpha, relu, 0u, 1.f, 0u,
                              stream)) {

@@ -71,6 +71,8 @@ CONV_CASES = [
     (2, 8, 32, 32, 64, 3, 3, 1, 1),       # STN conv (Cin 32)
     (5, 1, 2, 256, 256, 3, 3, 1, 1),      # STN last conv on a 1x2 map, ragged M
     (1, 7, 5, 4, 37, 3, 3, 1, 1),         # odd sizes, mask channel count, Cout not /32
+    (2, 32, 128, 3, 64, 9, 9, 4, 4),      # 9x9 Cin=3 kernel, W = 128 (dgrad of the output layer)
+    (3, 7, 64, 3, 32, 9, 9, 4, 4),        # 9x9 Cin=3 kernel: odd height, one channel group, several row ranges
     (70, 5, 36, 64, 128, 3, 3, 1, 1),     # streaming 3x3 wgrad: W < 64, several images per row range, ragged rows
     (300, 1, 8, 64, 64, 3, 3, 1, 1),      # streaming 3x3 wgrad: one-row images (every row is an image boundary)
     (3, 40, 64, 64, 64, 3, 3, 1, 1),      # streaming 3x3 wgrad: fewer row blocks than CUs, tall images
