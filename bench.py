@@ -187,8 +187,10 @@ def main():
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16x3" if bx3 else "f32", "data": "synthetic",
-            "config": {"workload": "TBSRN + frozen CRNN-CTC train step (BASELINE configs[2]), STN on, "
-                                   "dropout on, 16x64->32x128", "per_gpu_batch": args.batch,
+            "config": {"workload": "%s + frozen CRNN-CTC train step (BASELINE configs[2]%s), STN on, "
+                                   "dropout on, 16x64->32x128" % (args.arch.upper(), "" if args.arch == "tbsrn"
+                                                                  else "; architecture variant"),
+                       "per_gpu_batch": args.batch,
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "arch": args.arch,
                        "collective_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
                        "arithmetic": ("split-bf16 MFMA (hi/lo operands, 3 products, fp32 accumulate)" +
