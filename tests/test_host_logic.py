@@ -91,6 +91,44 @@ def test_flat_buffers_alias_parameters():
     assert float(conv.weight.grad.abs().sum()) == 0.0
 
 
+def test_flat_buffers_keep_qkv_adjacent():
+    """the engine lays the q/k/v projection parameters of an attention module out consecutively and hands the module
+    packed views of the flat buffers (values and gradient targets alias the individual parameters)."""
+    from fudanocr_amd.engine import TrainStep
+
+    class MHA(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.linears = torch.nn.ModuleList([torch.nn.Linear(8, 8) for _ in range(4)])
+            self._packed_qkv = None
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.block1 = torch.nn.Linear(8, 8)
+            self.multihead = MHA()
+            self.block3 = torch.nn.Linear(8, 8)
+
+    torch.manual_seed(0)
+    net = Net()
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    step = TrainStep(net, crit=None)
+    after = net.state_dict()
+    assert list(after.keys()) == list(before.keys())              # state_dict schema and values untouched
+    assert all(torch.equal(after[k], before[k]) for k in before)
+    w, b = net.multihead._packed_qkv
+    lin = net.multihead.linears
+    assert w.shape == (24, 8) and b.shape == (24,)
+    assert torch.equal(w, torch.cat([lin[i].weight for i in range(3)], 0))
+    assert torch.equal(b, torch.cat([lin[i].bias for i in range(3)], 0))
+    assert w.data_ptr() == lin[0].weight.data_ptr() and w._focr_grad.data_ptr() == lin[0].weight.grad.data_ptr()
+    w._focr_grad.fill_(2.0)                                         # a packed gradient write lands in all three
+    assert all(float(lin[i].weight.grad.min()) == 2.0 for i in range(3)) and float(lin[3].weight.grad.abs().max()) == 0.0
+    with torch.no_grad():
+        step.flat.flat_param.add_(1.0)                              # an optimiser update is seen through the views
+    assert torch.equal(w[8:16], lin[1].weight)
+
+
 DP_WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %r)
