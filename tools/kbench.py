@@ -137,3 +137,26 @@ if "ln" in what:
     print("layernorm fwd median %8.1f us  min %8.1f us" % (m, mn))
     m, mn = timeit(bwd)
     print("layernorm bwd median %8.1f us  min %8.1f us" % (m, mn))
+if "gru" in what:
+    # TSRN GruBlock scans at B = 128 on the 16 x 64 map: gru1 vertical (nseq = B*64, T = 16), gru2 horizontal (B*16, 64)
+    rows = B * 16 * 64
+    gxg = torch.randn(rows, 192, device="cuda", generator=g)
+    whh = torch.randn(2, 96, 32, device="cuda", generator=g) * 0.2
+    bhh = torch.randn(2, 96, device="cuda", generator=g) * 0.1
+    hs = torch.empty(rows, 64, device="cuda")
+    gts = torch.empty(rows, 2, 128, device="cuda")
+    dh = torch.randn(rows, 64, device="cuda", generator=g)
+    dgx, dgh = torch.empty(rows, 192, device="cuda"), torch.empty(rows, 192, device="cuda")
+    hpv = torch.empty(rows, 2, 32, device="cuda")
+    for name, (nseq, t, ic, os_, is_, ts) in (("gru1 vertical T=16", (B * 64, 16, 64, 16 * 64, 1, 64)),
+                                              ("gru2 horizontal T=64", (B * 16, 64, 1, 64, 0, 1))):
+        def fwd():
+            _lib.call("focr_gru_bidir_fwd", K._p(gxg), K._p(whh), K._p(bhh), K._p(hs), K._p(gts), nseq, t, ic, os_, is_, ts,
+                      K._stream())
+
+        def bwd():
+            _lib.call("focr_gru_bidir_bwd", K._p(dh), K._p(whh), K._p(gts), K._p(hs), K._p(dgx), K._p(dgh), K._p(hpv), nseq,
+                      t, ic, os_, is_, ts, K._stream())
+        m, mn = timeit(fwd)
+        m2, mn2 = timeit(bwd)
+        print("%-22s fwd median %8.1f us (%.2f us/step)  bwd median %8.1f us (%.2f us/step)" % (name, m, m / t, m2, m2 / t))
