@@ -18,6 +18,7 @@ SIGNATURES = {
     "focr_conv2d_wgrad": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, L, P],
     "focr_conv2d_wgrad_ws_floats": [I, I, I, I, I, I, I, I, I],
     "focr_weight_flip_transpose": [P, P, I, I, I, I, P],
+    "focr_weight_flip_transpose_batched": [P, I, I, P],
     "focr_colsum": [P, P, L, I, I, P],
     "focr_attention_fwd": [P, P, P, P, P, P, I, I, I, I, I, F, F, U, P],
     "focr_attention_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, F, P],

@@ -532,6 +532,38 @@ extern "C" int focr_conv2d_wgrad(const float* x, const float* dy, float* dw, flo
   return FOCR_OK;
 }
 
+// All layers of a model in ONE launch (the weights do not change during backward, so the training step flips every
+// layer once, up front, instead of launching a ~6 us kernel in front of each data-gradient GEMM).
+// descs_dev: device array of n focr_flip_desc (include/focr.h).
+struct FlipDesc {
+  const float* w;
+  float* wd;
+  int cout, kh, kw, cin;
+};
+__global__ __launch_bounds__(256) void weight_flip_transpose_batched_kernel(const FlipDesc* __restrict__ descs) {
+  const FlipDesc d = descs[blockIdx.y];
+  const int total = d.cout * d.kh * d.kw * d.cin;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int co = i % d.cout;
+    int t = i / d.cout;
+    int kw = t % d.kw;
+    t /= d.kw;
+    int kh = t % d.kh;
+    int ci = t / d.kh;
+    d.wd[i] = d.w[((size_t)(co * d.kh + (d.kh - 1 - kh)) * d.kw + (d.kw - 1 - kw)) * d.cin + ci];
+  }
+}
+extern "C" int focr_weight_flip_transpose_batched(const void* descs_dev, int n, int max_elems, hipStream_t stream) {
+  FOCR_CHECK_ARG(descs_dev && n > 0 && max_elems > 0, "bad argument");
+  int gx = cdiv(max_elems, 256 * 8);
+  if (gx > 64) gx = 64;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(weight_flip_transpose_batched_kernel, dim3(gx, n), 256, 0, stream,
+                     reinterpret_cast<const FlipDesc*>(descs_dev));
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+
 extern "C" int focr_weight_flip_transpose(const float* w, float* wd, int Cout, int KH, int KW,
                                           int Cin, hipStream_t stream) {
   FOCR_CHECK_ARG(w && wd, "null pointer");

@@ -138,6 +138,7 @@ class TrainStep:
         self.opt = FusedClipAdam(self.flat, lr, betas, 1e-8, max_norm)
         self.pg = process_group
         self.wgrad_side_stream = bool(wgrad_side_stream)
+        self.flips = K.FlipTable()               # one batched weight flip per step for all data-gradient GEMMs
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         n = self.flat.numel
         edges = [n * i // n_buckets // 4 * 4 for i in range(n_buckets)] + [n]
@@ -247,6 +248,9 @@ class TrainStep:
         sr = self.model(images_lr)
         loss, mse, _, ctc = self.crit(sr, images_hr, label_strs, encoded)
         on_gpu = self.flat.flat_grad.is_cuda
+        if on_gpu:
+            self.flips.refresh()
+            K.FLIPS = self.flips
         if on_gpu and self.wgrad_side_stream:
             # the zeroed flat gradient must be visible to the side stream before its kernels accumulate into it
             K._SIDE["enabled"] = True
@@ -255,6 +259,9 @@ class TrainStep:
             (loss * 100).backward()
         finally:
             K._SIDE["enabled"] = False
+            K.FLIPS = None
+        if on_gpu:
+            self.flips.build(self.flat.flat_grad.device)       # no-op after the first step
         K.check_deferred()                                 # every parked residual gradient was picked up
         if on_gpu:
             K.join_side_stream()                           # weight gradients complete before all-reduce / optimiser

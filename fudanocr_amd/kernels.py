@@ -98,6 +98,72 @@ def check_deferred():
         raise RuntimeError("fudanocr_amd: a deferred residual gradient was never consumed by its GEMM backward")
 
 
+# ----------------------------------------------------------------------------------------
+# Flipped / transposed weights for the data-gradient GEMMs.  Weights do not change during backward, so the training
+# engine flips every layer in ONE launch per step (FlipTable) instead of one ~6 us launch in front of each dgrad;
+# frozen weights (the recogniser) are flipped once.  The first step registers the layers as their backward runs.
+# ----------------------------------------------------------------------------------------
+class FlipTable:
+    def __init__(self):
+        self.reg = {}            # weight data_ptr -> (cout, kh, kw, cin, frozen)
+        self.views = {}          # weight data_ptr -> flipped weights (valid for the current step)
+        self.frozen_ver = {}     # frozen weight data_ptr -> tensor version its cached flip belongs to
+        self.built = False
+        self.n_live = 0
+
+    def lookup(self, wk, cout, kh, kw, cin, frozen):
+        ptr = wk.data_ptr()
+        wd = self.views.get(ptr)
+        if wd is None:
+            if not self.built:
+                self.reg[ptr] = (cout, kh, kw, cin, bool(frozen))
+                if frozen:
+                    self.frozen_ver[ptr] = wk._version
+            return None
+        if frozen and self.frozen_ver.get(ptr) != wk._version:     # frozen weights were overwritten (e.g. a checkpoint
+            return None                                            # was loaded): fall back to a fresh per-layer flip
+        return wd
+
+    def _descs(self, items, device):
+        import numpy as np
+        dt = np.dtype([("w", "<u8"), ("wd", "<u8"), ("cout", "<i4"), ("kh", "<i4"), ("kw", "<i4"), ("cin", "<i4")])
+        arr = np.zeros(len(items), dtype=dt)
+        for i, (ptr, view, (cout, kh, kw, cin, _)) in enumerate(items):
+            arr[i] = (ptr, view.data_ptr(), cout, kh, kw, cin)
+        return torch.from_numpy(arr.view(np.uint8).copy()).to(device)
+
+    def build(self, device):
+        """after the first backward: one buffer for all flipped weights + the device descriptor tables"""
+        if self.built or not self.reg:
+            return
+        total = sum(c * a * b * d for c, a, b, d, _ in self.reg.values())
+        self.buf = torch.empty(total, device=device, dtype=torch.float32)
+        off, live, frozen = 0, [], []
+        for ptr, geo in self.reg.items():
+            n = geo[0] * geo[1] * geo[2] * geo[3]
+            view = self.buf[off:off + n]
+            off += n
+            (frozen if geo[4] else live).append((ptr, view, geo))
+            self.views[ptr] = view
+        self.max_live = max([g[0] * g[1] * g[2] * g[3] for _, _, g in live], default=0)
+        self.n_live = len(live)
+        self.live_desc = self._descs(live, device) if live else None
+        if frozen:                                   # frozen layers: flipped once, here
+            fd = self._descs(frozen, device)
+            _lib.call("focr_weight_flip_transpose_batched", _p(fd), len(frozen),
+                      max(g[0] * g[1] * g[2] * g[3] for _, _, g in frozen), _stream())
+            self._keep = fd
+        self.built = True
+
+    def refresh(self):
+        """once per step, before backward: re-flip the trainable layers"""
+        if self.built and self.n_live:
+            _lib.call("focr_weight_flip_transpose_batched", _p(self.live_desc), self.n_live, self.max_live, _stream())
+
+
+FLIPS = None                     # set by the engine (engine.TrainStep); None: every dgrad flips its own weights
+
+
 # side stream for engine-owned weight gradients (see _Conv2d.backward); the engine enables it and joins it
 _SIDE = {"enabled": False, "stream": None, "used": False}
 
@@ -234,8 +300,10 @@ class _Conv2d(torch.autograd.Function):
                 if alpha != 1.0:
                     _lib.call("focr_axpy", _p(dw), _NULL, _p(dw), dw.numel(), alpha, _stream())
         if ctx.needs_input_grad[0]:
-            wd = torch.empty(wk.numel(), device=dy.device, dtype=torch.float32)
-            _lib.call("focr_weight_flip_transpose", _p(wk), _p(wd), cout, kh, kw, cin, _stream())
+            wd = FLIPS.lookup(wk, cout, kh, kw, cin, not weight.requires_grad) if FLIPS is not None else None
+            if wd is None:
+                wd = torch.empty(wk.numel(), device=dy.device, dtype=torch.float32)
+                _lib.call("focr_weight_flip_transpose", _p(wk), _p(wd), cout, kh, kw, cin, _stream())
             radd = _take_deferred(x4) if ctx.take_deferred else None     # parked residual gradient of x: + in the epilogue
             if radd is not None:
                 radd = radd.reshape(-1, cin)

@@ -70,6 +70,13 @@ int focr_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, 
 /* w[Cout][KH][KW][Cin] -> wd[Cin][KH][KW][Cout] with both spatial axes flipped */
 int focr_weight_flip_transpose(const float* w, float* wd, int Cout, int KH, int KW, int Cin,
                                focr_stream_t stream);
+/* the same for n layers in one launch: descs_dev = device array of n focr_flip_desc */
+typedef struct focr_flip_desc {
+  const float* w; /* [Cout][KH][KW][Cin] */
+  float* wd;      /* [Cin][KH][KW][Cout], taps flipped */
+  int cout, kh, kw, cin;
+} focr_flip_desc;
+int focr_weight_flip_transpose_batched(const void* descs_dev, int n, int max_elems, focr_stream_t stream);
 /* out[c] = sum_r x[r*ld + c]   (bias gradients) */
 int focr_colsum(const float* x, float* out, long rows, int C, int ld, focr_stream_t stream);
 /* specialised 9x9, pad 4, Cin=64 -> Cout<=3|4 convolution (SR output layer, model/tsrn.py:43):
