@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_bx3_kernel(const float* __res
 #pragma unroll
   for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
   float mrun = -1e30f, l = 0.f;
-  const uint32_t thr = DROPOUT ? (uint32_t)(p_drop * 65536.0f + 0.5f) : 0u;
+  const uint32_t thr = DROPOUT ? attn_drop_thr16(p_drop) : 0u;
   const float inv_keep = DROPOUT ? 1.f / (1.f - (float)thr / 65536.f) : 1.f;
   const int NG = Ntok / 32;
   const int qg = __builtin_amdgcn_readfirstlane(qb_ * 4 + wave);
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
   f32x16 dkacc, dvacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dkacc[r] = 0.f; dvacc[r] = 0.f; }
-  const float inv_keep = DROPOUT ? 1.f / (1.f - (float)(uint32_t)(p_drop * 65536.0f + 0.5f) / 65536.f) : 1.f;
+  const float inv_keep = DROPOUT ? 1.f / (1.f - (float)attn_drop_thr16(p_drop) / 65536.f) : 1.f;
 
   const int rp = tid >> 3, c0 = (tid & 7) * 4;
   float4 q0, q1, g0, g1;
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_bx3_kernel(
   f32x16 dqacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) dqacc[r] = 0.f;
-  const float inv_keep = DROPOUT ? 1.f / (1.f - (float)(uint32_t)(p_drop * 65536.0f + 0.5f) / 65536.f) : 1.f;
+  const float inv_keep = DROPOUT ? 1.f / (1.f - (float)attn_drop_thr16(p_drop) / 65536.f) : 1.f;
   const int NG = Ntok / 32;
   const int qg = __builtin_amdgcn_readfirstlane(qb_ * 4 + wave);
   const uint64_t* mgrp = reinterpret_cast<const uint64_t*>(MASK) + ((size_t)bh_ * NG + qg) * NG * 16;

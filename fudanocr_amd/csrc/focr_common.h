@@ -106,6 +106,12 @@ __device__ __forceinline__ float keep_if_bit(float v, uint32_t w, int bit) {
 // halves of the 64-bit word r of the group: a ready-made lane mask for v_cndmask (forward / dQ kernels: ONE VALU
 // op per score, the words arrive through scalar loads).  The dK/dV kernel (lane = key) loads its key's word
 // per lane and tests bit (query offset) with v_bfe_i32.
+// attention dropout probability, quantised to 1/4096 and expressed in 1/65536 units (low 4 bits zero): the keep-bit
+// generator needs one xorshift word per significant bit of the keep probability, so 12-bit quantisation (p = 0.1 ->
+// 0.10010) saves a third of its work; every kernel derives its 1/(1-p) from the same number
+__host__ __device__ __forceinline__ uint32_t attn_drop_thr16(float p_drop) {
+  return (uint32_t)(p_drop * 4096.0f + 0.5f) << 4;
+}
 __device__ __forceinline__ int mask_slot(int kk) { return 2 * ((kk & 3) + 4 * (kk >> 3)) + ((kk >> 2) & 1); }
 // (builtin, not inline asm: the compiler must see the instruction to honour the trans-use / MFMA-read hazards)
 __device__ __forceinline__ float keep_lanes(float x, uint64_t m) {

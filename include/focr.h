@@ -89,7 +89,7 @@ int focr_conv9x9_small_cout_wgrad(const float* x, const float* dy, float* dw, fl
 /* ---- fused attention: model/tbsrn.py:132-150 (+ the head split/merge of :116-126) -----------
  * q,k,v (and dq,dk,dv): row pitch ld; o, d_o: row pitch ldo (0 = ld) -- q,k,v may be column slices of one packed
  * [B,Ntok,3*128] projection; head h in columns h*32..h*32+31; lse: [B,H,Ntok]; Ntok % 128 == 0.
- * p_drop: dropout on the probabilities (tbsrn.py:147-148); the forward draws the mask from a counter
+ * p_drop: dropout on the probabilities (tbsrn.py:147-148), quantised to 1/4096; the forward draws the mask from a counter
  * hash seeded stream into mask: uint32 [B*H, Ntok/32 query groups, Ntok/32 key groups, 32 slots]; bit j of a word =
  * query 32*qg+j, the word's key = 32*kg+kk with slot = 2*((kk&3)+4*(kk>>3)) + ((kk>>2)&1)
  * (B*H*Ntok*Ntok/32 words, needed iff p>0). */

@@ -256,7 +256,7 @@ def test_attention_dropout_exact_against_extracted_mask(precision):
     bits = dense.permute(0, 1, 2, 5, 3, 4).reshape(b, 4, t, t).double()             # [b,4,q,key]
     keep = bits.mean().item()
     assert abs(keep - 0.9) < 4e-3, keep
-    thr = round(p * 65536)
+    thr = round(p * 4096) * 16                 # attention dropout quantisation (focr_common.h attn_drop_thr16)
     heads = lambda z: z.view(b, t, 4, 32).transpose(1, 2)
     pr = torch.softmax(heads(q) @ heads(k).transpose(-1, -2) / math.sqrt(32), -1) * bits / (1 - thr / 65536)
     o = (pr @ heads(v)).transpose(1, 2).reshape(b, t, 128)
