@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--arch", default="tbsrn")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16x3-allsplit", "fp32"],
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16x3-allsplit", "bf16x3-dgrad16", "fp32"],
                     help="contraction arithmetic: split-bf16 MFMA with single-bf16 gradient accumulations in the "
                          "attention backward (library default, focr_set_precision(2)); the same with split "
                          "products everywhere (mode 1); or exact fp32 MFMA (mode 0)")
@@ -114,7 +114,7 @@ def main():
     from fudanocr_amd.smoke import build_models
     from fudanocr_amd.utils.synth import make_batch
     _lib.load()
-    _lib.set_precision({"bf16x3": 2, "bf16x3-allsplit": 1, "fp32": 0}[args.precision])
+    _lib.set_precision({"bf16x3": 2, "bf16x3-allsplit": 1, "bf16x3-dgrad16": 3, "fp32": 0}[args.precision])
     net, rec, crit = build_models(dev, args.arch)
     step = TrainStep(net, crit, dropout=True, wgrad_side_stream=os.environ.get("FOCR_WGRAD_SIDE", "1") != "0")
     lr, hr, labels = make_batch(args.batch, 1234 + rank)
@@ -136,7 +136,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i == args.steps - conv_steps:
-            _lib.add_timing(["focr_conv2d_fwd"])
+            _lib.add_timing(["focr_conv2d_fwd", "focr_conv3x3_frag_fwd"])
         out = step(lr, hr, encoded=enc)
     sync()
     dt = time.perf_counter() - t0

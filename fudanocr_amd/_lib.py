@@ -20,6 +20,11 @@ SIGNATURES = {
     "focr_weight_flip_transpose": [P, P, I, I, I, I, P],
     "focr_weight_flip_transpose_batched": [P, I, I, P],
     "focr_colsum": [P, P, L, I, I, P],
+    "focr_weight_frag_bytes": [I, I],
+    "focr_weight_prep_frag": [P, P, I, I, I, I, I, P],
+    "focr_weight_prep_frag_batched": [P, I, L, P],
+    "focr_conv3x3_frag_tiles": [I, I, I],
+    "focr_conv3x3_frag_fwd": [P, P, P, P, P, P, I, I, I, I, I, F, I, I, I, I, I, P],
     "focr_attention_fwd": [P, P, P, P, P, P, I, I, I, I, I, F, F, U, P],
     "focr_attention_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, F, P],
     "focr_bn_train_fwd": [P, P, P, P, P, P, P, P, P, P, P, L, I, F, F, I, P],
@@ -93,8 +98,9 @@ def load():
     lib.focr_lstm_ws_bytes.restype = ctypes.c_long
     lib.focr_grad_sumsq_ws_floats.restype = ctypes.c_long
     lib.focr_conv2d_wgrad_ws_floats.restype = ctypes.c_long
+    lib.focr_weight_frag_bytes.restype = ctypes.c_long
     _lib = lib
-    if os.environ.get("FOCR_PRECISION"):          # 0 fp32 | 1 bf16x3 (default) | 2 bf16x3 + bf16 gradient accumulation
+    if os.environ.get("FOCR_PRECISION"):          # 0 fp32 | 1 bf16x3 | 2 (default) + bf16 attention-gradient sums | 3 + bf16 dgrad
         rc = lib.focr_set_precision(int(os.environ["FOCR_PRECISION"]))
         if rc != 0:
             raise RuntimeError("FOCR_PRECISION: " + lib.focr_last_error().decode())
@@ -139,7 +145,8 @@ def _stop_timing(with_args):
 
 
 def set_precision(mode):
-    """0 = fp32 MFMA, 1 = split-bf16 ("bf16x3") MFMA for the kernels that have both paths."""
+    """0 = fp32 MFMA, 1 = split-bf16 ("bf16x3") MFMA, 2 = 1 + single-bf16 gradient accumulations in the attention
+    backward, 3 = 2 + single-bf16 data-gradient convolutions (csrc/focr_core.hip)."""
     call("focr_set_precision", int(mode))
 
 

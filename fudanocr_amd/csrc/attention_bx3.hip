@@ -483,7 +483,7 @@ int focr_attn_bwd_bx3(const float* q, const float* k, const float* v, const floa
                       const float* dwork, const uint32_t* mask, float* dq, float* dk, float* dv, int B, int H,
                       int Ntok, int ld, int ldo, float scale, float p_drop, hipStream_t stream) {
   dim3 grid(B * H * (Ntok / 128));
-  const bool fast = focr_get_precision() == 2;
+  const bool fast = focr_get_precision() >= 2;
 #define LAUNCH_BWD(DR, FA)                                                                                        \
   do {                                                                                                            \
     hipLaunchKernelGGL((attn_bwd_dkv_bx3_kernel<DR, FA>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dk, dv, \

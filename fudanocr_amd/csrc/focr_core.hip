@@ -20,10 +20,14 @@ extern "C" int focr_version(void) { return 100; }
 //       dQ += dS K) use single bf16 products: they have no softmax-style cancellation, their rounding error
 //       (2^-9 per term, averaged over 1024 terms) is far below the 1e-2 gradient gate, while the score recompute
 //       and dP = dO V^T (which feed exp / the dP - D cancellation) stay bf16x3.  Forward results are identical to 1.
+//   3 = as 2, and the DATA-GRADIENT convolutions that run on the halo kernel (conv3x3_halo.hip) use a single bf16
+//       product (activations' gradients and weights rounded to bf16, fp32 accumulate) -- the arithmetic of every
+//       bf16 mixed-precision training stack.  Forward results are identical to 1 and 2; the host selects the plane
+//       count per call (focr_conv3x3_frag_fwd), this flag only tells it what the library-wide choice is.
 static int g_precision = 2;
 extern "C" int focr_set_precision(int mode) {
-  if (mode < 0 || mode > 2) {
-    focr_set_error("focr_set_precision: mode must be 0 (fp32), 1 (bf16x3) or 2 (bf16x3, bf16 gradient accumulation)");
+  if (mode < 0 || mode > 3) {
+    focr_set_error("focr_set_precision: mode must be 0 (fp32), 1 (bf16x3), 2 (bf16x3, bf16 gradient accumulation) or 3 (2 + bf16 data gradients)");
     return FOCR_EINVAL;
   }
   g_precision = mode;

@@ -139,6 +139,8 @@ class TrainStep:
         self.pg = process_group
         self.wgrad_side_stream = bool(wgrad_side_stream)
         self.flips = K.FlipTable()               # one batched weight flip per step for all data-gradient GEMMs
+        self.frags = K.FragTable(managed=True)   # pre-split fragment-ordered weights of the halo-kernel layers: one
+                                                 # batched preparation launch per step (forward + data-gradient forms)
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         n = self.flat.numel
         edges = [n * i // n_buckets // 4 * 4 for i in range(n_buckets)] + [n]
@@ -245,9 +247,16 @@ class TrainStep:
                     m.eval()
         self.flat.zero_grad()
         self._works, self._sent = [], []
-        sr = self.model(images_lr)
-        loss, mse, _, ctc = self.crit(sr, images_hr, label_strs, encoded)
         on_gpu = self.flat.flat_grad.is_cuda
+        if on_gpu:
+            self.frags.refresh()
+            K.FRAGS = self.frags
+        try:
+            sr = self.model(images_lr)
+            loss, mse, _, ctc = self.crit(sr, images_hr, label_strs, encoded)
+        except BaseException:
+            K.FRAGS = None
+            raise
         if on_gpu:
             self.flips.refresh()
             K.FLIPS = self.flips
@@ -260,6 +269,7 @@ class TrainStep:
         finally:
             K._SIDE["enabled"] = False
             K.FLIPS = None
+            K.FRAGS = None
         if on_gpu:
             self.flips.build(self.flat.flat_grad.device)       # no-op after the first step
         K.check_deferred()                                 # every parked residual gradient was picked up
@@ -267,5 +277,6 @@ class TrainStep:
             K.join_side_stream()                           # weight gradients complete before all-reduce / optimiser
         self.allreduce_grads()
         self.opt.step(self.world)
+        K.bump_weight_epoch()                              # parameters changed behind autograd's version counters
         return {"loss": loss.detach(), "mse": mse.detach(),
                 "ctc": ctc.detach() if torch.is_tensor(ctc) else None, "sr": sr.detach()}

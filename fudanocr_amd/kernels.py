@@ -10,6 +10,7 @@ kernel wants, with the reference's state_dict shapes unchanged.
 import contextlib
 import ctypes
 import math
+import weakref
 
 import torch
 
@@ -164,6 +165,116 @@ class FlipTable:
 FLIPS = None                     # set by the engine (engine.TrainStep); None: every dgrad flips its own weights
 
 
+# ----------------------------------------------------------------------------------------
+# Pre-split, MFMA-fragment-ordered bf16 weights for the halo convolution kernel (csrc/conv3x3_halo.hip): the kernel
+# DMAs 1 KB weight pieces straight into LDS, so the fp32 -> bf16 hi/lo split and the fragment permutation are done
+# ONCE per weight update here instead of in every block of every launch.
+#   * outside a training engine every entry is validated against the tensor's identity and version counter (plus the
+#     engine's WEIGHT_EPOCH: the fused Adam kernel updates parameters through raw pointers, which autograd's version
+#     counter does not see);
+#   * inside engine.TrainStep the table is `managed`: the trainable layers registered during the first step are
+#     re-prepared by ONE batched launch at the start of every later step (forward and flipped/data-gradient forms).
+# Entries are keyed by the parameter OBJECT (weak reference), never by a bare data pointer, and only leaf tensors are
+# cached: a per-forward temporary (torch.cat of GRU weights, a non-channels_last copy) is prepared on the spot.
+# ----------------------------------------------------------------------------------------
+WEIGHT_EPOCH = 0                 # bumped by the engine whenever it rewrites parameters behind autograd's back
+
+
+def bump_weight_epoch():
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+
+
+class _FragEntry:
+    __slots__ = ("ref", "buf", "geom", "ptr", "version", "epoch", "managed")
+
+
+class FragTable:
+    def __init__(self, managed=False):
+        self.managed = bool(managed)
+        self.entries = {}            # (id(weight), flip) -> _FragEntry
+        self.live = []               # managed entries, refreshed by refresh()
+        self.desc = None
+        self.max_threads = 0
+
+    @staticmethod
+    def _prep(e, wk, flip):
+        cout, kh, kw, cin = e.geom
+        _lib.call("focr_weight_prep_frag", _p(wk), ctypes.c_void_p(e.buf.data_ptr()), cout, kh, kw, cin, int(flip),
+                  _stream())
+
+    def get(self, weight, wk, cout, kh, kw, cin, flip):
+        """fragment-ordered weights of `weight` (physically OHWI tensor `wk`); flip: data-gradient form"""
+        cacheable = weight.is_leaf and wk.data_ptr() == weight.data_ptr()
+        key = (id(weight), bool(flip))
+        e = self.entries.get(key) if cacheable else None
+        geom = (cout, kh, kw, cin)
+        if e is not None and (e.ref() is not weight or e.geom != geom or e.ptr != wk.data_ptr()):
+            if e.managed:
+                self.live = [(x, f) for x, f in self.live if x is not e]
+                self.desc = None
+            e = None
+        if e is not None:
+            if e.managed:
+                return e.buf                                    # refreshed at the start of this step
+            if e.version == weight._version and (not weight.requires_grad or e.epoch == WEIGHT_EPOCH):
+                return e.buf
+            e.version, e.epoch = weight._version, WEIGHT_EPOCH
+            self._prep(e, wk, flip)
+            return e.buf
+        e = _FragEntry()
+        rows, k = (cin, kh * kw * cout) if flip else (cout, kh * kw * cin)
+        e.buf = torch.empty(_lib.load().focr_weight_frag_bytes(rows, k), device=wk.device, dtype=torch.uint8)
+        e.geom, e.ptr, e.version, e.epoch = geom, wk.data_ptr(), weight._version, WEIGHT_EPOCH
+        e.ref = weakref.ref(weight) if cacheable else (lambda: None)
+        e.managed = bool(self.managed and cacheable and weight.requires_grad)
+        self._prep(e, wk, flip)
+        if cacheable:
+            self.entries[key] = e
+            if e.managed:
+                self.live.append((e, bool(flip)))
+                self.desc = None
+        return e.buf
+
+    def refresh(self):
+        """managed tables, once per step before the forward: re-prepare every trainable layer in one launch"""
+        live = [(e, f) for e, f in self.live if e.ref() is not None]
+        if len(live) != len(self.live):
+            self.live, self.desc = live, None
+        if not self.live:
+            return
+        if self.desc is None:
+            import numpy as np
+            dt = np.dtype([("w", "<u8"), ("wf", "<u8"), ("cout", "<i4"), ("kh", "<i4"), ("kw", "<i4"), ("cin", "<i4"),
+                           ("flip", "<i4"), ("pad", "<i4")])
+            arr = np.zeros(len(self.live), dtype=dt)
+            self.max_threads = 0
+            for i, (e, f) in enumerate(self.live):
+                cout, kh, kw, cin = e.geom
+                arr[i] = (e.ptr, e.buf.data_ptr(), cout, kh, kw, cin, int(f), 0)
+                self.max_threads = max(self.max_threads, e.buf.numel() // 32)
+            self.desc = torch.from_numpy(arr.view(np.uint8).copy()).to(self.live[0][0].buf.device)
+        _lib.call("focr_weight_prep_frag_batched", _p(self.desc), len(self.live), self.max_threads, _stream())
+
+
+_FRAGS_DEFAULT = FragTable(managed=False)
+FRAGS = None                     # the engine's managed table while one of its steps runs
+
+
+def _frag_weights(weight, wk, cout, kh, kw, cin, flip):
+    return (FRAGS or _FRAGS_DEFAULT).get(weight, wk, cout, kh, kw, cin, flip)
+
+
+def _halo_ok(h, w, cin, cout, kh, kw, ph, pw):
+    """3x3 / pad 1 layers that run on the halo kernel: channel counts in multiples of 64 and a map that fills at least
+    half of its 4 x 32 pixel tiles (the STN head's 2 x 8 maps stay on the generic kernel)."""
+    if not (kh == 3 and kw == 3 and ph == 1 and pw == 1 and cin % 64 == 0 and cout % 64 == 0):
+        return False
+    if _lib.get_precision() == 0:
+        return False
+    return 2 * h * w >= ((h + 3) // 4 * 4) * ((w + 31) // 32 * 32)
+
+
 # side stream for engine-owned weight gradients (see _Conv2d.backward); the engine enables it and joins it
 _SIDE = {"enabled": False, "stream": None, "used": False}
 
@@ -189,10 +300,16 @@ def _is_out_layer(cin, cout, kh, kw, ph, pw, w, residual, alpha, relu):
             and w <= 128 and residual is None and alpha == 1.0 and not relu)
 
 
-def _conv_fwd_raw(x4, w_ohwi, bias, residual, cout, kh, kw, ph, pw, alpha, relu):
+def _conv_fwd_raw(x4, w_ohwi, bias, residual, cout, kh, kw, ph, pw, alpha, relu, frag=None, planes=2, stats=None):
+    """frag: fragment-ordered bf16 weights (FragTable) -> halo kernel with `planes` products' worth of operand planes;
+    stats: optional [tiles, cout, 2] per-tile (sum, sum of squares) output for a following BatchNorm."""
     n, h, w, cin = x4.shape
     oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
     y = torch.empty((n, oh, ow, cout), device=x4.device, dtype=torch.float32)
+    if frag is not None:
+        _lib.call("focr_conv3x3_frag_fwd", _p(x4), ctypes.c_void_p(frag.data_ptr()), _p(bias), _p(residual), _p(y),
+                  _p(stats), n, h, w, cin, cout, float(alpha), int(relu), int(planes), 0, 0, 0, _stream())
+        return y
     if _is_out_layer(cin, cout, kh, kw, ph, pw, w, residual, alpha, relu):
         _lib.call("focr_conv9x9_small_cout_fwd", _p(x4), _p(w_ohwi), _p(bias), _p(y), n, h, w, cin, cout,
                   _stream())
@@ -236,7 +353,10 @@ class _Conv2d(torch.autograd.Function):
                       float(alpha), float(drop_p), _new_seed(), ctypes.byref(ks), _stream())
             ctx.drop_scale = float(ks.value)
         else:
-            y = _conv_fwd_raw(x4, wk, bias, res4, cout, kh, kw, ph, pw, alpha, relu)
+            frag = None
+            if _halo_ok(x4.shape[1], x4.shape[2], x4.shape[3], cout, kh, kw, ph, pw):
+                frag = _frag_weights(weight, wk, cout, kh, kw, x4.shape[3], False)
+            y = _conv_fwd_raw(x4, wk, bias, res4, cout, kh, kw, ph, pw, alpha, relu, frag=frag)
         ctx.geom = (kh, kw, ph, pw, float(alpha), bool(relu), bias is not None, residual is not None)
         ctx.targets = (_target(weight), _target(bias))
         ctx.save_for_backward(x4, weight, y if relu else None)
@@ -300,14 +420,23 @@ class _Conv2d(torch.autograd.Function):
                 if alpha != 1.0:
                     _lib.call("focr_axpy", _p(dw), _NULL, _p(dw), dw.numel(), alpha, _stream())
         if ctx.needs_input_grad[0]:
-            wd = FLIPS.lookup(wk, cout, kh, kw, cin, not weight.requires_grad) if FLIPS is not None else None
-            if wd is None:
-                wd = torch.empty(wk.numel(), device=dy.device, dtype=torch.float32)
-                _lib.call("focr_weight_flip_transpose", _p(wk), _p(wd), cout, kh, kw, cin, _stream())
             radd = _take_deferred(x4) if ctx.take_deferred else None     # parked residual gradient of x: + in the epilogue
             if radd is not None:
                 radd = radd.reshape(-1, cin)
-            dx4 = _conv_fwd_raw(dy4, wd, None, radd, cin, kh, kw, kh - 1 - ph, kw - 1 - pw, alpha, False)
+            if _halo_ok(oh, ow, cout, cin, kh, kw, kh - 1 - ph, kw - 1 - pw):
+                # data gradient on the halo kernel: flipped weights in fragment order; a single bf16 product under
+                # precision mode 3 (csrc/focr_core.hip), split products otherwise
+                wf = _frag_weights(weight, wk, cout, kh, kw, cin, True)
+                dx4 = _conv_fwd_raw(dy4, None, None, radd, cin, kh, kw, 1, 1, alpha, False, frag=wf,
+                                    planes=1 if _lib.get_precision() == 3 else 2)
+            else:
+                persistent = weight.is_leaf and wk.data_ptr() == weight.data_ptr()
+                wd = FLIPS.lookup(wk, cout, kh, kw, cin, not weight.requires_grad) \
+                    if (FLIPS is not None and persistent) else None
+                if wd is None:
+                    wd = torch.empty(wk.numel(), device=dy.device, dtype=torch.float32)
+                    _lib.call("focr_weight_flip_transpose", _p(wk), _p(wd), cout, kh, kw, cin, _stream())
+                dx4 = _conv_fwd_raw(dy4, wd, None, radd, cin, kh, kw, kh - 1 - ph, kw - 1 - pw, alpha, False)
             dx = dx4 if len(ctx.x_shape) == 4 else dx4.reshape(ctx.x_shape)
         if not ctx.needs_input_grad[1] and has_bias and ctx.needs_input_grad[2]:      # bias gradient alone
             db = tb if tb is not None else torch.empty(cout, device=dy.device, dtype=torch.float32)

@@ -37,8 +37,10 @@ typedef void* focr_stream_t; /* hipStream_t */
 const char* focr_last_error(void);
 int focr_version(void);
 /* contraction precision of the kernels that have both paths (process-wide):
- *   0 = exact fp32 on the f32-input MFMA; 1 (default) = split bf16 "bf16x3" (hi/lo operands, 3 products,
- *   fp32 accumulate) on the bf16 MFMA pipe -- same end-to-end error as fp32 (tools/exp_split_precision.py) */
+ *   0 = exact fp32 on the f32-input MFMA; 1 = split bf16 "bf16x3" (hi/lo operands, 3 products, fp32 accumulate) on the
+ *   bf16 MFMA pipe -- same end-to-end error as fp32 (tools/exp_split_precision.py); 2 (default) = 1 with single-bf16
+ *   gradient accumulations in the attention backward; 3 = 2 with single-bf16 data-gradient convolutions on the halo
+ *   kernel.  Forward results are identical in modes 1-3 (csrc/focr_core.hip). */
 int focr_set_precision(int mode);
 int focr_get_precision(void);
 
@@ -77,6 +79,31 @@ typedef struct focr_flip_desc {
   int cout, kh, kw, cin;
 } focr_flip_desc;
 int focr_weight_flip_transpose_batched(const void* descs_dev, int n, int max_elems, focr_stream_t stream);
+
+/* ---- 3x3 / pad 1 convolution with the input tile resident in LDS ("halo" kernel, csrc/conv3x3_halo.hip) --------
+ * Same layers as focr_conv2d_fwd when KH = KW = 3, pad 1, Cin % 64 == 0, Cout % 64 == 0: SRB conv1/conv2 and block7
+ * (model/tbsrn.py:232-251, model/tsrn.py:77-98), the upsample conv (model/tsrn.py:104-114), the CRNN body
+ * (model/crnn/crnn.py:31-63) and their data gradients.  The weights are consumed PRE-SPLIT (bf16 hi/lo planes) and in
+ * MFMA-fragment order: focr_weight_prep_frag* produce that form once per weight update --
+ *   piece (n / 32, k / 16, plane) = 1 KB, lane 32 * ((k >> 3) & 1) + (n & 31) holds k & 7 (8 bf16);
+ *   flip = 0: rows n = Cout, k = (kh, kw, ci)       (forward);
+ *   flip = 1: rows n = Cin,  k = (KH-1-kh, KW-1-kw, co)  (data gradient: the call below on dy with Cin/Cout swapped).
+ * focr_weight_frag_bytes(rows, k): size of that buffer.  planes = 2: split products (fp32-equivalent); 1: single bf16.
+ * stats (nullable): float [focr_conv3x3_frag_tiles(N,H,W)][Cout][2] per-tile (sum, sum of squares) of the stored
+ * outputs, for the BatchNorm that follows (model/tbsrn.py:234,237; folded by focr_bn_train_fwd_stats). */
+long focr_weight_frag_bytes(int rows, int k);
+int focr_weight_prep_frag(const float* w, void* wfrag, int Cout, int KH, int KW, int Cin, int flip,
+                          focr_stream_t stream);
+typedef struct focr_wprep_desc {
+  const float* w; /* [Cout][KH][KW][Cin] */
+  void* wfrag;
+  int cout, kh, kw, cin, flip, pad_;
+} focr_wprep_desc;
+int focr_weight_prep_frag_batched(const void* descs_dev, int n, long max_threads, focr_stream_t stream);
+int focr_conv3x3_frag_tiles(int N, int H, int W);
+int focr_conv3x3_frag_fwd(const float* x, const void* wfrag, const float* bias, const float* residual, float* y,
+                          float* stats, int N, int H, int W, int Cin, int Cout, float alpha, int relu, int planes,
+                          int ldy, int ldr, int ldx, focr_stream_t stream);
 /* out[c] = sum_r x[r*ld + c]   (bias gradients) */
 int focr_colsum(const float* x, float* out, long rows, int C, int ld, focr_stream_t stream);
 /* specialised 9x9, pad 4, Cin=64 -> Cout<=3|4 convolution (SR output layer, model/tsrn.py:43):
