@@ -28,6 +28,7 @@ SIGNATURES = {
     "focr_attention_fwd": [P, P, P, P, P, P, I, I, I, I, I, F, F, U, P],
     "focr_attention_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, F, P],
     "focr_bn_train_fwd": [P, P, P, P, P, P, P, P, P, P, P, L, I, F, F, I, P],
+    "focr_bn_train_fwd_stats": [P, P, I, P, P, P, P, P, P, P, P, P, L, I, F, F, I, P],
     "focr_bn_eval_fwd": [P, P, P, P, P, P, P, P, L, I, F, I, P],
     "focr_bn_bwd": [P, P, P, P, P, P, P, P, P, P, L, I, I, I, P],
     "focr_layernorm_fwd": [P, P, P, P, P, P, P, L, I, F, P],
@@ -52,6 +53,7 @@ SIGNATURES = {
     "focr_maxpool_bwd": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "focr_tps_fwd": [P, P, P, P, P, P, I, I, I, I, I, P],
     "focr_tps_bwd": [P, P, P, P, P, P, I, I, I, I, I, P],
+    "focr_tps_bwd_img": [P, P, P, I, I, I, I, P],
     "focr_bicubic_gray_fwd": [P, P, I, I, I, I, I, P],
     "focr_bicubic_gray_bwd": [P, P, I, I, I, I, I, P],
     "focr_lstm_bidir_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, P],

@@ -10,6 +10,10 @@
 // sequential; alpha_{t-1}(s-1), alpha_{t-1}(s-2) come from LDS.  The gradient uses
 //   d nll / d logit[t][c] = softmax[t][c] - sum_{s: ext(s)=c} exp(alpha_t(s)+beta_t(s)-lp[t][c]-ll)
 // and is already scaled by 1/(L*B) ('mean' reduction); infeasible samples give loss 0, grad 0.
+// Limits: T <= 64, C <= 64 (checked on the host) and label length L <= 31 (S = 2L+1 <= 64 lanes): lengths live on the
+// device, so the kernel treats a longer label as infeasible (loss 0, gradient 0 -- never an out-of-range LDS access);
+// the Python wrapper (loss/ctc_focus_loss.py encode) rejects such labels while they are still host data.
+// The batch loss is reduced in a fixed order by ctc_reduce_kernel: bit-identical run to run (no atomics).
 #include "focr_common.h"
 
 #define CTC_TMAX 64
@@ -24,7 +28,7 @@ __global__ __launch_bounds__(64) void ctc_kernel(const float* __restrict__ logit
                                                  const int* __restrict__ targets,    // [sum L]
                                                  const int* __restrict__ tlen,       // [B]
                                                  const int* __restrict__ toff,       // [B]
-                                                 float* __restrict__ loss_sum,       // [1] += nll/L/B
+                                                 float* __restrict__ loss_sum,       // [1] (written by ctc_reduce_kernel)
                                                  float* __restrict__ nll_out,        // [B] raw nll
                                                  float* __restrict__ grad,           // [T,B,C]
                                                  int T, int B, int C) {
@@ -33,7 +37,9 @@ __global__ __launch_bounds__(64) void ctc_kernel(const float* __restrict__ logit
   __shared__ float bet[2][64];
   __shared__ float occ[64];
   const int b = blockIdx.x, s = threadIdx.x;
-  const int L = tlen[b];
+  const int Lraw = tlen[b];
+  const bool too_long = Lraw > 31 || Lraw < 0;      // would not fit the 64-lane lattice: handled as infeasible
+  const int L = too_long ? 0 : Lraw;
   const int S = 2 * L + 1;
   const int off = toff[b];
   // extended label of this lane
@@ -75,12 +81,9 @@ __global__ __launch_bounds__(64) void ctc_kernel(const float* __restrict__ logit
   }
   float ll = alpha[T - 1][S - 1];
   if (S > 1) ll = lse2(ll, alpha[T - 1][S - 2]);
-  const bool feasible = ll > -1e29f;
+  const bool feasible = ll > -1e29f && !too_long;
   const float norm = 1.f / ((float)(L > 0 ? L : 1) * (float)B);
-  if (s == 0) {
-    nll_out[b] = feasible ? -ll : 0.f;
-    if (feasible) atomicAdd(loss_sum, -ll * norm);
-  }
+  if (s == 0) nll_out[b] = feasible ? -ll : 0.f;      // summed in fixed order by ctc_reduce_kernel
   // ---- beta + gradient ----
   int cur = 0;
   {
@@ -117,6 +120,18 @@ __global__ __launch_bounds__(64) void ctc_kernel(const float* __restrict__ logit
   }
 }
 
+// loss = sum_b nll[b] / (max(L_b, 1) * B): lane i adds samples i, i + 64, ... in order, then a fixed shuffle tree
+__global__ __launch_bounds__(64) void ctc_reduce_kernel(const float* __restrict__ nll, const int* __restrict__ tlen,
+                                                        float* __restrict__ loss, int B) {
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < B; b += 64) {
+    const int L = tlen[b];
+    acc += nll[b] / ((float)((L > 0 && L <= 31) ? L : 1) * (float)B);
+  }
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) loss[0] = acc;
+}
+
 __global__ void scale_dev_kernel(const float* __restrict__ x, const float* __restrict__ sc, float* __restrict__ y,
                                  long n) {
   const float k = sc[0];
@@ -128,12 +143,9 @@ extern "C" int focr_ctc_fwd(const float* logits, const int* targets, const int* 
                             int B, int C, hipStream_t stream) {
   FOCR_CHECK_ARG(logits && targets && target_lengths && target_offsets && loss && nll && grad_logits, "null pointer");
   FOCR_CHECK_ARG(T > 0 && T <= CTC_TMAX && C > 1 && C <= 64 && B > 0, "need T <= 64, C <= 64");
-  if (hipMemsetAsync(loss, 0, sizeof(float), stream) != hipSuccess) {
-    focr_set_error("focr_ctc_fwd: memset failed");
-    return FOCR_EHIP;
-  }
   hipLaunchKernelGGL(ctc_kernel, dim3(B), 64, 0, stream, logits, targets, target_lengths, target_offsets, loss, nll,
                      grad_logits, T, B, C);
+  hipLaunchKernelGGL(ctc_reduce_kernel, dim3(1), 64, 0, stream, (const float*)nll, target_lengths, loss, B);
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }

@@ -638,6 +638,65 @@ extern "C" int focr_bn_train_fwd(const float* x, const float* gamma, const float
   return FOCR_OK;
 }
 
+// Batch statistics from per-tile partial sums produced by the convolution that wrote x (focr_conv3x3_frag_fwd's
+// `stats` output: part[tile][C][2] = (sum, sum of squares) of that tile's outputs): no pass over x for the statistics.
+// One block per channel; every thread adds its tiles in double precision, then a fixed-order LDS tree: deterministic.
+// var = E[x^2] - mean^2 evaluated in double on fp32 partials of <= 128 values each.
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ part, int nparts,
+                                                                float* __restrict__ save_mean,
+                                                                float* __restrict__ save_invstd,
+                                                                float* __restrict__ rmean, float* __restrict__ rvar,
+                                                                long long* nbt, long rows, int C, float momentum,
+                                                                float eps) {
+  __shared__ double r1[256], r2[256];
+  const int c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int j = threadIdx.x; j < nparts; j += 256) {
+    const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)j * C + c) * 2);
+    s1 += (double)v.x;
+    s2 += (double)v.y;
+  }
+  r1[threadIdx.x] = s1;
+  r2[threadIdx.x] = s2;
+  __syncthreads();
+#pragma unroll
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) {
+      r1[threadIdx.x] += r1[threadIdx.x + w];
+      r2[threadIdx.x] += r2[threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double mean = r1[0] / (double)rows;
+    double var = r2[0] / (double)rows - mean * mean;
+    if (var < 0.0) var = 0.0;
+    save_mean[c] = (float)mean;
+    save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) {
+      const float unb = (float)(rows > 1 ? var * ((double)rows / (double)(rows - 1)) : var);
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+    }
+    if (c == 0 && nbt) *nbt += 1;
+  }
+}
+
+extern "C" int focr_bn_train_fwd_stats(const float* x, const float* part, int nparts, const float* gamma,
+                                       const float* beta, float* running_mean, float* running_var, long long* nbt,
+                                       const float* residual, float* y, float* save_mean, float* save_invstd,
+                                       long rows, int C, float momentum, float eps, int act, hipStream_t stream) {
+  FOCR_CHECK_ARG(x && part && gamma && beta && y && save_mean && save_invstd, "null pointer");
+  FOCR_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0 && nparts > 0, "need C % 4 == 0, nparts > 0");
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), 256, 0, stream, part, nparts, save_mean, save_invstd,
+                     running_mean, running_var, nbt, rows, C, momentum, eps);
+  long total4 = rows * C / 4;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total4)), 256, 0, stream, x, gamma, beta,
+                     (const float*)save_mean, (const float*)save_invstd, residual, y, total4, C, act);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+
 // eval: normalise with running stats; invstd_out: C floats (kept for the backward)
 extern "C" int focr_bn_eval_fwd(const float* x, const float* gamma, const float* beta,
                                 const float* running_mean, const float* running_var,

@@ -344,6 +344,47 @@ extern "C" int focr_tps_fwd(const float* img, const float* ctrl, const float* in
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }
+// d loss / d image of the bilinear sampling (F.grid_sample backward w.r.t. its input, zeros padding,
+// tps_spatial_transformer.py:10-18): every output pixel scatters its gradient to the four cells it read.
+// dimg must be zeroed by the caller (focr_tps_bwd_img does it); fp32 atomics (the image has 3-4 channels).
+__global__ __launch_bounds__(256) void tps_bwd_img_kernel(const float* __restrict__ dout,   // [B,H,W,C]
+                                                          const float* __restrict__ src,    // [B,H*W,2]
+                                                          float* __restrict__ dimg,         // [B,H,W,C]
+                                                          int H, int W, int C) {
+  const int b = blockIdx.x;
+  float* di = dimg + (size_t)b * H * W * C;
+  for (int p = threadIdx.x; p < H * W; p += blockDim.x) {
+    const float sx = src[((size_t)b * H * W + p) * 2], sy = src[((size_t)b * H * W + p) * 2 + 1];
+    const float gx = fminf(fmaxf(sx, 0.f), 1.f) * 2.f - 1.f;
+    const float gy = fminf(fmaxf(sy, 0.f), 1.f) * 2.f - 1.f;
+    const float fx = ((gx + 1.f) * W - 1.f) * 0.5f, fy = ((gy + 1.f) * H - 1.f) * 0.5f;
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float tx = fx - x0f, ty = fy - y0f;
+    const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
+    const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
+    for (int c = 0; c < C; ++c) {
+      const float g = dout[((size_t)b * H * W + p) * C + c];
+      if (vx0 && vy0) atomicAdd(&di[((size_t)y0 * W + x0) * C + c], g * (1.f - tx) * (1.f - ty));
+      if (vx1 && vy0) atomicAdd(&di[((size_t)y0 * W + x0 + 1) * C + c], g * tx * (1.f - ty));
+      if (vx0 && vy1) atomicAdd(&di[((size_t)(y0 + 1) * W + x0) * C + c], g * (1.f - tx) * ty);
+      if (vx1 && vy1) atomicAdd(&di[((size_t)(y0 + 1) * W + x0 + 1) * C + c], g * tx * ty);
+    }
+  }
+}
+
+extern "C" int focr_tps_bwd_img(const float* dout, const float* src, float* dimg, int B, int H, int W, int C,
+                                hipStream_t stream) {
+  FOCR_CHECK_ARG(dout && src && dimg && B > 0 && H > 0 && W > 0 && C > 0, "bad argument");
+  if (hipMemsetAsync(dimg, 0, sizeof(float) * (size_t)B * H * W * C, stream) != hipSuccess) {
+    focr_set_error("focr_tps_bwd_img: memset failed");
+    return FOCR_EHIP;
+  }
+  hipLaunchKernelGGL(tps_bwd_img_kernel, dim3(B), 256, 0, stream, dout, src, dimg, H, W, C);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+
 extern "C" int focr_tps_bwd(const float* dout, const float* img, const float* src, const float* inv_kernel,
                             const float* coord_repr, float* dctrl, int B, int H, int W, int C, int NC,
                             hipStream_t stream) {

@@ -226,7 +226,7 @@ class FragTable:
         rows, k = (cin, kh * kw * cout) if flip else (cout, kh * kw * cin)
         e.buf = torch.empty(_lib.load().focr_weight_frag_bytes(rows, k), device=wk.device, dtype=torch.uint8)
         e.geom, e.ptr, e.version, e.epoch = geom, wk.data_ptr(), weight._version, WEIGHT_EPOCH
-        e.ref = weakref.ref(weight) if cacheable else (lambda: None)
+        e.ref = weakref.ref(weight, lambda _r, key=key: self.entries.pop(key, None)) if cacheable else (lambda: None)
         e.managed = bool(self.managed and cacheable and weight.requires_grad)
         self._prep(e, wk, flip)
         if cacheable:
@@ -325,7 +325,9 @@ class _Conv2d(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, pad, alpha, relu, drop_p=0.0, take_deferred=False,
-                defer_residual=False):
+                defer_residual=False, want_stats=False):
+        """want_stats (halo-kernel layers only): also returns the per-tile (sum, sum of squares) partials of y
+        [tiles, Cout, 2] for a following train-mode BatchNorm (non-differentiable second output)."""
         cout = weight.shape[0]
         ctx.take_deferred, ctx.defer_residual = bool(take_deferred), bool(defer_residual)
         ctx.res_key = _dkey(residual) if (residual is not None and defer_residual) else None
@@ -353,17 +355,25 @@ class _Conv2d(torch.autograd.Function):
                       float(alpha), float(drop_p), _new_seed(), ctypes.byref(ks), _stream())
             ctx.drop_scale = float(ks.value)
         else:
-            frag = None
+            frag = stats = None
             if _halo_ok(x4.shape[1], x4.shape[2], x4.shape[3], cout, kh, kw, ph, pw):
                 frag = _frag_weights(weight, wk, cout, kh, kw, x4.shape[3], False)
-            y = _conv_fwd_raw(x4, wk, bias, res4, cout, kh, kw, ph, pw, alpha, relu, frag=frag)
+                if want_stats:
+                    tiles = _lib.load().focr_conv3x3_frag_tiles(x4.shape[0], x4.shape[1], x4.shape[2])
+                    stats = torch.empty((tiles, cout, 2), device=x4.device, dtype=torch.float32)
+            elif want_stats:
+                raise RuntimeError("want_stats needs a halo-kernel layer (conv_bn checks eligibility)")
+            y = _conv_fwd_raw(x4, wk, bias, res4, cout, kh, kw, ph, pw, alpha, relu, frag=frag, stats=stats)
         ctx.geom = (kh, kw, ph, pw, float(alpha), bool(relu), bias is not None, residual is not None)
         ctx.targets = (_target(weight), _target(bias))
         ctx.save_for_backward(x4, weight, y if relu else None)
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            return y, stats
         return y if x.dim() == 4 else y.reshape(*lead, cout)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_unused):
         x4, weight, y = ctx.saved_tensors
         kh, kw, ph, pw, alpha, relu, has_bias, has_res = ctx.geom
         n, h, w, cin = x4.shape
@@ -445,7 +455,7 @@ class _Conv2d(torch.autograd.Function):
             dw = None
         if tb is not None:
             db = None
-        return dx, dw, db, dres, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias=None, pad=(0, 0), residual=None, alpha=1.0, relu=False, take_deferred=False):
@@ -465,12 +475,19 @@ def linear(x, weight, bias=None, residual=None, alpha=1.0, relu=False, dropout=0
 # ----------------------------------------------------------------------------------------
 class _BatchNormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, rmean, rvar, nbt, residual, training, act, momentum, eps):
+    def forward(ctx, x, gamma, beta, rmean, rvar, nbt, residual, training, act, momentum, eps, stats=None):
         c = x.shape[-1]
         rows = x.numel() // c
         _chk(x, gamma, beta, rmean, rvar, residual)
         y = torch.empty_like(x)
-        if training:
+        if training and stats is not None:
+            # batch statistics from the producing convolution's per-tile partial sums: no statistics pass over x
+            mean = torch.empty(c, device=x.device)
+            invstd = torch.empty(c, device=x.device)
+            _lib.call("focr_bn_train_fwd_stats", _p(x), _p(stats), stats.shape[0], _p(gamma), _p(beta), _p(rmean),
+                      _p(rvar), _p(nbt), _p(residual), _p(y), _p(mean), _p(invstd), rows, c, float(momentum),
+                      float(eps), act, _stream())
+        elif training:
             mean = torch.empty(c, device=x.device)
             invstd = torch.empty(c, device=x.device)
             ws = torch.empty(_lib.load().focr_bn_ws_floats(rows, c), device=x.device)
@@ -506,12 +523,30 @@ class _BatchNormAct(torch.autograd.Function):
         else:
             _lib.call("focr_bn_bwd", _p(dz), _p(x), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(dx), _NULL,
                       _NULL, _NULL, rows, c, act, 0, _stream())
-        return dx, dg, db, None, None, None, (dz if has_res else None), None, None, None, None
+        return dx, dg, db, None, None, None, (dz if has_res else None), None, None, None, None, None
 
 
 def batchnorm_act(x, gamma, beta, rmean, rvar, nbt, training, act=ACT_NONE, residual=None,
-                  momentum=0.1, eps=1e-5):
-    return _BatchNormAct.apply(x, gamma, beta, rmean, rvar, nbt, residual, training, act, momentum, eps)
+                  momentum=0.1, eps=1e-5, stats=None):
+    return _BatchNormAct.apply(x, gamma, beta, rmean, rvar, nbt, residual, training, act, momentum, eps, stats)
+
+
+def conv_bn(x, conv, bn, act=ACT_NONE, residual=None, take_deferred=False):
+    """act(bn(conv(x))) [+ residual] for a Conv2d / BatchNorm2d module pair (tbsrn.py:246-249, tsrn.py:89-93).  In
+    training mode on a halo-kernel layer the convolution's epilogue emits the per-tile sums the BatchNorm needs, so
+    the two statistics passes over the conv output disappear."""
+    training = bn.training or not bn.track_running_stats
+    w = conv.weight
+    kh, kw = w.shape[2], w.shape[3]
+    stats = None
+    if training and x.is_cuda and x.dim() == 4 and _halo_ok(x.shape[1], x.shape[2], x.shape[3], w.shape[0], kh, kw,
+                                                            conv.padding[0], conv.padding[1]):
+        y, stats = _Conv2d.apply(x, w, conv.bias, None, conv.padding, 1.0, False, 0.0, take_deferred, False, True)
+    else:
+        y = _Conv2d.apply(x, w, conv.bias, None, conv.padding, 1.0, False, 0.0, take_deferred, False)
+    return batchnorm_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                         bn.num_batches_tracked if training else None, training, act=act, residual=residual,
+                         momentum=bn.momentum, eps=bn.eps, stats=stats)
 
 
 # ----------------------------------------------------------------------------------------
@@ -879,8 +914,8 @@ def maxpool(x, kernel, stride=None, pad=(0, 0)):
 
 
 class _TPSWarp(torch.autograd.Function):
-    """TPS grid + bilinear sampling of an NHWC image; gradient flows to the control points only
-    (the warped tensor is the input image -- nothing trainable lies upstream of it)."""
+    """TPS grid + bilinear sampling of an NHWC image; gradients for the control points and -- when the image itself
+    requires one (d loss / d LR image, F.grid_sample's input gradient) -- for the image."""
 
     @staticmethod
     def forward(ctx, img, ctrl, inv_kernel, coord_repr):
@@ -904,7 +939,11 @@ class _TPSWarp(torch.autograd.Function):
         dctrl = torch.empty((b, nc, 2), device=dout.device)
         _lib.call("focr_tps_bwd", _p(dout), _p(img), _p(src), _p(inv_kernel), _p(coord_repr), _p(dctrl), b, h,
                   w, c, nc, _stream())
-        return None, dctrl, None, None
+        dimg = None
+        if ctx.needs_input_grad[0]:
+            dimg = torch.empty_like(img)
+            _lib.call("focr_tps_bwd_img", _p(dout), _p(src), _p(dimg), b, h, w, c, _stream())
+        return dimg, dctrl, None, None
 
 
 def tps_warp(img, ctrl, inv_kernel, coord_repr):

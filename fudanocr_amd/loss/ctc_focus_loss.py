@@ -16,8 +16,14 @@ class CTCFocusLoss(nn.Module):
         self.recognizer = [recognizer]          # not registered: stays out of state_dict/parameters
         self.converter = strLabelConverter(alphabet)
 
+    MAX_LABEL_LEN = 31      # csrc/ctc.hip: one lane per extended-label position, 2L+1 <= 64
+
     def encode(self, label_strs, device):
         t, l = self.converter.encode(list(label_strs))
+        if int(l.max()) > self.MAX_LABEL_LEN:
+            raise ValueError("CTC label longer than %d characters (the CTC kernel's lattice is one 64-lane wave); "
+                             "filter such samples in the data pipeline (reference max_len semantics, "
+                             "dataset/dataset.py:107-131)" % self.MAX_LABEL_LEN)
         return t.to(device), l.to(device)
 
     def forward(self, sr_img, hr_img, label_strs=None, encoded=None):

@@ -151,8 +151,8 @@ class RecurrentResidualBlock(nn.Module):
 
     def forward(self, x):
         g = torch.is_grad_enabled() and x.requires_grad
-        r = self.bn1(self.conv1(x, take_deferred=g), act=K.ACT_MISH)
-        r = self.bn2(self.conv2(r))
+        r = K.conv_bn(x, self.conv1, self.bn1, act=K.ACT_MISH, take_deferred=g)
+        r = K.conv_bn(r, self.conv2, self.bn2)
         n, h, w, c = r.shape
         out = self.feature_enhancer(r.view(n, h * w, c), residual=x.view(n, h * w, c), defer_block_input=g)
         return out.view(n, h, w, c)
@@ -209,6 +209,6 @@ class TBSRN(nn.Module):
         for i in range(self.srb_nums):
             h = getattr(self, "block%d" % (i + 2))(h)
         tail7 = getattr(self, "block%d" % (self.srb_nums + 2))
-        h = tail7[1](tail7[0](h), residual=b1)                 # block1 + block7
+        h = K.conv_bn(h, tail7[0], tail7[1], residual=b1)      # block1 + block7
         h = getattr(self, "block%d" % (self.srb_nums + 3))(h)
         return K.to_nchw(h, tanh=True)

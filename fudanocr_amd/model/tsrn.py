@@ -50,8 +50,8 @@ class RecurrentResidualBlock(nn.Module):
         self.gru2 = GruBlock(channels, channels)
 
     def forward(self, x):
-        r = self.bn1(self.conv1(x), act=K.ACT_MISH)
-        r = self.bn2(self.conv2(r))
+        r = K.conv_bn(x, self.conv1, self.bn1, act=K.ACT_MISH)
+        r = K.conv_bn(r, self.conv2, self.bn2)
         r = self.gru1(r, vertical=True)
         return self.gru2(K.add(x, r))
 
@@ -89,6 +89,6 @@ class TSRN(nn.Module):
         for i in range(self.srb_nums):
             h = getattr(self, "block%d" % (i + 2))(h)
         tail7 = getattr(self, "block%d" % (self.srb_nums + 2))
-        h = tail7[1](tail7[0](h), residual=b1)
+        h = K.conv_bn(h, tail7[0], tail7[1], residual=b1)
         h = getattr(self, "block%d" % (self.srb_nums + 3))(h)
         return K.to_nchw(h, tanh=True)

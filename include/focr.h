@@ -136,6 +136,12 @@ int focr_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
                       float* running_var, long long* num_batches_tracked, const float* residual,
                       float* y, float* save_mean, float* save_invstd, float* ws, long rows, int C,
                       float momentum, float eps, int act, focr_stream_t stream);
+/* train-mode forward with the batch statistics taken from per-tile partial sums written by the producing convolution
+ * (focr_conv3x3_frag_fwd `stats`: part[nparts][C][2] = (sum, sum of squares)): no statistics pass over x. */
+int focr_bn_train_fwd_stats(const float* x, const float* part, int nparts, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, long long* num_batches_tracked,
+                            const float* residual, float* y, float* save_mean, float* save_invstd, long rows, int C,
+                            float momentum, float eps, int act, focr_stream_t stream);
 int focr_bn_eval_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean,
                      const float* running_var, const float* residual, float* y, float* invstd_out,
                      long rows, int C, float eps, int act, focr_stream_t stream);
@@ -192,6 +198,11 @@ int focr_tps_fwd(const float* img, const float* ctrl, const float* inv_kernel, c
 int focr_tps_bwd(const float* dout, const float* img, const float* src, const float* inv_kernel,
                  const float* coord_repr, float* dctrl, int B, int H, int W, int C, int NC,
                  focr_stream_t stream);
+/* gradient of the same warp w.r.t. the sampled image (F.grid_sample backward w.r.t. input,
+ * model/tps_spatial_transformer.py:10-18): dimg[B,H,W,C] is overwritten; src = the sampling coordinates focr_tps_fwd
+ * saved. */
+int focr_tps_bwd_img(const float* dout, const float* src, float* dimg, int B, int H, int W, int C,
+                     focr_stream_t stream);
 /* parse_crnn_data: interfaces/base.py:319-325 ; x NCHW [B,Cx>=3,H,IW] -> y [B,H,OW] */
 int focr_bicubic_gray_fwd(const float* x_nchw, float* y, int B, int Cx, int H, int IW, int OW,
                           focr_stream_t stream);

@@ -30,7 +30,7 @@ def close(got, ref, tol=2e-5, what=""):
     assert err <= lim, "%s: max abs err %.3e > %.3e (ref max %.3e)" % (what, err, lim, ref.abs().max().item())
 
 
-@pytest.fixture(params=[0, 1, 2], ids=["fp32", "bf16x3", "bf16x3-fastgrad"])
+@pytest.fixture(params=[0, 1, 2, 3], ids=["fp32", "bf16x3", "bf16x3-fastgrad", "bf16x3-dgrad16"])
 def precision(request):
     """run a test under both contraction precisions of the MFMA kernels that have two paths"""
     from fudanocr_amd import _lib
@@ -46,8 +46,18 @@ def ptol(precision, base=2e-5):
 
 
 def gtol(precision):
-    """attention input gradients: mode 2 accumulates dV/dK/dQ with single bf16 products (2^-9 per term)"""
-    return 3e-3 if precision == 2 else ptol(precision)
+    """attention input gradients: modes 2/3 accumulate dV/dK/dQ with single bf16 products (2^-9 per term)"""
+    return 3e-3 if precision >= 2 else ptol(precision)
+
+
+def dtol(precision, halo):
+    """conv data gradients: mode 3 contracts dy and the weights as single bf16 on the halo-kernel layers"""
+    return 4e-3 if (precision == 3 and halo) else ptol(precision)
+
+
+def is_halo(h, w, cin, cout, kh, kw, ph, pw):
+    return (kh == 3 and kw == 3 and ph == 1 and pw == 1 and cin % 64 == 0 and cout % 64 == 0
+            and 2 * h * w >= ((h + 3) // 4 * 4) * ((w + 31) // 32 * 32))
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -76,6 +86,10 @@ CONV_CASES = [
     (70, 5, 36, 64, 128, 3, 3, 1, 1),     # streaming 3x3 wgrad: W < 64, several images per row range, ragged rows
     (300, 1, 8, 64, 64, 3, 3, 1, 1),      # streaming 3x3 wgrad: one-row images (every row is an image boundary)
     (3, 40, 64, 64, 64, 3, 3, 1, 1),      # streaming 3x3 wgrad: fewer row blocks than CUs, tall images
+    (8, 16, 50, 64, 128, 3, 3, 1, 1),     # halo kernel: CRNN conv1 shape (W = 50: ragged column tile), XCD tile order
+    (3, 8, 25, 128, 256, 3, 3, 1, 1),     # halo kernel: two input-channel slices, several output groups
+    (2, 4, 26, 256, 64, 3, 3, 1, 1),      # halo kernel: four slices, one row tile
+    (9, 6, 33, 64, 64, 3, 3, 1, 1),       # halo kernel: H % 4 != 0, W = 33 (one valid pixel in the last tile)
 ]
 
 
@@ -94,9 +108,77 @@ def test_conv2d(case, precision):
     yd = K().conv2d(xd, wd, bd, pad=(ph, pw))
     close(yd.permute(0, 3, 1, 2), y, ptol(precision), what="conv fwd")
     yd.backward(dev(gy.permute(0, 2, 3, 1)))
-    close(xd.grad.permute(0, 3, 1, 2), x.grad, ptol(precision), what="conv dgrad")
+    close(xd.grad.permute(0, 3, 1, 2), x.grad, dtol(precision, is_halo(h, w, cout, cin, kh, kw, kh - 1 - ph, kw - 1 - pw)),
+          what="conv dgrad")
     close(wd.grad, wt.grad, ptol(precision, 5e-5), what="conv wgrad")
     close(bd.grad, b.grad, 5e-5, what="conv bias grad")
+
+
+@pytest.mark.parametrize("shape", [(8, 16, 64, 64, 64), (3, 7, 37, 128, 64), (2, 16, 64, 64, 256)])
+def test_halo_conv_c_abi(shape):
+    """focr_conv3x3_frag_fwd through the C ABI: prepared (fragment-ordered, pre-split) weights, both plane counts,
+    fused residual / relu / alpha, the flipped (data-gradient) weight form and the per-tile BatchNorm partial sums."""
+    import ctypes
+    from fudanocr_amd import _lib
+    k = K()
+    n, h, w, cin, cout = shape
+    x = rnd(n, cin, h, w, seed=1)
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=1 / math.sqrt(9 * cin))
+    b = rnd(cout, seed=3)
+    r = rnd(n, cout, h, w, seed=4)
+    ref = F.relu(0.5 * F.conv2d(x, wt, None, padding=1) + b.view(1, -1, 1, 1) + r)
+    xd, rd, bd = dev(x.permute(0, 2, 3, 1)), dev(r.permute(0, 2, 3, 1)), dev(b)
+    wd = dev(wt.permute(0, 2, 3, 1))                       # OHWI
+    lib = _lib.load()
+    wf = torch.empty(lib.focr_weight_frag_bytes(cout, 9 * cin), dtype=torch.uint8, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())           # noqa: E731
+    _lib.call("focr_weight_prep_frag", vp(wd), vp(wf), cout, 3, 3, cin, 0, st)
+    tiles = lib.focr_conv3x3_frag_tiles(n, h, w)
+    for planes, tol in ((2, 1e-4), (1, 4e-3)):
+        y = torch.full((n, h, w, cout), float("nan"), device="cuda")
+        stats = torch.full((tiles, cout, 2), float("nan"), device="cuda")
+        _lib.call("focr_conv3x3_frag_fwd", vp(xd), vp(wf), vp(bd), vp(rd), vp(y), vp(stats), n, h, w, cin, cout, 0.5, 1,
+                  planes, 0, 0, 0, st)
+        close(y.permute(0, 3, 1, 2), ref, tol, what="halo fwd planes=%d" % planes)
+        yy = y.double().reshape(-1, cout)
+        close(stats[:, :, 0].sum(0), yy.sum(0).float(), 2e-5, what="stats sum")
+        close(stats[:, :, 1].sum(0), (yy * yy).sum(0).float(), 2e-5, what="stats sumsq")
+    # data-gradient form: flip-prepared weights of the SAME layer applied to a gradient with Cout channels
+    gy = rnd(n, cout, h, w, seed=5)
+    xg = x.clone().requires_grad_(True)
+    F.conv2d(xg, wt, None, padding=1).backward(gy)
+    wff = torch.empty(lib.focr_weight_frag_bytes(cin, 9 * cout), dtype=torch.uint8, device="cuda")
+    _lib.call("focr_weight_prep_frag", vp(wd), vp(wff), cout, 3, 3, cin, 1, st)
+    dx = torch.empty((n, h, w, cin), device="cuda")
+    gyd = dev(gy.permute(0, 2, 3, 1))
+    _lib.call("focr_conv3x3_frag_fwd", vp(gyd), vp(wff), None, None, vp(dx), None, n, h, w, cout, cin, 1.0, 0, 2, 0, 0, 0,
+              st)
+    close(dx.permute(0, 3, 1, 2), xg.grad, 1e-4, what="halo dgrad")
+    del k
+
+
+def test_frag_table_tracks_weight_updates():
+    """the cached fragment-ordered weights follow in-place parameter updates (version counter) and engine-style raw
+    updates (WEIGHT_EPOCH), and temporaries are never cached"""
+    k = K()
+    x = dev(rnd(2, 8, 32, 64, seed=1))
+    wt = cl(rnd(64, 64, 3, 3, seed=2, scale=0.05))
+    y0 = k.conv2d(x, wt, None, pad=(1, 1)).detach().clone()
+    with torch.no_grad():
+        wt.mul_(2.0)                                        # bumps the version counter
+    y1 = k.conv2d(x, wt, None, pad=(1, 1)).detach()
+    close(y1, 2 * y0, 1e-4, what="after in-place update")
+    n_before = len(k._FRAGS_DEFAULT.entries)
+    tmp = (wt.detach() * 3.0).contiguous(memory_format=torch.channels_last)   # a temporary: dropped with the tensor
+    y2 = k.conv2d(x, tmp, None, pad=(1, 1))
+    close(y2, 6 * y0, 1e-4, what="temporary weights")
+    del tmp, y2
+    assert len(k._FRAGS_DEFAULT.entries) <= n_before
+    wt.data.mul_(0.5)                                       # raw update: autograd's version counter does not move ...
+    k.bump_weight_epoch()                                   # ... which is what the engine's epoch bump is for
+    y3 = k.conv2d(x, wt, None, pad=(1, 1)).detach()
+    close(y3, y0, 1e-4, what="after epoch bump")
 
 
 def test_conv2d_fused_epilogue(precision):
@@ -596,3 +678,119 @@ def test_attention_packed_qkv(precision):
     close(od, o, ptol(precision), what="packed attn fwd")
     od.backward(dev(go))
     close(qd.grad, qkv.grad, gtol(precision), what="packed attn dqkv")
+
+
+@pytest.mark.parametrize("act", [0, 4])
+def test_conv_bn_fused_statistics(act):
+    """conv -> train-mode BatchNorm with the statistics taken from the convolution's epilogue partial sums
+    (kernels.conv_bn) against F.conv2d + F.batch_norm in float64, forward and all gradients"""
+    from fudanocr_amd.model._layers import BatchNorm2d, Conv2d
+    n, c, h, w = 5, 64, 16, 64
+    x = rnd(n, c, h, w, seed=1).requires_grad_(True)
+    res = rnd(n, c, h, w, seed=2).requires_grad_(True)
+    conv, bn = Conv2d(c, c, 3, padding=1).cuda(), BatchNorm2d(c).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(rnd(c, seed=3).float() + 1.5)
+        bn.bias.copy_(rnd(c, seed=4).float())
+        conv.bias.copy_(rnd(c, seed=5).float() * 3)          # a large mean: E[x^2] - mean^2 must still hold up
+    wt = conv.weight.detach().double().cpu().requires_grad_(True)
+    cb = conv.bias.detach().double().cpu().requires_grad_(True)
+    g, be = bn.weight.detach().double().cpu().requires_grad_(True), bn.bias.detach().double().cpu().requires_grad_(True)
+    rm, rv = torch.zeros(c, dtype=torch.float64), torch.ones(c, dtype=torch.float64)
+    y = F.batch_norm(F.conv2d(x, wt, cb, padding=1), rm, rv, g, be, True, 0.1, 1e-5)
+    if act == 4:
+        y = y * torch.tanh(F.softplus(y))
+    y = y + res
+    gy = rnd(*y.shape, seed=6)
+    y.backward(gy)
+    xd = dev(x.permute(0, 2, 3, 1)).requires_grad_(True)
+    rd = dev(res.permute(0, 2, 3, 1)).requires_grad_(True)
+    yd = K().conv_bn(xd, conv, bn, act=act, residual=rd)
+    close(yd.permute(0, 3, 1, 2), y, 1e-4, what="conv_bn fwd")
+    close(bn.running_mean, rm, 1e-4, what="running mean")
+    close(bn.running_var, rv, 1e-4, what="running var")
+    yd.backward(dev(gy.permute(0, 2, 3, 1)))
+    close(xd.grad.permute(0, 3, 1, 2), x.grad, 2e-4, what="conv_bn dx")
+    close(bn.weight.grad, g.grad, 2e-4, what="dgamma")
+    close(bn.bias.grad, be.grad, 2e-4, what="dbeta")
+    close(conv.weight.grad, wt.grad, 2e-4, what="dw")
+
+
+def test_tps_image_gradient():
+    """d loss / d image of the TPS warp (F.grid_sample backward w.r.t. its input) against the float64 oracle"""
+    from oracle import sr_oracle as O
+    inv, rep, ctrl0 = O.tps_constants()
+    g = torch.Generator().manual_seed(5)
+    ctrl = ctrl0[None].repeat(2, 1, 1).double()
+    ctrl[0] = O.stn_fc2_bias().view(20, 2).double()
+    ctrl[1] += (torch.rand(20, 2, generator=g, dtype=torch.float64) - 0.5) * 0.3
+    img = torch.rand(2, 3, 16, 64, generator=g, dtype=torch.float64).requires_grad_(True)
+    P = {"tps.inverse_kernel": inv.double(), "tps.target_coordinate_repr": rep.double(),
+         "tps.padding_matrix": torch.zeros(3, 2, dtype=torch.float64)}
+    out = O.tps_warp(P, img, ctrl)
+    gout = rnd(*out.shape, seed=4)
+    out.backward(gout)
+    idv = dev(img.permute(0, 2, 3, 1)).requires_grad_(True)
+    od = K().tps_warp(idv, dev(ctrl), dev(inv), dev(rep))
+    od.backward(dev(gout.permute(0, 2, 3, 1)))
+    # the fp32 sampling coordinate (23-term dot product, then x 64 pixels) is good to ~1e-4 pixel: weights move by that
+    close(idv.grad.permute(0, 3, 1, 2), img.grad, 1e-3, what="tps d image")
+
+
+def test_ctc_long_label_and_determinism():
+    """labels beyond the kernel's 31-character lattice are refused on the host and, if they reach the kernel anyway,
+    handled as infeasible (loss 0, gradient 0, no out-of-range access); the batch loss is bit-identical run to run"""
+    from fudanocr_amd.loss.ctc_focus_loss import CTCFocusLoss
+    crit = CTCFocusLoss(None)
+    with pytest.raises(ValueError):
+        crit.encode(["a" * 32, "abc"], "cuda")
+    t, c = 26, 37
+    labels = ["abc", "b" * 40, "hello"]
+    tgt = torch.tensor([ord(ch) - ord("a") + 11 for s_ in labels for ch in s_], dtype=torch.int32)
+    tlen = torch.tensor([len(s_) for s_ in labels], dtype=torch.int32)
+    logits = dev(rnd(t, len(labels), c, seed=1, scale=3)).requires_grad_(True)
+    out = K().ctc_loss(logits, tgt.cuda(), tlen.cuda())
+    out.backward()
+    assert torch.isfinite(out) and torch.isfinite(logits.grad).all()
+    assert torch.all(logits.grad[:, 1] == 0)
+    ok = [0, 2]
+    sub_t = torch.tensor([ord(ch) - ord("a") + 11 for i in ok for ch in labels[i]], dtype=torch.int32)
+    sub = K().ctc_loss(logits.detach()[:, ok].contiguous(), sub_t.cuda(), tlen[ok].cuda())
+    close(out * 3, sub * 2, what="long label contributes zero")
+    big = dev(rnd(t, 128, c, seed=2, scale=3))
+    tg = torch.randint(1, 37, (128 * 7,), dtype=torch.int32, generator=torch.Generator().manual_seed(3)).cuda()
+    tl = torch.full((128,), 7, dtype=torch.int32).cuda()
+    vals = {K().ctc_loss(big, tg, tl).item() for _ in range(5)}
+    assert len(vals) == 1, vals
+
+
+def test_attention_tiny_dropout_probability():
+    """a dropout probability below the 1/4096 quantisation step means 'no dropout' (not 'drop everything')"""
+    q, k_, v = (dev(rnd(1, 256, 128, seed=i)) for i in (1, 2, 3))
+    o0 = K().attention(q, k_, v, 4, 0.0)
+    o1 = K().attention(q, k_, v, 4, 1e-5)
+    assert torch.equal(o0, o1)
+    with pytest.raises(RuntimeError):
+        K().attention(q, k_, v, 4, 0.99995)
+
+
+def test_mish_threshold_branch(golden_dir=None):
+    """the reference's mish uses softplus with threshold 20 (tsrn.py:117-125): the +/-25 vector of the golden unit
+    fixture through both HIP kernels that fuse mish (BatchNorm epilogue, pixel-shuffle)"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "units.npz"))
+    xs, ys = torch.tensor(g["mish_x"]).double(), torch.tensor(g["mish_y"]).double()
+    # BatchNorm in eval mode with identity statistics = pure mish on the input
+    c = 4
+    x = xs.repeat(c, 1).t().contiguous()                          # [11, 4]
+    one, zero = torch.ones(c, device="cuda"), torch.zeros(c, device="cuda")
+    y = K().batchnorm_act(dev(x).view(1, 1, -1, c), one, zero, zero, one - 1e-5, None, False, act=4)
+    close(y.view(-1, c)[:, 0], ys, 1e-5, what="mish via bn epilogue")
+    # pixel-shuffle + mish: [1, 1, W, 4 * 1] -> [1, 2, 2W, 1]
+    pre = dev(xs.view(1, 1, -1, 1).repeat(1, 1, 1, 4)).requires_grad_(True)
+    z = K().pixelshuffle_mish(pre)
+    close(z[0, 0, ::2, 0], ys, 1e-5, what="mish via pixel shuffle")
+    xr = xs.clone().requires_grad_(True)
+    (xr * torch.tanh(F.softplus(xr, threshold=20))).sum().backward()
+    z.sum().backward()
+    close(pre.grad[0, 0, :, 0], xr.grad, 1e-5, what="mish gradient")

@@ -27,10 +27,11 @@ def build(arch="tbsrn"):
     return build_models(torch.device("cuda:0"), arch)
 
 
-@pytest.fixture(params=[2, 1], ids=["fastgrad", "bf16x3"])
+@pytest.fixture(params=[2, 1, 3], ids=["fastgrad", "bf16x3", "dgrad16"])
 def prec_mode(request):
-    """model-level parity under both bf16x3 modes: 2 = the default (single-bf16 gradient accumulations in the
-    attention backward), 1 = split products everywhere.  Forward results are identical in the two modes."""
+    """model-level parity under the bf16x3 modes: 2 = the default (single-bf16 gradient accumulations in the
+    attention backward), 1 = split products everywhere, 3 = 2 + single-bf16 data-gradient convolutions on the halo
+    kernel.  Forward results are identical in the three modes."""
     from fudanocr_amd import _lib
     old = _lib.get_precision()
     _lib.set_precision(request.param)
@@ -79,11 +80,14 @@ def test_train_mse_golden(arch, golden_dir, prec_mode):
     eval_dropout(net)
     lr, hr, _ = make_batch(4, 1234)
     from fudanocr_amd import kernels as K
-    sr = net(lr.cuda())
+    x = lr.cuda().requires_grad_(True)
+    sr = net(x)
     mse = K.mse_loss(sr, hr.cuda())
     (mse * 100).backward()
     assert rel_to_max(sr, g["sr"]) < 1e-3
     assert abs(mse.item() - float(g["mse"])) < 1e-3 * float(g["mse"])
+    # d loss / d LR image (through the TPS sampling AND the STN head): fixture F5's `dlr`
+    assert rel_to_max(x.grad, g["dlr"]) < 2e-2
     P = dict(net.named_parameters())
     assert rel_to_max(P["block1.0.weight"].grad, g["g_block1_w"]) < 2e-2
     assert rel_to_max(P["block8.1.bias"].grad, g["g_block8_b"]) < 2e-2
