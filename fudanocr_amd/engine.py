@@ -141,7 +141,14 @@ class TrainStep:
         self.flips = K.FlipTable()               # one batched weight flip per step for all data-gradient GEMMs
         self.frags = K.FragTable(managed=True)   # pre-split fragment-ordered weights of the halo-kernel layers: one
                                                  # batched preparation launch per step (forward + data-gradient forms)
+        self.ctx = K.StepContext()               # this engine's deferred gradients / tables / side stream (the autograd
+                                                 # nodes recorded during its forward carry it into their backward)
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        if self.world > 1:
+            # replicas must START identical (nn.DataParallel replicates device 0's module, base.py:178-179); after this
+            # one broadcast they stay bit-identical without any per-step parameter traffic
+            dist.broadcast(self.flat.flat_param, src=dist.get_global_rank(process_group, 0) if process_group else 0,
+                           group=process_group)
         n = self.flat.numel
         edges = [n * i // n_buckets // 4 * 4 for i in range(n_buckets)] + [n]
         self.buckets = [(edges[i], edges[i + 1]) for i in range(n_buckets) if edges[i + 1] > edges[i]]
@@ -216,7 +223,7 @@ class TrainStep:
             ev.record()                                    # gradients of this range are complete here ...
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                K.join_side_stream(self.comm_stream)       # ... once the side-stream weight gradients are in too
+                self.ctx.join_side_stream(self.comm_stream)    # ... once the side-stream weight gradients are in too
                 self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         else:
             self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
@@ -248,33 +255,31 @@ class TrainStep:
         self.flat.zero_grad()
         self._works, self._sent = [], []
         on_gpu = self.flat.flat_grad.is_cuda
+        c = self.ctx
+        c.frags = self.frags if on_gpu else None
         if on_gpu:
             self.frags.refresh()
-            K.FRAGS = self.frags
         try:
-            sr = self.model(images_lr)
-            loss, mse, _, ctc = self.crit(sr, images_hr, label_strs, encoded)
-        except BaseException:
-            K.FRAGS = None
-            raise
-        if on_gpu:
-            self.flips.refresh()
-            K.FLIPS = self.flips
-        if on_gpu and self.wgrad_side_stream:
-            # the zeroed flat gradient must be visible to the side stream before its kernels accumulate into it
-            K._SIDE["enabled"] = True
-            K.side_stream().wait_stream(torch.cuda.current_stream())
-        try:
+            with K.use_context(c):
+                sr = self.model(images_lr)
+                loss, mse, _, ctc = self.crit(sr, images_hr, label_strs, encoded)
+            if on_gpu:
+                self.flips.refresh()
+                c.flips = self.flips
+            if on_gpu and self.wgrad_side_stream:
+                # the zeroed flat gradient must be visible to the side stream before its kernels accumulate into it
+                c.side_enabled = True
+                c.side_stream().wait_stream(torch.cuda.current_stream())
             (loss * 100).backward()
         finally:
-            K._SIDE["enabled"] = False
-            K.FLIPS = None
-            K.FRAGS = None
+            c.side_enabled = False
+            c.flips = None
+            c.frags = None
         if on_gpu:
             self.flips.build(self.flat.flat_grad.device)       # no-op after the first step
-        K.check_deferred()                                 # every parked residual gradient was picked up
+        c.check_deferred()                                 # every parked residual gradient was picked up
         if on_gpu:
-            K.join_side_stream()                           # weight gradients complete before all-reduce / optimiser
+            c.join_side_stream()                           # weight gradients complete before all-reduce / optimiser
         self.allreduce_grads()
         self.opt.step(self.world)
         K.bump_weight_epoch()                              # parameters changed behind autograd's version counters

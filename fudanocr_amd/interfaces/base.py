@@ -29,19 +29,40 @@ class TextBase(object):
         self.voc_type = config.TRAIN.voc_type
         if not torch.cuda.is_available():
             raise RuntimeError("fudanocr_amd needs an MI355X: there is no CPU fallback (the CPU oracle is test-only)")
-        self.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        if getattr(args, "text_focus", False):
+            raise NotImplementedError("--text_focus (the text-focus loss recognizer, reference loss/text_focus_loss.py"
+                                      ":54-99) is not built; the measured step trains with MSE + CRNN-CTC")
+        # one process per GPU (replaces nn.DataParallel, reference base.py:178-179): bind this process to its device
+        # BEFORE any kernel runs (kernels launch on torch's current stream of the current device) and join the RCCL
+        # process group, so that engine.TrainStep sees world > 1 and all-reduces the gradients
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local)
+        self.device = torch.device("cuda", local)
+        if self.world > 1 and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            backend = os.environ.get("FOCR_DIST_BACKEND", "nccl")           # "gloo": ranks sharing one GPU (tests)
+            if backend == "nccl":
+                torch.distributed.init_process_group("nccl", device_id=self.device)
+            else:
+                torch.distributed.init_process_group(backend)
         alphabet = "0123456789abcdefghijklmnopqrstuvwxyz"
         self.converter_crnn = strLabelConverter(alphabet)
         self.cal_psnr = ssim_psnr.calculate_psnr
         self.cal_ssim = ssim_psnr.SSIM()
         self.ckpt_path = os.path.join("checkpoint", self.exp_name)
-        if not args.test and not getattr(args, "demo", False):
+        if not args.test and not getattr(args, "demo", False) and self.rank == 0:
             if os.path.exists(self.ckpt_path) and not self.resume:
                 shutil.rmtree(self.ckpt_path)              # reference base.py:80-84
             os.makedirs(self.ckpt_path, exist_ok=True)
             logging.basicConfig(format="%(message)s", level=logging.INFO, force=True,
                                 handlers=[logging.FileHandler(os.path.join(self.ckpt_path, "log.txt")),
                                           logging.StreamHandler()])
+        elif self.rank == 0:
+            logging.basicConfig(format="%(message)s", level=logging.INFO, force=True)
+        else:                                               # ranks > 0: no directory wipes, no log files
+            logging.basicConfig(format="%(message)s", level=logging.WARNING, force=True)
         self.logging = logging
 
     # ---- data ------------------------------------------------------------------------------
@@ -49,7 +70,9 @@ class TextBase(object):
         cfg = self.config.TRAIN
         if cfg.train_data_dir:
             raise NotImplementedError("TextZoom LMDB reader is not built in this image (SURVEY.md 8f N3)")
-        ds = SyntheticTextZoom(self.batch_size, int(getattr(cfg, "iters_per_epoch", 20)), cfg.manualSeed, self.mask)
+        # every rank draws its own shard of the global minibatch (seed + rank), as DataParallel's scatter did
+        ds = SyntheticTextZoom(self.batch_size, int(getattr(cfg, "iters_per_epoch", 20)),
+                               cfg.manualSeed + 1000 * self.rank, self.mask)
         return ds, ds
 
     def get_val_data(self):
@@ -98,6 +121,8 @@ class TextBase(object):
         return K.bicubic_gray(imgs_input, 100)
 
     def save_checkpoint(self, netG, epoch, iters, best_acc_dict, best_model_info, is_best, converge_list, exp_name):
+        if self.rank != 0:                                  # replicas are bit-identical: rank 0 writes
+            return
         os.makedirs(self.ckpt_path, exist_ok=True)
         save_dict = {
             "state_dict_G": {k: v.detach().cpu().contiguous() for k, v in netG.state_dict().items()},

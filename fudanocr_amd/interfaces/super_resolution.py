@@ -2,6 +2,7 @@
 path.  One optimisation step = engine.TrainStep (model.train() -> sr -> crit -> (loss*100).backward() ->
 [all-reduce] -> clip 0.25 -> Adam), eval = SR -> PSNR/SSIM -> parse_crnn_data -> CRNN -> greedy decode ->
 exact-match accuracy."""
+import os
 import time
 from datetime import datetime
 
@@ -86,3 +87,57 @@ class TextSR(base.TextBase):
         n = sum(len(ld) for ld in loaders) * self.batch_size
         self.logging.info("fps %.1f" % (n / (time.time() - t0)))
         return res
+
+    @torch.no_grad()
+    def demo(self):
+        """Reference interfaces/super_resolution.py:331-420: every image of --demo_dir is resized to 64 x 16 (PIL
+        bicubic), optionally given the mean-threshold mask channel, super-resolved, and recognised by the CRNN both
+        from the LR input and from the SR output; logs '<lr string> ===> <sr string>' per image and the fps."""
+        import numpy as np
+        from PIL import Image
+        mask_ = self.mask
+
+        def transform_(path):
+            img = Image.open(path)
+            img = img.resize((64, 16), Image.BICUBIC)
+            arr = np.asarray(img.convert("RGB"), dtype=np.uint8)
+            t = torch.from_numpy(arr.copy()).permute(2, 0, 1).float().div_(255.0)       # ToTensor
+            if mask_:
+                m = img.convert("L")
+                thres = np.array(m).mean()
+                m = m.point(lambda x: 0 if x > thres else 255)
+                t = torch.cat((t, torch.from_numpy(np.asarray(m, dtype=np.uint8).copy())[None].float().div_(255.0)), 0)
+            return t.unsqueeze(0)
+
+        md = self.generator_init()
+        model, rec = md["model"], md["recognizer"]
+        if rec is None:
+            rec, _ = self.CRNN_init()
+        rec.eval()
+        for p in model.parameters():
+            p.requires_grad = False
+        model.eval()
+        names = sorted(os.listdir(self.args.demo_dir))
+        results, sr_time, t0 = [], 0.0, time.time()
+        for im_name in names:
+            images_lr = transform_(os.path.join(self.args.demo_dir, im_name)).to(self.device)
+            t1 = time.time()
+            images_sr = model(images_lr)
+            sr_time += time.time() - t1
+            strs = []
+            for im in (images_lr, images_sr):
+                # parse_crnn_data resizes BOTH axes to (32, 100) (base.py:319-325): the LR branch goes 16 -> 32 rows
+                # first (eval-only resampling on the device), then the shared HIP bicubic-luma kernel along W
+                x3 = im[:, :3]
+                if x3.shape[2] != 32:
+                    x3 = torch.nn.functional.interpolate(x3, (32, x3.shape[3]), mode="bicubic", align_corners=False)
+                out = rec(self.parse_crnn_data(x3.contiguous()))                         # [26, 1, 37]
+                _, preds = out.max(2)
+                preds = preds.transpose(1, 0).contiguous().view(-1)
+                strs.append(self.converter_crnn.decode(preds.cpu().to(torch.int32),
+                                                       torch.IntTensor([out.size(0)]), raw=False))
+            self.logging.info("{} ===> {}".format(strs[0], strs[1]))
+            results.append((im_name, strs[0], strs[1]))
+        fps = len(names) / max(time.time() - t0, 1e-9)
+        self.logging.info("fps={}".format(fps))
+        return {"results": results, "fps": fps, "sr_time": sr_time}

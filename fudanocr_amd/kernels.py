@@ -10,6 +10,7 @@ kernel wants, with the reference's state_dict shapes unchanged.
 import contextlib
 import ctypes
 import math
+import threading
 import weakref
 
 import torch
@@ -73,30 +74,77 @@ def _new_seed():
 # complete gradient.  The model code opts in on both sides (defer=True / take_deferred=True) -- it knows the wiring.
 # A parked gradient that is never picked up would be a silent error: check_deferred() raises at the next forward.
 # ----------------------------------------------------------------------------------------
-_DEFERRED = {}
+class StepContext:
+    """Per-owner (engine instance) state of the autograd wrappers: parked residual gradients, the flipped / fragment
+    weight tables and the weight-gradient side stream.  Forward passes pick the context up from a THREAD-LOCAL slot
+    (`use_context`), and every autograd node remembers the context it was recorded under, so its backward -- which
+    autograd may run on a worker thread -- finds the same state: two engines, or concurrent backward threads, in
+    one process never share a table."""
+
+    def __init__(self, managed_frags=False):
+        self.deferred = {}
+        self.flips = None                # FlipTable while an engine step's backward runs
+        self.frags = None                # managed FragTable while an engine step runs (None: the default table)
+        self.side_enabled = False
+        self.side_stream_obj = None
+        self.side_used = False
+
+    # -- deferred residual gradients
+    def defer_grad(self, t, g):
+        k = _dkey(t)
+        if k in self.deferred:
+            raise RuntimeError("two deferred gradients for the same tensor")
+        self.deferred[k] = g
+
+    def take_deferred(self, t):
+        return self.deferred.pop(_dkey(t), None)
+
+    def check_deferred(self):
+        if self.deferred:
+            self.deferred.clear()
+            raise RuntimeError("fudanocr_amd: a deferred residual gradient was never consumed by its GEMM backward")
+
+    # -- weight-gradient side stream
+    def side_stream(self):
+        if not self.side_enabled:
+            return None
+        if self.side_stream_obj is None:
+            self.side_stream_obj = torch.cuda.Stream()
+        self.side_used = True
+        return self.side_stream_obj
+
+    def join_side_stream(self, stream=None):
+        """make `stream` (default: current) wait for everything queued on the weight-gradient side stream"""
+        if self.side_used and self.side_stream_obj is not None:
+            (stream or torch.cuda.current_stream()).wait_stream(self.side_stream_obj)
+
+
+_DEFAULT_CTX = StepContext()
+_TLS = threading.local()
+
+
+def current_context():
+    return getattr(_TLS, "ctx", None) or _DEFAULT_CTX
+
+
+@contextlib.contextmanager
+def use_context(c):
+    prev = getattr(_TLS, "ctx", None)
+    _TLS.ctx = c
+    try:
+        yield c
+    finally:
+        _TLS.ctx = prev
 
 
 def _dkey(t):
     return (t.data_ptr(), t.numel())
 
 
-def _defer_grad(t, g):
-    k = _dkey(t)
-    if k in _DEFERRED:
-        raise RuntimeError("two deferred gradients for the same tensor")
-    _DEFERRED[k] = g
-
-
-def _take_deferred(t):
-    return _DEFERRED.pop(_dkey(t), None)
-
-
 def check_deferred():
-    """raise if a deferred residual gradient was never consumed (called at the start of a model forward and by the
-    engine after backward)"""
-    if _DEFERRED:
-        _DEFERRED.clear()
-        raise RuntimeError("fudanocr_amd: a deferred residual gradient was never consumed by its GEMM backward")
+    """raise if a deferred residual gradient of the current context was never consumed (called at the start of a
+    model forward and by the engine after backward)"""
+    current_context().check_deferred()
 
 
 # ----------------------------------------------------------------------------------------
@@ -162,7 +210,6 @@ class FlipTable:
             _lib.call("focr_weight_flip_transpose_batched", _p(self.live_desc), self.n_live, self.max_live, _stream())
 
 
-FLIPS = None                     # set by the engine (engine.TrainStep); None: every dgrad flips its own weights
 
 
 # ----------------------------------------------------------------------------------------
@@ -258,11 +305,10 @@ class FragTable:
 
 
 _FRAGS_DEFAULT = FragTable(managed=False)
-FRAGS = None                     # the engine's managed table while one of its steps runs
 
 
-def _frag_weights(weight, wk, cout, kh, kw, cin, flip):
-    return (FRAGS or _FRAGS_DEFAULT).get(weight, wk, cout, kh, kw, cin, flip)
+def _frag_weights(step, weight, wk, cout, kh, kw, cin, flip):
+    return (step.frags or _FRAGS_DEFAULT).get(weight, wk, cout, kh, kw, cin, flip)
 
 
 def _halo_ok(h, w, cin, cout, kh, kw, ph, pw):
@@ -273,25 +319,6 @@ def _halo_ok(h, w, cin, cout, kh, kw, ph, pw):
     if _lib.get_precision() == 0:
         return False
     return 2 * h * w >= ((h + 3) // 4 * 4) * ((w + 31) // 32 * 32)
-
-
-# side stream for engine-owned weight gradients (see _Conv2d.backward); the engine enables it and joins it
-_SIDE = {"enabled": False, "stream": None, "used": False}
-
-
-def side_stream():
-    if not _SIDE["enabled"]:
-        return None
-    if _SIDE["stream"] is None:
-        _SIDE["stream"] = torch.cuda.Stream()
-    _SIDE["used"] = True
-    return _SIDE["stream"]
-
-
-def join_side_stream(stream=None):
-    """make `stream` (default: current) wait for everything queued on the weight-gradient side stream"""
-    if _SIDE["used"] and _SIDE["stream"] is not None:
-        (stream or torch.cuda.current_stream()).wait_stream(_SIDE["stream"])
 
 
 def _is_out_layer(cin, cout, kh, kw, ph, pw, w, residual, alpha, relu):
@@ -329,6 +356,7 @@ class _Conv2d(torch.autograd.Function):
         """want_stats (halo-kernel layers only): also returns the per-tile (sum, sum of squares) partials of y
         [tiles, Cout, 2] for a following train-mode BatchNorm (non-differentiable second output)."""
         cout = weight.shape[0]
+        ctx.step = step = current_context()
         ctx.take_deferred, ctx.defer_residual = bool(take_deferred), bool(defer_residual)
         ctx.res_key = _dkey(residual) if (residual is not None and defer_residual) else None
         if weight.dim() == 2:
@@ -357,7 +385,7 @@ class _Conv2d(torch.autograd.Function):
         else:
             frag = stats = None
             if _halo_ok(x4.shape[1], x4.shape[2], x4.shape[3], cout, kh, kw, ph, pw):
-                frag = _frag_weights(weight, wk, cout, kh, kw, x4.shape[3], False)
+                frag = _frag_weights(step, weight, wk, cout, kh, kw, x4.shape[3], False)
                 if want_stats:
                     tiles = _lib.load().focr_conv3x3_frag_tiles(x4.shape[0], x4.shape[1], x4.shape[2])
                     stats = torch.empty((tiles, cout, 2), device=x4.device, dtype=torch.float32)
@@ -375,6 +403,7 @@ class _Conv2d(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, *_unused):
         x4, weight, y = ctx.saved_tensors
+        step = ctx.step
         kh, kw, ph, pw, alpha, relu, has_bias, has_res = ctx.geom
         n, h, w, cin = x4.shape
         cout = weight.shape[0]
@@ -389,9 +418,9 @@ class _Conv2d(torch.autograd.Function):
             dy4 = g
         dres = dy4.reshape(dy.shape) if has_res else None
         if has_res and ctx.defer_residual and ctx.needs_input_grad[3]:
-            if ctx.res_key in _DEFERRED:
+            if ctx.res_key in step.deferred:
                 raise RuntimeError("two deferred gradients for the same tensor")
-            _DEFERRED[ctx.res_key] = dy4          # picked up by the data-gradient kernel of the tensor's other consumer
+            step.deferred[ctx.res_key] = dy4      # picked up by the data-gradient kernel of the tensor's other consumer
             dres = None
         wk = _ohwi(weight)
         dx = dw = db = None
@@ -411,7 +440,7 @@ class _Conv2d(torch.autograd.Function):
             # Weight gradients that land in the engine's flat buffer feed nothing inside backward: they run on the
             # side stream, concurrently with the data-gradient chain on the main stream (both kinds of kernels are
             # latency/occupancy bound, not throughput bound).  The engine joins the streams before the optimiser.
-            side = side_stream() if (tw is not None and (db is None or tb is not None)) else None
+            side = step.side_stream() if (tw is not None and (db is None or tb is not None)) else None
             if side is not None:
                 ev = torch.cuda.Event()
                 ev.record()
@@ -430,19 +459,19 @@ class _Conv2d(torch.autograd.Function):
                 if alpha != 1.0:
                     _lib.call("focr_axpy", _p(dw), _NULL, _p(dw), dw.numel(), alpha, _stream())
         if ctx.needs_input_grad[0]:
-            radd = _take_deferred(x4) if ctx.take_deferred else None     # parked residual gradient of x: + in the epilogue
+            radd = step.take_deferred(x4) if ctx.take_deferred else None  # parked residual gradient of x: + in the epilogue
             if radd is not None:
                 radd = radd.reshape(-1, cin)
             if _halo_ok(oh, ow, cout, cin, kh, kw, kh - 1 - ph, kw - 1 - pw):
                 # data gradient on the halo kernel: flipped weights in fragment order; a single bf16 product under
                 # precision mode 3 (csrc/focr_core.hip), split products otherwise
-                wf = _frag_weights(weight, wk, cout, kh, kw, cin, True)
+                wf = _frag_weights(step, weight, wk, cout, kh, kw, cin, True)
                 dx4 = _conv_fwd_raw(dy4, None, None, radd, cin, kh, kw, 1, 1, alpha, False, frag=wf,
                                     planes=1 if _lib.get_precision() == 3 else 2)
             else:
                 persistent = weight.is_leaf and wk.data_ptr() == weight.data_ptr()
-                wd = FLIPS.lookup(wk, cout, kh, kw, cin, not weight.requires_grad) \
-                    if (FLIPS is not None and persistent) else None
+                wd = step.flips.lookup(wk, cout, kh, kw, cin, not weight.requires_grad) \
+                    if (step.flips is not None and persistent) else None
                 if wd is None:
                     wd = torch.empty(wk.numel(), device=dy.device, dtype=torch.float32)
                     _lib.call("focr_weight_flip_transpose", _p(wk), _p(wd), cout, kh, kw, cin, _stream())
@@ -555,6 +584,7 @@ def conv_bn(x, conv, bn, act=ACT_NONE, residual=None, take_deferred=False):
 class _LayerNormStd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, residual, a, b, eps, defer=False):
+        ctx.step = current_context()
         ctx.defer = bool(defer) and residual is not None
         d = x.shape[-1]
         rows = x.numel() // d
@@ -582,7 +612,7 @@ class _LayerNormStd(torch.autograd.Function):
                   _p(db), rows, d, eps, int(ta is not None and tb is not None), _stream())
         dres = dx if has_res else None
         if ctx.defer and ctx.needs_input_grad[1]:
-            _defer_grad(residual, dx)             # added by the data-gradient kernel of the residual's other consumer
+            ctx.step.defer_grad(residual, dx)     # added by the data-gradient kernel of the residual's other consumer
             dres = None
         return dx, dres, (None if ta is not None else da), (None if tb is not None else db), None, None
 

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Entry point with the reference's command line (scene-text-telescope/main.py:17-40):
-  python -m fudanocr_amd.main --arch tbsrn --batch_size 128 --STN --exp_name X [--test] [--resume ckpt]
-Multi-GPU: launch with torch.distributed.run, one process per GPU (replaces yaml `ngpu` + DataParallel)."""
+"""Entry point with the reference's command line (scene-text-telescope/main.py:6-40):
+  python -m fudanocr_amd.main --arch tbsrn --batch_size 128 --STN --exp_name X [--test | --demo] [--resume ckpt]
+Multi-GPU: launch with torch.distributed.run, one process per GPU (replaces yaml `ngpu` + DataParallel):
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m fudanocr_amd.main ...
+TextBase.__init__ binds the process to cuda:LOCAL_RANK and joins the RCCL process group when WORLD_SIZE > 1."""
 import argparse
 import os
 
@@ -13,15 +15,17 @@ from .utils.util import AttrDict
 
 def main(config, args):
     mission = TextSR(config, args)
-    if args.test:
+    if args.test:                      # same dispatch order as the reference (main.py:8-15)
         return mission.test()
+    elif args.demo:
+        return mission.demo()
     return mission.train()
 
 
 def parse(argv=None):
     p = argparse.ArgumentParser(description="")
     p.add_argument("--arch", default="tbsrn", choices=["tbsrn", "tsrn"])
-    p.add_argument("--text_focus", action="store_true", help="reference flag; the text-focus recognizer is out of scope")
+    p.add_argument("--text_focus", action="store_true", help="reference flag (text-focus loss recognizer, SURVEY 8f N1): not built -- raises instead of silently training without it")
     p.add_argument("--exp_name", required=True, help="Type your experiment name")
     p.add_argument("--test", action="store_true", default=False)
     p.add_argument("--test_data_dir", type=str, default="")

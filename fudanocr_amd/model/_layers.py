@@ -55,10 +55,12 @@ class PReLU(nn.PReLU):
 
 
 class ReLUTag(nn.ReLU):
-    """Placeholder keeping the reference's module slot; the ReLU itself is fused upstream."""
+    """The reference's nn.ReLU module slot.  The product's containers (CRNN.forward, STNHead) fuse this ReLU into the
+    preceding convolution / BatchNorm epilogue and skip the module; called directly (e.g. through a plain
+    nn.Sequential walk) it IS a ReLU, so no path can silently lose the non-linearity."""
 
     def forward(self, x):
-        return x
+        return torch.relu(x)
 
 
 class MaxPool2d(nn.MaxPool2d):

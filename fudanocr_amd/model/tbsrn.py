@@ -120,9 +120,17 @@ class FeatureEnhancer(nn.Module):
 
 
 class mish(nn.Module):
+    """x * tanh(softplus(x)) (reference tbsrn.py:258-266).  The blocks fuse it into the BatchNorm / pixel-shuffle
+    kernels; the module's own forward is the same function for direct callers."""
+
     def __init__(self):
         super().__init__()
         self.activated = True
+
+    def forward(self, x):
+        if self.activated:
+            x = x * torch.tanh(torch.nn.functional.softplus(x))
+        return x
 
 
 class GruBlock(nn.Module):

@@ -111,3 +111,47 @@ def test_bench_multiprocess_path(tmp_path):
     res = json.loads(line[0])
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 16 and res["value"] > 0
     assert res["scaling"] == "weak" and "cpu_baseline" not in res
+
+
+MAIN_WORKER = r"""
+import os, sys, yaml, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+os.chdir(%r)
+from fudanocr_amd import main as M
+from fudanocr_amd.utils.util import AttrDict
+cfg = AttrDict(yaml.load(open(os.path.join(os.path.dirname(M.__file__), "config", "super_resolution.yaml")),
+                         Loader=yaml.Loader))
+cfg.TRAIN.iters_per_epoch, cfg.TRAIN.displayInterval, cfg.TRAIN.saveInterval = 3, 1, 2
+captured = {}
+from fudanocr_amd.interfaces import base as B
+orig = B.TextBase.optimizer_init
+def spy(self, model, crit):
+    captured["step"] = orig(self, model, crit)
+    return captured["step"]
+B.TextBase.optimizer_init = spy
+res = M.main(cfg, M.parse(["--arch", "tbsrn", "--STN", "--exp_name", "dp", "--batch_size", "4"]))
+step = captured["step"]
+assert dist.is_initialized() and step.world == 2, "main.py did not join the process group"
+mine = step.flat.flat_param.detach().clone()
+other = mine.clone()
+dist.broadcast(other, src=0)
+assert torch.equal(mine, other), "replicas diverged"
+rank = dist.get_rank()
+print("rank", rank, "ok; checkpoint written:", os.path.exists("checkpoint/dp/model_best.pth"))
+dist.destroy_process_group()
+"""
+
+
+def test_main_py_under_two_ranks(tmp_path):
+    """`python -m torch.distributed.run ... -m fudanocr_amd.main` must train ONE data-parallel job, not N
+    independent replicas: TextBase joins the process group and binds the device, ranks draw different shards, only
+    rank 0 wipes / writes the checkpoint directory, parameters stay bit-identical."""
+    script = tmp_path / "main_dp_worker.py"
+    script.write_text(MAIN_WORKER % (ROOT, str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", WORLD_SIZE="2", FOCR_DIST_BACKEND="gloo")
+    procs, outs = _run_two([([sys.executable, str(script)], dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+                            for r in range(2)])
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
+    assert os.path.exists(tmp_path / "checkpoint" / "dp" / "model_best.pth")
+    assert "log.txt" in os.listdir(tmp_path / "checkpoint" / "dp")

@@ -113,6 +113,30 @@ def test_train_mse_golden(arch, golden_dir, prec_mode):
     assert not bad, bad[:10]
 
 
+def test_crnn_decoded_strings_golden(golden_dir):
+    """rows a21 / N4: CRNN logits computed on the GPU, argmax on the device, greedy decode -> the strings the
+    REFERENCE's decoders produced from the reference's logits (fixture decode.json, case crnn_leg)"""
+    fx = json.load(open(os.path.join(golden_dir, "decode.json")))
+    case = next(c for c in fx["cases"] if c["name"] == "crnn_leg")
+    _, rec, _ = build()
+    from fudanocr_amd import kernels as K
+    from fudanocr_amd.utils.utils_crnn import get_crnn_pred
+    img = torch.rand(4, 3, 32, 128, generator=torch.Generator().manual_seed(77))
+    with torch.no_grad():
+        out = rec(K.bicubic_gray(img.cuda(), 100)).permute(1, 0, 2).contiguous()       # [B, T, 37]
+    # name-keyed random weights give flat logits (top-2 margins down to 3e-4): frames whose golden margin is inside the
+    # 1e-3 logit tolerance may legitimately flip, every other frame's argmax must match the reference's
+    gl = torch.tensor(np.load(os.path.join(golden_dir, "crnn_leg.npz"))["logits"]).permute(1, 0, 2)
+    top2 = gl.topk(2, dim=2).values
+    decided = (top2[..., 0] - top2[..., 1]) > 2e-3 * gl.abs().max()
+    am = out.argmax(2).cpu()
+    ref_am = torch.tensor(case["argmax"])
+    assert decided.float().mean() > 0.5
+    assert torch.equal(am[decided], ref_am[decided])
+    patched = torch.nn.functional.one_hot(torch.where(decided, am, ref_am), 37).float().cuda()
+    assert get_crnn_pred(patched) == case["get_crnn_pred"]
+
+
 def test_crnn_leg_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, "crnn_leg.npz"))
     _, rec, _ = build()
@@ -241,3 +265,30 @@ def test_harness_train_eval_checkpoint(tmp_path, monkeypatch):
     m.load_state_dict(ck["state_dict_G"])
     conv = ck["converge"][-1]
     assert 0 <= conv["acc"] <= 1 and conv["psnr"] > 0 and -1 <= conv["ssim"] <= 1
+
+
+def test_harness_demo_and_dispatch(tmp_path, monkeypatch):
+    """main.py dispatches --demo to TextSR.demo() (reference main.py:8-15, interfaces/super_resolution.py:331-420):
+    every image of the demo directory is resized to 64 x 16, super-resolved and recognised from LR and from SR;
+    --text_focus (not built) refuses loudly instead of silently training without it."""
+    import os
+    import yaml
+    from PIL import Image
+    from fudanocr_amd import main as M
+    from fudanocr_amd.utils.util import AttrDict
+    monkeypatch.chdir(tmp_path)
+    demo = tmp_path / "demo"
+    demo.mkdir()
+    rng = np.random.RandomState(3)
+    for i, (w, h) in enumerate([(100, 31), (64, 16), (200, 60)]):
+        Image.fromarray(rng.randint(0, 256, (h, w, 3), dtype=np.uint8)).save(demo / ("im%d.png" % i))
+    cfg = AttrDict(yaml.load(open(os.path.join(os.path.dirname(M.__file__), "config", "super_resolution.yaml")),
+                             Loader=yaml.Loader))
+    for extra in ([], ["--mask"]):
+        args = M.parse(["--arch", "tbsrn", "--STN", "--exp_name", "d", "--demo", "--demo_dir", str(demo)] + extra)
+        res = M.main(cfg, args)
+        assert [r[0] for r in res["results"]] == ["im0.png", "im1.png", "im2.png"]
+        assert all(isinstance(a, str) and isinstance(b, str) for _, a, b in res["results"]) and res["fps"] > 0
+    assert not (tmp_path / "checkpoint").exists()              # a demo run never touches the checkpoint directory
+    with pytest.raises(NotImplementedError):
+        M.main(cfg, M.parse(["--arch", "tbsrn", "--exp_name", "d", "--text_focus"]))

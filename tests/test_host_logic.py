@@ -192,3 +192,92 @@ def test_eval_metrics_match_reference(golden_dir):
     assert abs(float(ssim_psnr.SSIM()(ia, ib)) - ref["ssim"]) < 1e-5
     for text, voc, want in ref["str_filt"]:
         assert str_filt(text, voc) == want
+
+
+def test_greedy_decode_matches_reference_fixture(golden_dir):
+    """row a21: the product's strLabelConverter.decode and get_crnn_pred reproduce the strings the REFERENCE's own
+    decoders produced (tests/golden/decode.json, tools/make_golden_decode.py) on runs / blanks / edge sequences and on
+    the CRNN logits of fixture F4"""
+    import json
+    import numpy as np
+    from fudanocr_amd.utils.utils_crnn import get_crnn_pred, strLabelConverter
+    fx = json.load(open(os.path.join(golden_dir, "decode.json")))
+    conv = strLabelConverter("0123456789abcdefghijklmnopqrstuvwxyz")
+    scores = {"synthetic": torch.tensor(np.load(os.path.join(golden_dir, "decode_scores.npz"))["synthetic"]),
+              "crnn_leg": torch.tensor(np.load(os.path.join(golden_dir, "crnn_leg.npz"))["logits"]).permute(1, 0, 2)}
+    for case in fx["cases"]:
+        sc = scores[case["name"]].contiguous()
+        preds = sc.argmax(2)
+        assert preds.tolist() == case["argmax"]
+        n, t = preds.shape
+        flat, sizes = preds.reshape(-1).to(torch.int32), torch.IntTensor([t] * n)
+        assert conv.decode(flat, sizes, raw=False) == case["decode"]
+        assert conv.decode(flat, sizes, raw=True) == case["decode_raw"]
+        assert [conv.decode(preds[i].to(torch.int32), torch.IntTensor([t]), raw=False) for i in range(n)] == \
+            case["decode_single"]
+        assert get_crnn_pred(sc) == case["get_crnn_pred"]
+        assert case["get_crnn_pred"] == case["decode"]          # the reference's two decoders agree with each other
+
+
+def test_integration_recipe_module_level(tmp_path, golden_dir):
+    """INTEGRATION.md section 1, executed: a stand-in for the reference tree (package `model` with `model.crnn`, and an
+    `interfaces.base` that imports and constructs the networks exactly like reference interfaces/base.py:20-25,138-176,
+    309-311) is patched by the documented recipe; the classes it then constructs are the HIP-backed ones, with the
+    reference's constructor signatures and state_dict schema."""
+    import importlib
+    import json
+    import textwrap
+    ref = tmp_path / "reftree"
+    (ref / "model" / "crnn").mkdir(parents=True)
+    (ref / "interfaces").mkdir()
+    (ref / "model" / "__init__.py").write_text("")
+    (ref / "model" / "crnn" / "__init__.py").write_text("")
+    for name in ("tbsrn", "tsrn"):                      # placeholders for the reference's own (CUDA) implementations
+        (ref / "model" / (name + ".py")).write_text("class %s:\n    ORIGIN = 'reference'\n" % name.upper())
+    (ref / "model" / "crnn" / "crnn.py").write_text("class CRNN:\n    ORIGIN = 'reference'\n")
+    (ref / "interfaces" / "__init__.py").write_text("")
+    (ref / "interfaces" / "base.py").write_text(textwrap.dedent("""
+        from model import tbsrn, tsrn
+        from model.crnn import crnn
+
+        def generator_init(arch, scale_factor=2, width=128, height=32, STN=True, mask=False, srb=5, hd_u=32):
+            if arch == 'tbsrn':
+                return tbsrn.TBSRN(scale_factor=scale_factor, width=width, height=height, STN=STN, mask=mask,
+                                   srb_nums=srb, hidden_units=hd_u)
+            return tsrn.TSRN(scale_factor=scale_factor, width=width, height=height, STN=STN, mask=mask,
+                             srb_nums=srb, hidden_units=hd_u)
+
+        def CRNN_init():
+            return crnn.CRNN(32, 1, 37, 256)
+    """))
+    saved = {k: sys.modules.get(k) for k in ("model", "model.tbsrn", "model.tsrn", "model.crnn", "model.crnn.crnn",
+                                             "interfaces", "interfaces.base")}
+    sys.path.insert(0, str(ref))
+    try:
+        for k in saved:
+            sys.modules.pop(k, None)
+        # ---- the recipe of INTEGRATION.md section 1 ----
+        import fudanocr_amd  # noqa: F401
+        from fudanocr_amd.model import tbsrn, tsrn
+        from fudanocr_amd.model.crnn import crnn
+        import model
+        import model.crnn                                  # noqa: F401  (the reference package)
+        model.tbsrn, model.tsrn, model.crnn.crnn = tbsrn, tsrn, crnn
+        sys.modules["model.tbsrn"], sys.modules["model.tsrn"] = tbsrn, tsrn
+        sys.modules["model.crnn.crnn"] = crnn
+        # ---- what the reference's interfaces/base.py then does ----
+        base = importlib.import_module("interfaces.base")
+        net, tnet, rec = base.generator_init("tbsrn"), base.generator_init("tsrn", STN=False), base.CRNN_init()
+        assert type(net).__module__.startswith("fudanocr_amd.") and type(rec).__module__.startswith("fudanocr_amd.")
+        schema = json.load(open(os.path.join(golden_dir, "schema.json")))
+        for name, m in (("tbsrn", net), ("crnn", rec)):
+            mine = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()]
+            assert mine == schema[name]
+        assert [k for k, _ in tnet.state_dict().items()][:3] == [r[0] for r in schema["tsrn"]][:3]
+    finally:
+        sys.path.remove(str(ref))
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
