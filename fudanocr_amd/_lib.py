@@ -69,6 +69,9 @@ SIGNATURES = {
     "focr_bn_bwd_ws_floats": [L, I],
     "focr_lstm_ws_bytes": [I, I, I, I],
     "focr_grad_sumsq_ws_floats": [],
+    "focr_psnr_ssim_ws_floats": [I, I, I],
+    "focr_psnr_ssim": [P, P, P, I, P, P, P, I, I, I, I, P],
+    "focr_u8_to_input": [P, P, I, I, I, I, P],
     "focr_set_precision": [I],
     "focr_get_precision": [],
     "focr_clip_adam": [P, P, P, P, P, L, F, F, F, F, I, F, F, P],
@@ -101,6 +104,7 @@ def load():
     lib.focr_grad_sumsq_ws_floats.restype = ctypes.c_long
     lib.focr_conv2d_wgrad_ws_floats.restype = ctypes.c_long
     lib.focr_weight_frag_bytes.restype = ctypes.c_long
+    lib.focr_psnr_ssim_ws_floats.restype = ctypes.c_long
     _lib = lib
     if os.environ.get("FOCR_PRECISION"):          # 0 fp32 | 1 bf16x3 | 2 (default) + bf16 attention-gradient sums | 3 + bf16 dgrad
         rc = lib.focr_set_precision(int(os.environ["FOCR_PRECISION"]))

@@ -205,6 +205,138 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_bx3_kernel(const float* __res
 }
 
 // =======================================================================================
+// forward, two query tiles per wave (block = 256 queries, wave = 2 x 32 queries)
+//   Head dim 32 makes the softmax VALU work per score (max, exp2, sum, keep-select, hi/lo split: ~9 ops) as long as the
+//   MFMA work per score (12 x 32 cycles per 32 x 32 tile); with one tile per wave the two run back to back inside
+//   every wave (S MFMAs -> softmax -> PV MFMAs is one dependency chain).  With two independent tiles per wave the
+//   softmax of tile A sits next to the S / PV MFMAs of tile B in the same instruction stream, every K / V fragment
+//   read from LDS feeds two MFMA triples instead of one, and the per-block K/V staging is shared by 256 queries.
+// =======================================================================================
+template <bool DROPOUT>
+__global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                            const float* __restrict__ V, float* __restrict__ O,
+                                                            float* __restrict__ LSE, const uint32_t* __restrict__ MASK,
+                                                            int Ntok, int ld, int ldo, float scale, float p_drop,
+                                                            uint64_t seed, int nheads) {
+  __shared__ __attribute__((aligned(16))) __bf16 Kh[64 * RP], Kl[64 * RP];
+  __shared__ __attribute__((aligned(16))) __bf16 Vth[32 * TP], Vtl[32 * TP];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  int bh_, qb_;
+  attn_block_decode(blockIdx.x, gridDim.x / (Ntok / 256), Ntok / 256, bh_, qb_);
+  const int H = nheads, h = bh_ % nheads, b = bh_ / nheads;
+  const size_t base = (size_t)b * Ntok * ld + h * 32;
+  const size_t baseo = (size_t)b * Ntok * ldo + h * 32;
+  const int q0 = qb_ * 256 + wave * 64 + li;                 // tile t: query q0 + 32 t
+
+  bf16x8 qh[2][2], ql[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+      row_frag(Q + base + (size_t)(q0 + 32 * t) * ld + 16 * m + 8 * lh, scale * LOG2E, qh[t][m], ql[t][m]);
+  f32x16 oacc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+  float mrun[2] = {-1e30f, -1e30f}, l[2] = {0.f, 0.f};
+  const uint32_t thr = DROPOUT ? attn_drop_thr16(p_drop) : 0u;
+  const float inv_keep = DROPOUT ? 1.f / (1.f - (float)thr / 65536.f) : 1.f;
+  const int NG = Ntok / 32;
+  const int qg = __builtin_amdgcn_readfirstlane(qb_ * 8 + wave * 2);
+  const uint64_t* mgrp = reinterpret_cast<const uint64_t*>(MASK) + ((size_t)bh_ * NG + qg) * NG * 16;
+
+  const int rp = tid >> 3, c0 = (tid & 7) * 4;         // key pair, first of 4 d columns
+  float4 k0, k1, v0, v1;
+  const int ntiles = Ntok / 64;
+  LOAD_KV(0);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    put_rows(Kh, Kl, rp, c0, k0, k1);
+    put_cols(Vth, Vtl, rp, c0, v0, v1);
+    __syncthreads();
+    if (kt + 1 < ntiles) LOAD_KV(kt + 1);
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      // keep-bit lane masks of both tiles (wave-uniform -> scalar loads), requested before the score MFMAs so that
+      // their latency is covered
+      uint64_t mk[2][16];
+      if (DROPOUT) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const uint64_t* mp = mgrp + ((size_t)t * NG + (kt * 2 + sub)) * 16;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mk[t][r] = mp[r];
+        }
+        __builtin_amdgcn_sched_barrier(0);       // keep the requests up here (the scheduler sinks them to their uses)
+      }
+      f32x16 s[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Kh[(sub * 32 + li) * RP + 16 * m + 8 * lh]);
+        bf16x8 al = *reinterpret_cast<const bf16x8*>(&Kl[(sub * 32 + li) * RP + 16 * m + 8 * lh]);
+        MFMA3(s[0], ah, al, qh[0][m], ql[0][m]);
+        MFMA3(s[1], ah, al, qh[1][m], ql[1][m]);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float mx = s[t][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(mrun[t], mx);
+        const float alpha = __builtin_amdgcn_exp2f(mrun[t] - mn);
+        mrun[t] = mn;
+        float ls = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(s[t][r] - mn);
+          ls += p;
+          s[t][r] = p;
+        }
+        if (DROPOUT) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[t][r] = keep_lanes(s[t][r], mk[t][r]);   // 1/(1-p) at the end
+        }
+        l[t] = l[t] * alpha + ls;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int kc = sub * 32 + 16 * m + 4 * lh;
+        bf16x8 vh = cat44(*reinterpret_cast<const bf16x4*>(&Vth[li * TP + kc]),
+                          *reinterpret_cast<const bf16x4*>(&Vth[li * TP + kc + 8]));
+        bf16x8 vl = cat44(*reinterpret_cast<const bf16x4*>(&Vtl[li * TP + kc]),
+                          *reinterpret_cast<const bf16x4*>(&Vtl[li * TP + kc + 8]));
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          bf16x8 ph, pl;
+          split_regs(s[t], m, ph, pl);
+          MFMA3(oacc[t], vh, vl, ph, pl);
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    float lt = l[t] + __shfl_xor(l[t], 32, 64);
+    const float inv = inv_keep / lt;
+    const int q = q0 + 32 * t;
+    float* orow = O + baseo + (size_t)q * ldo;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(orow + 8 * g + 4 * lh) = make_float4(
+          oacc[t][4 * g] * inv, oacc[t][4 * g + 1] * inv, oacc[t][4 * g + 2] * inv, oacc[t][4 * g + 3] * inv);
+    if (lh == 0) LSE[(size_t)(b * H + h) * Ntok + q] = (mrun[t] + __builtin_amdgcn_logf(lt)) * LN2;   // natural log
+  }
+}
+
+// =======================================================================================
 // backward pass 1: dK, dV   (block = 128 keys, wave = 32 keys, loop over 64-query tiles)
 //   S[q][key]  : A = Qs rows (LDS), B = K (regs)        dP[q][key] : A = dO rows (LDS), B = V (regs)
 //   dV^T[d][key] = sum_q dO[q][d] Pd[q][key] : A = dO^T (LDS transposed), B = split(Pd) regs
@@ -467,9 +599,24 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_bx3_kernel(
 }
 
 // launchers used by the dispatching C ABI entry points in attention.hip
+// 0: one query tile per wave (128-query blocks); 1: two tiles per wave (256-query blocks, needs Ntok % 256 == 0)
+#ifndef FOCR_ATTN_FWD_VARIANT
+#define FOCR_ATTN_FWD_VARIANT 1
+#endif
+int g_attn_fwd_variant = FOCR_ATTN_FWD_VARIANT;
 int focr_attn_fwd_bx3(const float* q, const float* k, const float* v, float* o, float* lse, uint32_t* mask,
                       int B, int H, int Ntok, int ld, int ldo, float scale, float p_drop, uint64_t seed,
                       hipStream_t stream) {
+  if (g_attn_fwd_variant == 1 && Ntok % 256 == 0) {
+    dim3 grid2(B * H * (Ntok / 256));
+    if (p_drop > 0.f)
+      hipLaunchKernelGGL((attn_fwd2_bx3_kernel<true>), grid2, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ld, ldo,
+                         scale, p_drop, seed, H);
+    else
+      hipLaunchKernelGGL((attn_fwd2_bx3_kernel<false>), grid2, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ld, ldo,
+                         scale, p_drop, seed, H);
+    return 0;
+  }
   dim3 grid(B * H * (Ntok / 128));
   if (p_drop > 0.f)
     hipLaunchKernelGGL((attn_fwd_bx3_kernel<true>), grid, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ld, ldo, scale,
@@ -479,6 +626,10 @@ int focr_attn_fwd_bx3(const float* q, const float* k, const float* v, float* o, 
                        p_drop, seed, H);
   return 0;
 }
+#ifndef FOCR_ATTN_BWD_VARIANT
+#define FOCR_ATTN_BWD_VARIANT 0
+#endif
+int g_attn_bwd_variant = FOCR_ATTN_BWD_VARIANT;
 int focr_attn_bwd_bx3(const float* q, const float* k, const float* v, const float* d_o, const float* lse,
                       const float* dwork, const uint32_t* mask, float* dq, float* dk, float* dv, int B, int H,
                       int Ntok, int ld, int ldo, float scale, float p_drop, hipStream_t stream) {

@@ -8,6 +8,8 @@ import shutil
 
 import torch
 
+from ..dataset import dataset
+from ..dataset import shards
 from ..dataset.dataset import SyntheticTextZoom
 from ..loss.ctc_focus_loss import CTCFocusLoss
 from ..model import tbsrn, tsrn
@@ -66,16 +68,68 @@ class TextBase(object):
         self.logging = logging
 
     # ---- data ------------------------------------------------------------------------------
+    # reference interfaces/base.py:67-69,91-136: `load_dataset` / `align_collate` pick the dataset and collate classes,
+    # get_train_data concatenates TRAIN.train_data_dir, get_val_data / get_test_data build one loader per directory.
+    # A directory holding a `meta.json` is a pre-decoded shard (dataset/shards.py: pinned staging, async H2D, device
+    # transform); anything else is opened as a TextZoom LMDB through the reference-API classes (needs `lmdb`).
+    # With no directories configured the harness runs on seeded synthetic TextZoom-shaped batches.
+    def _dataset_classes(self):
+        a = self.args
+        if getattr(a, "syn", False):
+            return dataset.lmdbDataset, dataset.alignCollate_syn
+        if getattr(a, "mixed", False):
+            return dataset.lmdbDataset_mix, dataset.alignCollate_real
+        return dataset.lmdbDataset_real, dataset.alignCollate_real
+
+    @property
+    def load_dataset(self):
+        return self._dataset_classes()[0]
+
+    @property
+    def align_collate(self):
+        return self._dataset_classes()[1]
+
+    def _loader(self, dirs, test):
+        cfg = self.config.TRAIN
+        if all(shards.is_shard(d) for d in dirs):
+            sets = [shards.ShardDataset(d, voc_type=cfg.voc_type, max_len=cfg.max_len) for d in dirs]
+            loader = shards.ShardLoader(sets, self.batch_size, self.device, shuffle=not test, drop_last=not test,
+                                        mask=self.mask, seed=cfg.manualSeed, rank=0 if test else self.rank,
+                                        world=1 if test else self.world)
+            return sets, loader
+        sets = [self.load_dataset(root=d, voc_type=cfg.voc_type, max_len=cfg.max_len, test=test) for d in dirs]
+        ds = dataset.ConcatDataset(sets)
+        sampler = None
+        if self.world > 1 and not test:
+            sampler = torch.utils.data.distributed.DistributedSampler(ds, self.world, self.rank, shuffle=True,
+                                                                      seed=int(cfg.manualSeed), drop_last=True)
+        loader = torch.utils.data.DataLoader(
+            ds, batch_size=self.batch_size, shuffle=(not test and sampler is None), sampler=sampler,
+            num_workers=int(cfg.workers), drop_last=not test,
+            collate_fn=self.align_collate(imgH=cfg.height, imgW=cfg.width, down_sample_scale=cfg.down_sample_scale,
+                                          mask=self.mask))
+        return ds, loader
+
     def get_train_data(self):
         cfg = self.config.TRAIN
+        if not isinstance(cfg.train_data_dir, list):
+            raise TypeError("check trainRoot")
         if cfg.train_data_dir:
-            raise NotImplementedError("TextZoom LMDB reader is not built in this image (SURVEY.md 8f N3)")
+            return self._loader(list(cfg.train_data_dir), test=False)
         # every rank draws its own shard of the global minibatch (seed + rank), as DataParallel's scatter did
         ds = SyntheticTextZoom(self.batch_size, int(getattr(cfg, "iters_per_epoch", 20)),
                                cfg.manualSeed + 1000 * self.rank, self.mask)
         return ds, ds
 
+    def get_test_data(self, dir_):
+        return self._loader([dir_], test=True)
+
     def get_val_data(self):
+        cfg = self.config.TRAIN
+        assert isinstance(cfg.VAL.val_data_dir, list)
+        if cfg.VAL.val_data_dir:
+            pairs = [self.get_test_data(d) for d in cfg.VAL.val_data_dir]
+            return [p[0] for p in pairs], [p[1] for p in pairs]
         ds = SyntheticTextZoom(self.batch_size, 2, 99, self.mask)
         return [ds], [ds]
 

@@ -8,6 +8,7 @@ from datetime import datetime
 
 import torch
 
+from ..utils import ssim_psnr
 from ..utils.util import str_filt
 from ..utils.utils_crnn import get_crnn_pred
 from . import base
@@ -66,8 +67,9 @@ class TextSR(base.TextBase):
             images_hr, images_lr, label_strs = data
             images_lr, images_hr = images_lr.to(self.device), images_hr.to(self.device)
             images_sr = model(images_lr)
-            psnr.append(float(self.cal_psnr(images_sr, images_hr)))
-            ssim.append(float(self.cal_ssim(images_sr, images_hr)))
+            p_, s_ = ssim_psnr.psnr_ssim(images_sr, images_hr)      # one fused device pass (cal_psnr / cal_ssim
+            psnr.append(float(p_))                                  # give the same values one metric at a time)
+            ssim.append(float(s_))
             if recognizer is not None:
                 out = recognizer(self.parse_crnn_data(images_sr[:, :3])).permute(1, 0, 2).contiguous()
                 pred = self.get_crnn_pred(out)
@@ -81,7 +83,12 @@ class TextSR(base.TextBase):
 
     def test(self):
         md = self.generator_init()
-        _, loaders = self.get_val_data()
+        tdir = getattr(self.args, "test_data_dir", "") or ""
+        if tdir and os.path.isdir(tdir):          # reference test(): one loader per sub-directory of --test_data_dir
+            subs = [os.path.join(tdir, d) for d in sorted(os.listdir(tdir)) if os.path.isdir(os.path.join(tdir, d))]
+            loaders = [self.get_test_data(d)[1] for d in (subs or [tdir])]
+        else:
+            _, loaders = self.get_val_data()
         t0 = time.time()
         res = [self.eval(md["model"], ld, md["crit"], 0, md["recognizer"]) for ld in loaders]
         n = sum(len(ld) for ld in loaders) * self.batch_size

@@ -245,6 +245,20 @@ int focr_clip_adam(float* p, const float* g, float* m, float* v, const float* su
                    float beta1, float beta2, float eps, int step, float max_norm, float gscale,
                    focr_stream_t stream);
 
+/* ---- evaluation metrics on the device (utils/ssim_psnr.py:9-78; interfaces/super_resolution.py:178-181) ------
+ * One pass over an NCHW pair (first 3 channels): sq_sum[b] = sum (255 a - 255 b)^2, ssim_sum[b] = sum of the SSIM map
+ * (window_size-tap normalised Gaussian `window_host`, a HOST array; zero padding; C1 = 0.01^2, C2 = 0.03^2).
+ * ws: focr_psnr_ssim_ws_floats(B, H, W) floats. */
+long focr_psnr_ssim_ws_floats(int B, int H, int W);
+int focr_psnr_ssim(const float* img1, const float* img2, const float* window_host, int window_size, float* sq_sum,
+                   float* ssim_sum, float* ws, int B, int C, int H, int W, focr_stream_t stream);
+
+/* ---- input pipeline, device half of resizeNormalize (dataset/dataset.py:136-152) ------------------------------
+ * uint8 [B,H,W,3] -> float32 [B,3(+1),H,W]: ToTensor (/255) and, with mask = 1, the mean-threshold mask channel
+ * (PIL integer luma, 1.0 where luma <= the image's mean luma).  Bit-identical to the reference's CPU transform. */
+int focr_u8_to_input(const unsigned char* u8_nhwc, float* out_nchw, int B, int H, int W, int mask,
+                     focr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

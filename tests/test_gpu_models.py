@@ -292,3 +292,28 @@ def test_harness_demo_and_dispatch(tmp_path, monkeypatch):
     assert not (tmp_path / "checkpoint").exists()              # a demo run never touches the checkpoint directory
     with pytest.raises(NotImplementedError):
         M.main(cfg, M.parse(["--arch", "tbsrn", "--exp_name", "d", "--text_focus"]))
+
+
+def test_eval_metrics_on_device(golden_dir):
+    """row N4: PSNR / SSIM from the fused HIP pass against fixture F9 (values produced by the reference's
+    utils/ssim_psnr.py) and, on other shapes / the per-image form, against the torch formula in float64"""
+    from fudanocr_amd.utils import ssim_psnr
+    ref = json.load(open(os.path.join(golden_dir, "metrics.json")))
+    g = torch.Generator().manual_seed(11)
+    ia = torch.rand(3, 3, 32, 128, generator=g)
+    ib = (ia + 0.1 * torch.randn(3, 3, 32, 128, generator=g)).clamp(0, 1)
+    assert abs(float(ssim_psnr.calculate_psnr(ia.cuda(), ib.cuda())) - ref["psnr"]) < 1e-4
+    assert abs(float(ssim_psnr.SSIM()(ia.cuda(), ib.cuda())) - ref["ssim"]) < 1e-5
+    p, s = ssim_psnr.psnr_ssim(ia.cuda(), ib.cuda())
+    assert abs(float(p) - ref["psnr"]) < 1e-4 and abs(float(s) - ref["ssim"]) < 1e-5
+    # 4-channel (mask) input: only the first three channels count; odd sizes; per-image means
+    a = torch.rand(5, 4, 17, 37, generator=g)
+    b = (a + 0.05 * torch.randn(5, 4, 17, 37, generator=g)).clamp(0, 1)
+    want = ssim_psnr.SSIM(size_average=False)(a.double(), b.double())
+    got = ssim_psnr.SSIM(size_average=False)(a.cuda(), b.cuda())
+    assert (got.cpu().double() - want).abs().max() < 1e-5
+    assert abs(float(ssim_psnr.calculate_psnr(a.cuda(), b.cuda())) - float(ssim_psnr.calculate_psnr(a.double(), b.double()))) < 1e-4
+    with pytest.raises(RuntimeError):
+        ssim_psnr.calculate_psnr(a.cuda(), b.cuda()[:, :2])
+    vals = {float(ssim_psnr.SSIM()(ia.cuda(), ib.cuda())) for _ in range(3)}
+    assert len(vals) == 1

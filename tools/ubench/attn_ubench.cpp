@@ -1,0 +1,83 @@
+// Standalone micro-benchmark of the attention kernels (no torch): variant A/B in one process, outputs compared.
+//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/attn_ubench.cpp -o build/attn_ubench
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include <cmath>
+#include <algorithm>
+#include "../../fudanocr_amd/csrc/attention.hip"
+#include "../../fudanocr_amd/csrc/attention_bx3.hip"
+
+extern "C" void focr_set_error(const char* fmt, ...) { va_list a; va_start(a, fmt); vfprintf(stderr, fmt, a); va_end(a); fputc('\n', stderr); }
+static int g_prec = 2;
+extern "C" int focr_get_precision(void) { return g_prec; }
+extern int g_attn_fwd_variant;
+extern int g_attn_bwd_variant;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+__global__ void fill_kernel(float* p, long n, uint32_t seed, float scale) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { uint32_t h = hash32((uint32_t)i * 2654435761u + seed); p[i] = scale * ((h >> 8) * (1.f / 8388608.f) - 1.f); }
+}
+static float* dalloc(long n, uint32_t seed, float scale) {
+  float* p; CK(hipMalloc(&p, n * sizeof(float)));
+  if (seed) hipLaunchKernelGGL(fill_kernel, dim3((n + 255) / 256), 256, 0, 0, p, n, seed, scale);
+  return p;
+}
+template <class F> static float timeit(F fn, int iters = 10) {
+  const int REP = 5;
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  for (int i = 0; i < 2; ++i) fn();
+  std::vector<float> ts;
+  for (int i = 0; i < iters; ++i) { CK(hipEventRecord(a, 0)); for (int r = 0; r < REP; ++r) fn(); CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b)); float ms; CK(hipEventElapsedTime(&ms, a, b)); ts.push_back(ms * 1e3f / REP); }
+  std::sort(ts.begin(), ts.end());
+  return ts[ts.size() / 2];
+}
+static double maxdiff(const float* da, const float* db, long n, double* mx) {
+  std::vector<float> a(n), b(n);
+  CK(hipMemcpy(a.data(), da, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), db, n * 4, hipMemcpyDeviceToHost));
+  double m = 0, r = 0;
+  for (long i = 0; i < n; ++i) { double d = fabs((double)a[i] - b[i]); if (!(d <= m)) m = d; r = std::max(r, (double)fabsf(a[i])); }
+  *mx = r;
+  return m;
+}
+
+int main(int argc, char** argv) {
+  const int B = argc > 1 ? atoi(argv[1]) : 128, H = 4, N = 1024, D = 128;
+  const long n = (long)B * N * D;
+  float *q = dalloc(n, 1, 2.f), *k = dalloc(n, 2, 2.f), *v = dalloc(n, 3, 1.f), *dO = dalloc(n, 4, 1.f);
+  float *o0 = dalloc(n, 0, 0), *o1 = dalloc(n, 0, 0), *lse0 = dalloc((long)B * H * N, 0, 0), *lse1 = dalloc((long)B * H * N, 0, 0);
+  float *dq0 = dalloc(n, 0, 0), *dk0 = dalloc(n, 0, 0), *dv0 = dalloc(n, 0, 0), *dq1 = dalloc(n, 0, 0), *dk1 = dalloc(n, 0, 0), *dv1 = dalloc(n, 0, 0);
+  float* work = dalloc((long)B * H * N, 0, 0);
+  uint32_t* mask; CK(hipMalloc(&mask, (size_t)B * H * N * (N / 32) * 4));
+  const float scale = 1.f / sqrtf(32.f);
+  const double fl = 4.0 * B * H * (double)N * N * 32;
+  for (float p : {0.1f, 0.0f}) {
+    g_attn_fwd_variant = 0;
+    focr_attention_fwd(q, k, v, o0, lse0, mask, B, H, N, D, D, scale, p, 1234, 0);
+    float t0 = timeit([&]() { focr_attention_fwd(q, k, v, o0, lse0, mask, B, H, N, D, D, scale, p, 1234, 0); });
+    g_attn_fwd_variant = 1;
+    focr_attention_fwd(q, k, v, o1, lse1, mask, B, H, N, D, D, scale, p, 1234, 0);
+    float t1 = timeit([&]() { focr_attention_fwd(q, k, v, o1, lse1, mask, B, H, N, D, D, scale, p, 1234, 0); });
+    float tm = p > 0 ? timeit([&]() { hipLaunchKernelGGL(attn_mask_kernel, dim3(262144), 256, 0, 0, mask, (long)B * H * N * (N / 32), p, (uint64_t)1234); }) : 0.f;
+    CK(hipDeviceSynchronize());
+    double mx, e = maxdiff(o0, o1, n, &mx), mx2, e2 = maxdiff(lse0, lse1, (long)B * H * N, &mx2);
+    printf("fwd p=%.1f: variant0 %7.1f us (%5.0f TF)  variant1 %7.1f us (%5.0f TF)  [mask kernel alone %6.1f us]  max|dO| %.2e of %.2e, max|dLSE| %.2e\n",
+           p, t0, fl / t0 / 1e6, t1, fl / t1 / 1e6, tm, e, mx, e2);
+    // backward (variants of the backward are compared the same way once they exist)
+    g_attn_bwd_variant = 0;
+    focr_attention_bwd(q, k, v, o0, dO, lse0, mask, dq0, dk0, dv0, work, B, H, N, D, D, scale, p, 0);
+    float b0 = timeit([&]() { focr_attention_bwd(q, k, v, o0, dO, lse0, mask, dq0, dk0, dv0, work, B, H, N, D, D, scale, p, 0); });
+    g_attn_bwd_variant = 1;
+    focr_attention_bwd(q, k, v, o0, dO, lse0, mask, dq1, dk1, dv1, work, B, H, N, D, D, scale, p, 0);
+    float b1 = timeit([&]() { focr_attention_bwd(q, k, v, o0, dO, lse0, mask, dq1, dk1, dv1, work, B, H, N, D, D, scale, p, 0); });
+    CK(hipDeviceSynchronize());
+    double m1, m2, m3;
+    double eq = maxdiff(dq0, dq1, n, &m1), ek = maxdiff(dk0, dk1, n, &m2), ev = maxdiff(dv0, dv1, n, &m3);
+    printf("bwd p=%.1f: variant0 %7.1f us  variant1 %7.1f us  max diff dq %.2e/%.2e dk %.2e/%.2e dv %.2e/%.2e\n", p, b0, b1, eq, m1, ek, m2, ev, m3);
+    fflush(stdout);
+  }
+  return 0;
+}
