@@ -14,7 +14,9 @@ Rules (chosen so that every layer is numerically "alive"):
     by 1e-3 on noise images.  They are state_dict entries, so overwriting them is a plain load.
   * BatchNorm (a key that has a sibling ``running_mean``): weight U[0.5,1.5],
     bias U[-0.1,0.1], running_mean U[-0.1,0.1], running_var U[0.5,1.5].
-  * LayerNorm ``a_2`` U[0.5,1.5], ``b_2`` U[-0.1,0.1]  (reference tbsrn.py:23-36).
+  * LayerNorm ``a_2`` U[0.5,1.5], ``b_2`` U[-0.1,0.1]  (reference tbsrn.py:23-36); the stroke-level-decomposition
+    transformer names them ``a`` / ``b`` (SLD model/transformer.py:247-248): same ranges.
+  * ``pe.pe`` (the SLD positional-encoding buffer, a state_dict entry): untouched.
   * PReLU slope (shape [1] weight): U[0.1,0.4].
   * dim >= 2: U[-1/sqrt(fan_in), +1/sqrt(fan_in)], fan_in = numel / shape[0];
     ``stn_head.stn_fc2.weight`` additionally scaled by 0.2 (keeps the warp mild).
@@ -96,7 +98,9 @@ def fill_value(key, shape, siblings):
         if leaf == "running_var":
             return _u(shape, 0.5, 1.5, key)
         return None
-    if leaf == "a_2":
+    if leaf == "pe" and len(shape) == 3:
+        return None
+    if leaf == "a_2" or (leaf == "a" and len(shape) == 1):
         return _u(shape, 0.5, 1.5, key)
     if leaf == "b_2":
         return _u(shape, -0.1, 0.1, key)
