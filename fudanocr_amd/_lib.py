@@ -72,6 +72,14 @@ SIGNATURES = {
     "focr_psnr_ssim_ws_floats": [I, I, I],
     "focr_psnr_ssim": [P, P, P, I, P, P, P, I, I, I, I, P],
     "focr_u8_to_input": [P, P, I, I, I, I, P],
+    "focr_add_relu_fwd": [P, P, P, L, P],
+    "focr_embedding_fwd": [P, P, P, L, I, F, P],
+    "focr_embedding_bwd": [P, P, P, L, I, F, P],
+    "focr_gather_rows": [P, P, P, L, I, I, P],
+    "focr_cross_entropy_fwd": [P, P, P, P, P, L, I, P],
+    "focr_adadelta": [P, P, P, P, L, F, F, F, F, P],
+    "focr_small_attention_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, F, U, P],
+    "focr_small_attention_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, P],
     "focr_set_precision": [I],
     "focr_get_precision": [],
     "focr_clip_adam": [P, P, P, P, P, L, F, F, F, F, I, F, F, P],

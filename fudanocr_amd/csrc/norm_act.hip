@@ -749,11 +749,22 @@ extern "C" int focr_bn_bwd(const float* dz, const float* x, const float* gamma, 
   return FOCR_OK;
 }
 
+int focr_ln_any_fwd(const float* x, const float* res, const float* a, const float* b, float* y, float* save_mean,
+                    float* save_rinv, long rows, int D, float eps, hipStream_t stream);
+int focr_ln_any_bwd(const float* dy, const float* x, const float* res, const float* a, const float* save_mean,
+                    const float* save_rinv, float* dx, float* da, float* db, long rows, int D, float eps,
+                    hipStream_t stream);
+
 extern "C" int focr_layernorm_fwd(const float* x, const float* residual, const float* a,
                                   const float* b, float* y, float* save_mean, float* save_rinv,
                                   long rows, int D, float eps, hipStream_t stream) {
   FOCR_CHECK_ARG(x && a && b && y && save_mean && save_rinv, "null pointer");
-  FOCR_CHECK_ARG(D == 128 && rows > 0, "only D == 128 is built");
+  FOCR_CHECK_ARG(D >= 2 && rows > 0, "bad shape");
+  if (D != 128) {                    // generic width (the SLD decoder's D = 1024): csrc/sld_ops.hip
+    focr_ln_any_fwd(x, residual, a, b, y, save_mean, save_rinv, rows, D, eps, stream);
+    FOCR_LAUNCH_CHECK();
+    return FOCR_OK;
+  }
   hipLaunchKernelGGL((ln_fwd_kernel<128>), dim3(cdiv(rows, 8)), 256, 0, stream, x, residual, a, b, y,
                      save_mean, save_rinv, rows, eps);
   FOCR_LAUNCH_CHECK();
@@ -765,10 +776,15 @@ extern "C" int focr_layernorm_bwd(const float* dy, const float* x, const float* 
                                   float* dx, float* da, float* db, long rows, int D, float eps,
                                   int prezeroed, hipStream_t stream) {
   FOCR_CHECK_ARG(dy && x && a && save_mean && save_rinv && dx && da && db, "null pointer");
-  FOCR_CHECK_ARG(D == 128 && rows > 0, "only D == 128 is built");
+  FOCR_CHECK_ARG(D >= 2 && rows > 0, "bad shape");
   if (!prezeroed) {
     MEMSET0(da, sizeof(float) * D);
     MEMSET0(db, sizeof(float) * D);
+  }
+  if (D != 128) {
+    focr_ln_any_bwd(dy, x, residual, a, save_mean, save_rinv, dx, da, db, rows, D, eps, stream);
+    FOCR_LAUNCH_CHECK();
+    return FOCR_OK;
   }
 #ifndef LN_BWD_BLOCKS
 #define LN_BWD_BLOCKS 512   // same-address atomics of the a_2/b_2 gradients dominate beyond this (2048: 78 us, 512: 54 us)

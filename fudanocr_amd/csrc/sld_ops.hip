@@ -1,0 +1,382 @@
+// Operators of the stroke-level-decomposition transformer recognizer (BASELINE configs[4]; reference
+// /root/reference/stroke-level-decomposition/model/transformer.py, train.py) that the SR path does not have:
+//   * generic-width LayerNorm (custom: unbiased std, eps on std; transformer.py:241-251, D = 1024),
+//   * relu(a + b) of the ResNet BasicBlock (transformer.py:66-75),
+//   * embedding lookup * sqrt(d) (transformer.py:269-277),
+//   * attention for FEW queries and long heads (4 heads x d_k 256, <= 30 queries, 30 / 256 keys; optional causal mask
+//     and dropout on the probabilities; transformer.py:184-238) -- one workgroup per (batch, head), fp32 FMA: the
+//     decoder is 4 % of the model's flops, the 3x3 convolutions of the encoder run on the halo kernel,
+//   * ragged row gather of the predictions (transformer.py:362-370), cross-entropy (train.py:41,70),
+//   * Adadelta (train.py:36-38) fused over the flat parameter buffer.
+#include "focr_common.h"
+
+// ------------------------------------------------------------------------------------------------- LayerNorm, any D
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void ln_any_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                         const float* __restrict__ a, const float* __restrict__ b,
+                                                         float* __restrict__ y, float* __restrict__ save_mean,
+                                                         float* __restrict__ save_rinv, int D, float eps) {
+  __shared__ float red[4];
+  const long row = blockIdx.x;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < D; i += 256) s += x[row * D + i] + (res ? res[row * D + i] : 0.f);
+  const float mean = block_sum256(s, red) / D;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < D; i += 256) {
+    const float u = x[row * D + i] + (res ? res[row * D + i] : 0.f) - mean;
+    q += u * u;
+  }
+  const float sd = sqrtf(block_sum256(q, red) / (D - 1));
+  const float rinv = 1.f / (sd + eps);
+  for (int i = threadIdx.x; i < D; i += 256) {
+    const float u = x[row * D + i] + (res ? res[row * D + i] : 0.f) - mean;
+    y[row * D + i] = a[i] * u * rinv + b[i];
+  }
+  if (threadIdx.x == 0) {
+    save_mean[row] = mean;
+    save_rinv[row] = rinv;
+  }
+}
+
+// dx (also the residual's gradient); da / db accumulated with atomics (few hundred rows)
+__global__ __launch_bounds__(256) void ln_any_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         const float* __restrict__ res, const float* __restrict__ a,
+                                                         const float* __restrict__ save_mean,
+                                                         const float* __restrict__ save_rinv, float* __restrict__ dx,
+                                                         float* __restrict__ da, float* __restrict__ db, int D,
+                                                         float eps) {
+  __shared__ float red[4];
+  const long row = blockIdx.x;
+  const float mean = save_mean[row], rinv = save_rinv[row], sd = 1.f / rinv - eps;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < D; i += 256) {
+    const float u = x[row * D + i] + (res ? res[row * D + i] : 0.f) - mean;
+    const float dn = dy[row * D + i] * a[i];
+    s1 += dn;
+    s2 += dn * u;
+  }
+  const float s_dn = block_sum256(s1, red);
+  const float s_dnu = block_sum256(s2, red);
+  const float k = rinv * rinv * s_dnu / ((D - 1) * sd), mdn = rinv * s_dn / D;
+  for (int i = threadIdx.x; i < D; i += 256) {
+    const float u = x[row * D + i] + (res ? res[row * D + i] : 0.f) - mean;
+    const float g = dy[row * D + i];
+    dx[row * D + i] = g * a[i] * rinv - k * u - mdn;
+    atomicAdd(&da[i], g * u * rinv);
+    atomicAdd(&db[i], g);
+  }
+}
+
+int focr_ln_any_fwd(const float* x, const float* res, const float* a, const float* b, float* y, float* save_mean,
+                    float* save_rinv, long rows, int D, float eps, hipStream_t stream) {
+  hipLaunchKernelGGL(ln_any_fwd_kernel, dim3((int)rows), 256, 0, stream, x, res, a, b, y, save_mean, save_rinv, D, eps);
+  return 1;
+}
+int focr_ln_any_bwd(const float* dy, const float* x, const float* res, const float* a, const float* save_mean,
+                    const float* save_rinv, float* dx, float* da, float* db, long rows, int D, float eps,
+                    hipStream_t stream) {
+  hipLaunchKernelGGL(ln_any_bwd_kernel, dim3((int)rows), 256, 0, stream, dy, x, res, a, save_mean, save_rinv, dx, da,
+                     db, D, eps);
+  return 1;
+}
+
+// ------------------------------------------------------------------------------------------------- relu(a + b)
+__global__ __launch_bounds__(256) void add_relu_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           float* __restrict__ y, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i];
+    reinterpret_cast<float4*>(y)[i] = make_float4(fmaxf(u.x + v.x, 0.f), fmaxf(u.y + v.y, 0.f), fmaxf(u.z + v.z, 0.f),
+                                                  fmaxf(u.w + v.w, 0.f));
+  }
+}
+extern "C" int focr_add_relu_fwd(const float* a, const float* b, float* y, long n, hipStream_t stream) {
+  FOCR_CHECK_ARG(a && b && y && n > 0 && n % 4 == 0, "need n % 4 == 0");
+  long g = (n / 4 + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(add_relu_fwd_kernel, dim3((int)g), 256, 0, stream, a, b, y, n / 4);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+// backward = focr_relu_bwd(dy, y, g): the same gradient goes to both addends
+
+// ------------------------------------------------------------------------------------------------- embedding
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(const long long* __restrict__ idx,
+                                                            const float* __restrict__ table, float* __restrict__ y,
+                                                            long rows, int D, float scale) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * D; i += (long)gridDim.x * 256) {
+    const long r = i / D;
+    const int c = (int)(i - r * D);
+    y[i] = table[idx[r] * D + c] * scale;
+  }
+}
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const long long* __restrict__ idx,
+                                                            const float* __restrict__ dy, float* __restrict__ dtable,
+                                                            long rows, int D, float scale) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * D; i += (long)gridDim.x * 256) {
+    const long r = i / D;
+    const int c = (int)(i - r * D);
+    atomicAdd(&dtable[idx[r] * D + c], dy[i] * scale);
+  }
+}
+extern "C" int focr_embedding_fwd(const long long* idx, const float* table, float* y, long rows, int D, float scale,
+                                  hipStream_t stream) {
+  FOCR_CHECK_ARG(idx && table && y && rows > 0 && D > 0, "bad argument");
+  long g = (rows * D + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(embedding_fwd_kernel, dim3((int)g), 256, 0, stream, idx, table, y, rows, D, scale);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+// dtable[V][D] is ACCUMULATED into (caller zeroes it, or passes a slice of the zeroed flat gradient buffer)
+extern "C" int focr_embedding_bwd(const long long* idx, const float* dy, float* dtable, long rows, int D, float scale,
+                                  hipStream_t stream) {
+  FOCR_CHECK_ARG(idx && dy && dtable && rows > 0 && D > 0, "bad argument");
+  long g = (rows * D + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3((int)g), 256, 0, stream, idx, dy, dtable, rows, D, scale);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- ragged gather
+// out[r] = in[idx[r]] (rows of D floats); mode 1: scatter (in[idx[r]] = out[r], the gather's backward; the caller
+// zeroes `in` first -- the indices of the prediction gather are unique)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const long long* __restrict__ idx,
+                                                          float* __restrict__ dst, long rows, int D, int scatter) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * D; i += (long)gridDim.x * 256) {
+    const long r = i / D;
+    const int c = (int)(i - r * D);
+    if (scatter) dst[idx[r] * D + c] = src[i];
+    else dst[i] = src[idx[r] * D + c];
+  }
+}
+extern "C" int focr_gather_rows(const float* src, const long long* idx, float* dst, long rows, int D, int scatter,
+                                hipStream_t stream) {
+  FOCR_CHECK_ARG(src && idx && dst && rows > 0 && D > 0, "bad argument");
+  long g = (rows * D + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((int)g), 256, 0, stream, src, idx, dst, rows, D, scatter);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- cross-entropy
+// loss = mean_r ( logsumexp(x[r]) - x[r][t_r] ), grad[r][c] = (softmax(x[r])[c] - [c == t_r]) / rows.
+// C <= 64 classes: one lane per class, one wave per row; the batch mean is a fixed-order fold (deterministic).
+__global__ __launch_bounds__(64) void ce_rows_kernel(const float* __restrict__ x, const long long* __restrict__ target,
+                                                     float* __restrict__ nll, float* __restrict__ grad, long rows,
+                                                     int C) {
+  const long r = blockIdx.x;
+  const int c = threadIdx.x;
+  const float v = c < C ? x[r * C + c] : -1e30f;
+  const float mx = wave_max(v);
+  const float e = c < C ? expf(v - mx) : 0.f;
+  const float sum = wave_sum(e);
+  const int t = (int)target[r];
+  if (c < C) grad[r * C + c] = (e / sum - (c == t ? 1.f : 0.f)) / (float)rows;
+  const float picked = wave_sum(c == t ? v : 0.f);
+  if (c == 0) nll[r] = mx + logf(sum) - picked;
+}
+__global__ __launch_bounds__(64) void ce_fold_kernel(const float* __restrict__ nll, float* __restrict__ loss, long rows) {
+  float acc = 0.f;
+  for (long r = threadIdx.x; r < rows; r += 64) acc += nll[r];
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) loss[0] = acc / (float)rows;
+}
+extern "C" int focr_cross_entropy_fwd(const float* logits, const long long* target, float* loss, float* nll_ws,
+                                      float* grad, long rows, int C, hipStream_t stream) {
+  FOCR_CHECK_ARG(logits && target && loss && nll_ws && grad && rows > 0 && C > 1 && C <= 64, "need 2 <= C <= 64");
+  hipLaunchKernelGGL(ce_rows_kernel, dim3((int)rows), 64, 0, stream, logits, target, nll_ws, grad, rows, C);
+  hipLaunchKernelGGL(ce_fold_kernel, dim3(1), 64, 0, stream, (const float*)nll_ws, loss, rows);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- Adadelta
+// torch.optim.Adadelta(lr, rho, eps): sq = rho sq + (1-rho) g^2; delta = sqrt(acc + eps) / sqrt(sq + eps) * g;
+// acc = rho acc + (1-rho) delta^2; p -= lr * delta.  gscale folds the data-parallel 1/world averaging into g.
+__global__ __launch_bounds__(256) void adadelta_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ sq, float* __restrict__ acc, long n,
+                                                       float lr, float rho, float eps, float gscale) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gi = g[i] * gscale;
+    const float s = rho * sq[i] + (1.f - rho) * gi * gi;
+    const float d = sqrtf(acc[i] + eps) / sqrtf(s + eps) * gi;
+    sq[i] = s;
+    acc[i] = rho * acc[i] + (1.f - rho) * d * d;
+    p[i] -= lr * d;
+  }
+}
+extern "C" int focr_adadelta(float* p, const float* g, float* sq, float* acc, long n, float lr, float rho, float eps,
+                             float gscale, hipStream_t stream) {
+  FOCR_CHECK_ARG(p && g && sq && acc && n > 0, "bad argument");
+  long gr = (n + 255) / 256;
+  if (gr > 8192) gr = 8192;
+  hipLaunchKernelGGL(adadelta_kernel, dim3((int)gr), 256, 0, stream, p, g, sq, acc, n, lr, rho, eps, gscale);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- attention
+// q [B, Lq, H*Dk] (row pitch ldq), k / v [B, Lk, H*Dk] (pitch ldk); head h = columns h*Dk .. h*Dk + Dk - 1.
+// One workgroup (256 threads) per (b, h).  P (softmax, before dropout) and Pd (after dropout: what multiplies V and
+// what the reference returns as the attention map) are written [B, H, Lq, Lk] for the backward.
+// causal: key j visible to query i iff j <= i (subsequent_mask, transformer.py:203-207).
+#define SA_LKMAX 256
+template <int DK>
+__global__ __launch_bounds__(256) void small_attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                             const float* __restrict__ V, float* __restrict__ O,
+                                                             float* __restrict__ P, float* __restrict__ Pd, int H,
+                                                             int Lq, int Lk, int ldq, int ldk, int ldo, float scale,
+                                                             int causal, uint32_t drop_thr, float keep_scale,
+                                                             uint64_t seed) {
+  __shared__ float qs[DK];
+  __shared__ float ps[SA_LKMAX];
+  __shared__ float red[4];
+  const int b = blockIdx.x / H, h = blockIdx.x % H, tid = threadIdx.x;
+  const float* qb = Q + (size_t)b * Lq * ldq + h * DK;
+  const float* kb = K + (size_t)b * Lk * ldk + h * DK;
+  const float* vb = V + (size_t)b * Lk * ldk + h * DK;
+  float* ob = O + (size_t)b * Lq * ldo + h * DK;
+  const size_t pbase = ((size_t)b * H + h) * Lq * Lk;
+  for (int i = 0; i < Lq; ++i) {
+    __syncthreads();
+    for (int d = tid; d < DK; d += 256) qs[d] = qb[(size_t)i * ldq + d];
+    __syncthreads();
+    // scores: thread = key
+    float s = -1e30f;
+    if (tid < Lk && (!causal || tid <= i)) {
+      const float4* kr = reinterpret_cast<const float4*>(kb + (size_t)tid * ldk);
+      float acc = 0.f;
+#pragma unroll 8
+      for (int d4 = 0; d4 < DK / 4; ++d4) {
+        const float4 kv = kr[d4];
+        acc += qs[4 * d4] * kv.x + qs[4 * d4 + 1] * kv.y + qs[4 * d4 + 2] * kv.z + qs[4 * d4 + 3] * kv.w;
+      }
+      s = acc * scale;
+    }
+    float mx = wave_max(s);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float e = s > -1e29f ? expf(s - mx) : 0.f;
+    const float sum = block_sum256(e, red);
+    const float p = e / sum;
+    float pd = p;
+    if (drop_thr) {
+      const uint32_t r = rng_hash(seed, (pbase + (size_t)i * Lk + tid)) >> 16;
+      pd = r < drop_thr ? 0.f : p * keep_scale;
+    }
+    if (tid < Lk) {
+      P[pbase + (size_t)i * Lk + tid] = p;
+      Pd[pbase + (size_t)i * Lk + tid] = pd;
+      ps[tid] = pd;
+    }
+    __syncthreads();
+    // output: thread = head dim
+    for (int d = tid; d < DK; d += 256) {
+      float acc = 0.f;
+      const int kend = causal ? i + 1 : Lk;
+      for (int j = 0; j < kend; ++j) acc += ps[j] * vb[(size_t)j * ldk + d];
+      ob[(size_t)i * ldo + d] = acc;
+    }
+  }
+}
+
+// backward: dQ, dK, dV (overwritten).  dS[i][j] = P (dropmask/keep * dPd - sum_j Pd dPd) with dPd = dO . V.
+template <int DK>
+__global__ __launch_bounds__(256) void small_attn_bwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                             const float* __restrict__ V, const float* __restrict__ dO,
+                                                             const float* __restrict__ P, const float* __restrict__ Pd,
+                                                             float* __restrict__ dQ, float* __restrict__ dK,
+                                                             float* __restrict__ dV, float* __restrict__ dS, int H,
+                                                             int Lq, int Lk, int ldq, int ldk, int ldo, float scale,
+                                                             int causal) {
+  __shared__ float gs[DK];
+  __shared__ float red[4];
+  const int b = blockIdx.x / H, h = blockIdx.x % H, tid = threadIdx.x;
+  const float* qb = Q + (size_t)b * Lq * ldq + h * DK;
+  const float* kb = K + (size_t)b * Lk * ldk + h * DK;
+  const float* vb = V + (size_t)b * Lk * ldk + h * DK;
+  const float* gb = dO + (size_t)b * Lq * ldo + h * DK;
+  const size_t pbase = ((size_t)b * H + h) * Lq * Lk;
+  float* ds = dS + pbase;                                  // workspace [B, H, Lq, Lk]
+  // phase A: dS rows
+  for (int i = 0; i < Lq; ++i) {
+    __syncthreads();
+    for (int d = tid; d < DK; d += 256) gs[d] = gb[(size_t)i * ldo + d];
+    __syncthreads();
+    float dpd = 0.f, p = 0.f, pd = 0.f;
+    const bool vis = tid < Lk && (!causal || tid <= i);
+    if (vis) {
+      const float4* vr = reinterpret_cast<const float4*>(vb + (size_t)tid * ldk);
+      float acc = 0.f;
+#pragma unroll 8
+      for (int d4 = 0; d4 < DK / 4; ++d4) {
+        const float4 vv = vr[d4];
+        acc += gs[4 * d4] * vv.x + gs[4 * d4 + 1] * vv.y + gs[4 * d4 + 2] * vv.z + gs[4 * d4 + 3] * vv.w;
+      }
+      dpd = acc;
+      p = P[pbase + (size_t)i * Lk + tid];
+      pd = Pd[pbase + (size_t)i * Lk + tid];
+    }
+    const float D = block_sum256(pd * dpd, red);
+    // dP = dPd * (Pd / P)  (Pd = P * mask / keep; P > 0 for every visible key)
+    const float dp = (vis && p > 0.f) ? dpd * (pd / p) : 0.f;
+    if (tid < Lk) ds[(size_t)i * Lk + tid] = vis ? p * (dp - D) : 0.f;
+  }
+  __syncthreads();
+  // phase B: thread = head dim
+  for (int d = tid; d < DK; d += 256) {
+    for (int i = 0; i < Lq; ++i) {
+      float acc = 0.f;
+      const int kend = causal ? i + 1 : Lk;
+      for (int j = 0; j < kend; ++j) acc += ds[(size_t)i * Lk + j] * kb[(size_t)j * ldk + d];
+      dQ[(size_t)b * Lq * ldq + h * DK + (size_t)i * ldq + d] = acc * scale;
+    }
+    for (int j = 0; j < Lk; ++j) {
+      float ak = 0.f, av = 0.f;
+      for (int i = causal ? j : 0; i < Lq; ++i) {
+        ak += ds[(size_t)i * Lk + j] * qb[(size_t)i * ldq + d];
+        av += Pd[pbase + (size_t)i * Lk + j] * gb[(size_t)i * ldo + d];
+      }
+      dK[(size_t)b * Lk * ldk + h * DK + (size_t)j * ldk + d] = ak * scale;
+      dV[(size_t)b * Lk * ldk + h * DK + (size_t)j * ldk + d] = av;
+    }
+  }
+}
+
+extern "C" int focr_small_attention_fwd(const float* q, const float* k, const float* v, float* o, float* p, float* pd,
+                                        int B, int H, int Lq, int Lk, int Dk, int ldq, int ldk, int ldo, float scale,
+                                        int causal, float p_drop, uint64_t seed, hipStream_t stream) {
+  FOCR_CHECK_ARG(q && k && v && o && p && pd, "null pointer");
+  FOCR_CHECK_ARG(Dk == 256 && Lk > 0 && Lk <= SA_LKMAX && Lq > 0 && ldk % 4 == 0, "need Dk == 256, Lk <= 256");
+  FOCR_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "bad dropout probability");
+  const uint32_t thr = (uint32_t)(p_drop * 65536.f + 0.5f);
+  FOCR_CHECK_ARG(thr < 65536u, "dropout probability rounds to 1");
+  const float ks = thr ? 65536.f / (65536.f - (float)thr) : 1.f;
+  hipLaunchKernelGGL((small_attn_fwd_kernel<256>), dim3(B * H), 256, 0, stream, q, k, v, o, p, pd, H, Lq, Lk, ldq, ldk,
+                     ldo, scale, causal, thr, ks, seed);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+// ws: B*H*Lq*Lk floats
+extern "C" int focr_small_attention_bwd(const float* q, const float* k, const float* v, const float* d_o,
+                                        const float* p, const float* pd, float* dq, float* dk, float* dv, float* ws,
+                                        int B, int H, int Lq, int Lk, int Dk, int ldq, int ldk, int ldo, float scale,
+                                        int causal, hipStream_t stream) {
+  FOCR_CHECK_ARG(q && k && v && d_o && p && pd && dq && dk && dv && ws, "null pointer");
+  FOCR_CHECK_ARG(Dk == 256 && Lk > 0 && Lk <= SA_LKMAX && Lq > 0 && ldk % 4 == 0, "need Dk == 256, Lk <= 256");
+  hipLaunchKernelGGL((small_attn_bwd_kernel<256>), dim3(B * H), 256, 0, stream, q, k, v, d_o, p, pd, dq, dk, dv, ws, H,
+                     Lq, Lk, ldq, ldk, ldo, scale, causal);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}

@@ -1,0 +1,121 @@
+"""Optimisation step of the stroke-level-decomposition recognizer (reference train.py:63-77: zero_grad -> forward ->
+CrossEntropyLoss -> backward -> Adadelta(lr=1.0, rho=0.9).step()), one process per GPU.
+
+Same machinery as fudanocr_amd.engine.TrainStep: flat parameter / gradient buffers, per-engine StepContext (fragment
+weights prepared once per step, weight gradients on a side stream), fused optimizer kernel, and -- replacing the
+reference's nn.DataParallel (train.py:28) -- an RCCL all-reduce of the flat gradient.  This model's message is 287 MB
+(71.7 M parameters), so unlike the SR nets the collective is bandwidth-relevant: the buffer goes out in
+32 MB buckets, and the buckets behind an encoder stage are launched from autograd hooks as soon as backward has left
+that stage (the flat buffer is in forward order, so everything behind a stage boundary is final), overlapping the
+remaining backward kernels."""
+import torch
+import torch.distributed as dist
+
+from .. import kernels as K
+from ..engine import FlatBuffers, _Boundary
+from . import ops
+
+
+class FusedAdadelta:
+    def __init__(self, flat, lr=1.0, rho=0.9, eps=1e-6):
+        self.flat, self.lr, self.rho, self.eps = flat, lr, rho, eps
+        self.sq = torch.zeros_like(flat.flat_param)
+        self.acc = torch.zeros_like(flat.flat_param)
+
+    def step(self, world=1):
+        ops.adadelta(self.flat.flat_param, self.flat.flat_grad, self.sq, self.acc, self.lr, self.rho, self.eps,
+                     1.0 / world)
+
+
+class SLDTrainStep:
+    """model: sld.model.transformer.Transformer.  step(image, length, text_input, text_gt) -> {'loss', 'pred'}"""
+
+    BUCKET = 8 << 20          # floats per all-reduce message (32 MB)
+
+    def __init__(self, model, lr=1.0, rho=0.9, process_group=None, wgrad_side_stream=True, dropout=True,
+                 boundaries=("layer1", "layer2", "layer3", "layer4")):
+        self.model, self.dropout = model, dropout
+        self.flat = FlatBuffers(list(model.parameters()))
+        self.opt = FusedAdadelta(self.flat, lr, rho)
+        self.ctx, self.frags, self.flips = K.StepContext(), K.FragTable(managed=True), K.FlipTable()
+        self.pg, self.wgrad_side_stream = process_group, bool(wgrad_side_stream)
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        if self.world > 1:
+            dist.broadcast(self.flat.flat_param, src=dist.get_global_rank(process_group, 0) if process_group else 0,
+                           group=process_group)
+        self.comm_stream = torch.cuda.Stream() if (self.world > 1 and self.flat.flat_grad.is_cuda) else None
+        self._works, self._sent_lo = [], self.flat.numel
+        ids = {id(p): off for p, off in zip(self.flat.params, self.flat.offsets)}
+        enc = model.encoder
+        self._stage_lo = {}
+        for name in boundaries:                       # flat offset where the stage AFTER this boundary's input begins
+            mod = getattr(enc, name)
+            offs = [ids[id(p)] for p in mod.parameters() if id(p) in ids]
+            if offs:
+                self._stage_lo[name] = min(offs)
+                mod.register_forward_pre_hook(self._make_hook(name))
+
+    def _make_hook(self, name):
+        def pre_hook(module, args):
+            if self.world == 1 or not torch.is_grad_enabled() or not args[0].requires_grad:
+                return None
+            # when the gradient arrives at this stage's INPUT, every parameter from this stage to the end is final
+            return (_Boundary.apply(args[0], lambda: self._send_down_to(self._stage_lo[name])),) + tuple(args[1:])
+        return pre_hook
+
+    def _send_down_to(self, lo):
+        """all-reduce flat_grad[lo : first offset already sent] in buckets"""
+        hi = self._sent_lo
+        if lo >= hi:
+            return
+        self._sent_lo = lo
+        ev = None
+        if self.comm_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+        for a in range(lo, hi, self.BUCKET):
+            view = self.flat.flat_grad[a:min(hi, a + self.BUCKET)]
+            if self.comm_stream is not None:
+                with torch.cuda.stream(self.comm_stream):
+                    self.comm_stream.wait_event(ev)
+                    self.ctx.join_side_stream(self.comm_stream)
+                    self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            else:
+                self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def __call__(self, image, length, text_input, text_gt):
+        self.model.train()
+        if not self.dropout:
+            for m in self.model.modules():
+                if isinstance(m, torch.nn.Dropout):
+                    m.eval()
+        self.flat.zero_grad()
+        self._works, self._sent_lo = [], self.flat.numel
+        on_gpu = self.flat.flat_grad.is_cuda
+        c = self.ctx
+        c.frags = self.frags if on_gpu else None
+        if on_gpu:
+            self.frags.refresh()
+        try:
+            with K.use_context(c):
+                result = self.model(image, length, text_input)
+                loss = ops.cross_entropy(result["pred"], text_gt)
+            if on_gpu:
+                self.flips.refresh()
+                c.flips = self.flips
+            if on_gpu and self.wgrad_side_stream:
+                c.side_enabled = True
+                c.side_stream().wait_stream(torch.cuda.current_stream())
+            loss.backward()
+        finally:
+            c.side_enabled, c.flips, c.frags = False, None, None
+        if on_gpu:
+            self.flips.build(self.flat.flat_grad.device)
+            c.join_side_stream()
+        if self.world > 1:
+            self._send_down_to(0)
+            for w in self._works:
+                w.wait()
+        self.opt.step(self.world)
+        K.bump_weight_epoch()
+        return {"loss": loss.detach(), "pred": result["pred"].detach()}

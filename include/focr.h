@@ -259,6 +259,35 @@ int focr_psnr_ssim(const float* img1, const float* img2, const float* window_hos
 int focr_u8_to_input(const unsigned char* u8_nhwc, float* out_nchw, int B, int H, int W, int mask,
                      focr_stream_t stream);
 
+/* ---- stroke-level-decomposition transformer recognizer (BASELINE configs[4]) --------------------------------
+ * /root/reference/stroke-level-decomposition/model/transformer.py, train.py.  The encoder's 3x3 convolutions, BatchNorm,
+ * max-pool, linears, LayerNorm (any width) and dropout reuse the entry points above; these are the additional ops. */
+/* y = relu(a + b): BasicBlock tail, transformer.py:66-75 (backward: focr_relu_bwd(dy, y, .) for both addends) */
+int focr_add_relu_fwd(const float* a, const float* b, float* y, long n, focr_stream_t stream);
+/* y[r] = table[idx[r]] * scale (Embeddings, transformer.py:269-277; idx int64); bwd ACCUMULATES into dtable */
+int focr_embedding_fwd(const long long* idx, const float* table, float* y, long rows, int D, float scale,
+                       focr_stream_t stream);
+int focr_embedding_bwd(const long long* idx, const float* dy, float* dtable, long rows, int D, float scale,
+                       focr_stream_t stream);
+/* ragged gather of prediction rows (transformer.py:362-370): scatter = 0: dst[r] = src[idx[r]]; 1: dst[idx[r]] = src[r] */
+int focr_gather_rows(const float* src, const long long* idx, float* dst, long rows, int D, int scatter,
+                     focr_stream_t stream);
+/* nn.CrossEntropyLoss (train.py:41,70): loss[0] = mean nll, grad = d loss / d logits; nll_ws: rows floats */
+int focr_cross_entropy_fwd(const float* logits, const long long* target, float* loss, float* nll_ws, float* grad,
+                           long rows, int C, focr_stream_t stream);
+/* torch.optim.Adadelta(lr, rho, eps) fused over flat buffers (train.py:36-38); gscale = 1/world */
+int focr_adadelta(float* p, const float* g, float* sq, float* acc, long n, float lr, float rho, float eps,
+                  float gscale, focr_stream_t stream);
+/* attention with few queries and 256-wide heads (MultiHeadedAttention/attention, transformer.py:184-238): q [B,Lq,H*Dk],
+ * k/v [B,Lk,H*Dk] (row pitches ldq/ldk, o: ldo), optional causal mask, dropout on the probabilities.  p / pd
+ * [B,H,Lq,Lk]: softmax before / after dropout (pd is the reference's returned attention map); ws: B*H*Lq*Lk floats. */
+int focr_small_attention_fwd(const float* q, const float* k, const float* v, float* o, float* p, float* pd, int B, int H,
+                             int Lq, int Lk, int Dk, int ldq, int ldk, int ldo, float scale, int causal, float p_drop,
+                             uint64_t seed, focr_stream_t stream);
+int focr_small_attention_bwd(const float* q, const float* k, const float* v, const float* d_o, const float* p,
+                             const float* pd, float* dq, float* dk, float* dv, float* ws, int B, int H, int Lq, int Lk,
+                             int Dk, int ldq, int ldk, int ldo, float scale, int causal, focr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
