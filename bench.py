@@ -1,16 +1,21 @@
 #!/usr/bin/env python3
-"""Headline benchmark: training images/sec of the SR + CTC optimisation step on synthetic
-16x64 -> 32x128 crops (BASELINE.json metric), one process per GPU.
+"""Headline benchmark: training images/sec of the FudanOCR hot path on synthetic crops, one process per GPU.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py [--config c3] --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = forward (TBSRN, STN on, dropout on) -> MSE + frozen-CRNN CTC -> (loss*100).backward()
--> [RCCL all-reduce of the flat gradient buffer] -> clip 0.25 -> Adam, on a device-resident
-synthetic batch of 128 images per GPU (BASELINE configs[2]/[3]; weak scaling).  Prints ONE JSON
-line on rank 0 with `roofline` (dominant kernel, measured with on-stream events in the timed
-region) and `cpu_baseline` (the CPU oracle timed on this box's host cores, bounded sample).
+Configurations (BASELINE.json `configs`; the metric is quoted on c3 at N = 1 and on c4 = c3 x 8 ranks):
+  c3 (default)  TBSRN + frozen CRNN-CTC, per-GPU batch 128: forward (STN on, dropout on) -> MSE + CTC ->
+                (loss*100).backward() -> [RCCL all-reduce of the flat gradient] -> clip 0.25 -> Adam
+  c2            TBSRN, per-GPU batch 64, SR forward-backward only (MSE loss, no recognizer)
+  c1            TSRN + CRNN-CTC (`--arch tsrn`): architecture variant of c3
+  c5            stroke-level-decomposition transformer recognizer, per-GPU batch 32: forward -> cross-entropy over the
+                ragged stroke predictions -> backward -> [all-reduce] -> Adadelta
+Inputs are device-resident synthetic batches (seed 1234 + rank); weights by the name-keyed deterministic fill.
+Prints ONE JSON line on rank 0 with `roofline` (the dominant kernel, measured with on-stream events inside the timed
+region; HBM traffic from the committed rocprofv3 PMC artefact) and `cpu_baseline` (the CPU oracle on this box's host
+cores, bounded sample).
 """
 import argparse
 import json
@@ -27,68 +32,170 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA = vector f32 peak
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak; the bf16x3 split issues 3 MFMA flops per algorithmic flop
-FLOP_PER_IMG = 18.131e9           # TBSRN fwd+bwd 15.311 + frozen CRNN 2.820
+# algorithmic fwd+bwd flops per image
+FLOP_PER_IMG = {"c3": 18.131e9, "c1": 5.366e9 + 2.820e9, "c2": 15.311e9, "c5": 94.667e9}
+DEFAULT_BATCH = {"c3": 128, "c1": 128, "c2": 64, "c5": 32}
+PMC_ARTEFACT = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
-def cpu_baseline(batch=4, budget_s=25.0):
-    """Oracle (CPU restatement of the reference maths, kind 'port') on the host cores.
-    Bounded sample: batch 4, as many timed steps as fit in `budget_s` seconds (at least one)."""
-    from fudanocr_amd.utils.synth import make_batch
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(config="c3", budget_s=25.0):
+    """Oracle (CPU restatement of the reference maths, kind 'port') on the host cores.  Bounded sample: batch 4 timed
+    for as many steps as fit in `budget_s` seconds (at least one), then -- if the budget allows -- one step at batch 16
+    (BASELINE.md section 3)."""
     from fudanocr_amd.utils.weight_fill import fill_dict_
-    from oracle import sr_oracle as O
-    cores = max(1, min(os.cpu_count() or 1, 32))      # beyond ~32 threads these small ops only slow down
+    host = os.cpu_count() or 1
+    cores = max(1, min(host, 32))            # beyond ~32 threads these small ops only slow down; `cores` = threads used
     torch.set_num_threads(cores)
-    P = O.make_params(O.schema_sr("tbsrn"))
-    fill_dict_({k: v.data for k, v in P.items()})
-    C = O.make_params(O.schema_crnn(), requires_grad=False)
-    fill_dict_(C)
-    opt = O.AdamState([v for v in P.values() if v.requires_grad])
-    lr, hr, labels = make_batch(batch, 1234)
-    tgt, tlen = O.encode_labels(labels)
-    t0 = time.perf_counter()
-    O.train_step(P, opt, "tbsrn", lr, hr, C, tgt, tlen, dropout_p=0.1)          # warm-up (also a size probe)
-    warm = time.perf_counter() - t0
-    steps, t0 = 0, time.perf_counter()
+    if config == "c5":
+        from fudanocr_amd.sld.synth import make_sld_batch
+        from oracle import sld_oracle as O
+        P = O.make_params()
+        fill_dict_({k: v.data for k, v in P.items()})
+        opt = O.AdadeltaState([v for v in P.values() if v.requires_grad])
+
+        def run(batch):
+            image, labels = make_sld_batch(batch, 1234)
+            seqs = [s + "$" for s in labels]
+            a2n = {c: i for i, c in enumerate(O.ALPHABET_STROKE)}
+            length = torch.tensor([len(s) for s in seqs])
+            ti = torch.zeros(batch, int(length.max()), dtype=torch.long)
+            for i, s in enumerate(seqs):
+                for j in range(len(s) - 1):
+                    ti[i, j + 1] = a2n[s[j]]
+            tg = torch.tensor([a2n[c] for s in seqs for c in s])
+            t0 = time.perf_counter()
+            O.train_step(P, opt, image, length, ti, tg, dropout_p=0.1)
+            return time.perf_counter() - t0
+        what = "SLD transformer step (fwd, CE, bwd, Adadelta)"
+    else:
+        from fudanocr_amd.utils.synth import make_batch
+        from oracle import sr_oracle as O
+        arch = "tsrn" if config == "c1" else "tbsrn"
+        P = O.make_params(O.schema_sr(arch))
+        fill_dict_({k: v.data for k, v in P.items()})
+        C = None
+        if config != "c2":
+            C = O.make_params(O.schema_crnn(), requires_grad=False)
+            fill_dict_(C)
+        opt = O.AdamState([v for v in P.values() if v.requires_grad])
+
+        def run(batch):
+            lr, hr, labels = make_batch(batch, 1234)
+            tgt, tlen = O.encode_labels(labels) if C is not None else (None, None)
+            t0 = time.perf_counter()
+            O.train_step(P, opt, arch, lr, hr, C, tgt, tlen, dropout_p=0.1)
+            return time.perf_counter() - t0
+        what = "%s%s step, fp32, torch CPU oracle" % (arch.upper(), "+CRNN-CTC" if C is not None else " MSE-only")
+    warm = run(4)                                         # warm-up (also a size probe)
+    steps, spent = 0, 0.0
     while True:
-        O.train_step(P, opt, "tbsrn", lr, hr, C, tgt, tlen, dropout_p=0.1)
+        spent += run(4)
         steps += 1
-        dt = time.perf_counter() - t0
-        if steps >= 5 or dt + warm + dt / steps > budget_s:
+        if steps >= 5 or spent + warm + spent / steps > budget_s:
             break
-    return {"value": round(batch * steps / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "%d timed steps of batch %d (TBSRN+CRNN-CTC step, fp32, torch CPU oracle, %d threads)"
-                      % (steps, batch, cores)}
+    value = 4 * steps / spent
+    b16 = None
+    if spent + warm + 4.5 * (spent / steps) < budget_s + 15:
+        b16 = round(16 / run(16), 3)
+    return {"value": round(value, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "host_cpu_count": host, "cpu_model": _cpu_model(), "batch16_images_per_sec": b16,
+            "sample": "%d timed steps of batch 4%s (%s, %d threads)"
+                      % (steps, " + 1 step of batch 16" if b16 else "", what, cores)}
 
 
-def cpu_baseline_guarded(timeout_s=150):
-    """Run the CPU leg in a child process so that a pathological host (thread oversubscription,
-    page-in stalls) can never hang the benchmark; returns a value-less record on timeout."""
+def cpu_baseline_guarded(config, timeout_s=170):
+    """Run the CPU leg in a child process so that a pathological host (thread oversubscription, page-in stalls) can
+    never hang the benchmark; returns a value-less record on timeout."""
     import subprocess
     try:
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], timeout=timeout_s,
-                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", config],
+                             timeout=timeout_s, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
         return json.loads(out.strip().splitlines()[-1])
     except Exception as e:                                   # noqa: BLE001
-        return {"value": None, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
+        return {"value": None, "unit": "images/sec", "cores": None, "kind": "port",
+                "host_cpu_count": os.cpu_count(), "cpu_model": _cpu_model(),
                 "sample": "CPU oracle leg did not finish within %ds (%s)" % (timeout_s, type(e).__name__)}
+
+
+def _pmc(kernel_key, batch):
+    """HBM bytes per launch of `kernel_key` from the committed PMC artefact (tools/pmc_traffic.py distils it from
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very command): 2 x FETCH_SIZE (gfx950 counts
+    half of a wide coalesced read, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, averaged over the kernel's launches."""
+    try:
+        art = json.load(open(PMC_ARTEFACT))
+        rec = art["kernels"][kernel_key]
+        if art.get("per_gpu_batch") != batch:
+            return None, None
+        return float(rec["bytes_per_launch"]), {"file": os.path.relpath(PMC_ARTEFACT, ROOT), "run": art.get("run"),
+                                                 "launches": rec.get("launches")}
+    except Exception:                                        # noqa: BLE001
+        return None, None
+
+
+def _gemm_rows(calls, kind):
+    """(flops, bytes, ms, n) over timed C-ABI calls of a conv / linear entry point"""
+    fl = by = ms = 0.0
+    n = 0
+    for t_ms, a in calls:
+        if kind == "frag":        # focr_conv3x3_frag_fwd(x, wf, bias, res, y, stats, N,H,W,Cin,Cout, alpha,relu,planes,..)
+            nn, h, w, cin, cout = (int(v) for v in a[6:11])
+            kh = kw = 3
+            oh, ow = h, w
+            has_res = bool(getattr(a[3], "value", a[3]))
+        elif kind == "fwd":       # focr_conv2d_fwd(x, w, bias, res, y, N,H,W,Cin,Cout,KH,KW,ph,pw,...)
+            nn, h, w, cin, cout, kh, kw, ph, pw = (int(v) for v in a[5:14])
+            if cin % 32:
+                continue          # tiny-Cin first layers run on the fp32 kernel
+            oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
+            has_res = bool(getattr(a[3], "value", a[3]))
+        else:                     # focr_conv2d_wgrad(x, dy, dw, db, N,H,W,Cin,Cout,KH,KW,ph,pw,...)
+            nn, h, w, cin, cout, kh, kw, ph, pw = (int(v) for v in a[4:13])
+            oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
+            has_res = False
+        m = nn * oh * ow
+        by += 4.0 * (nn * h * w * cin + cout * kh * kw * cin + m * cout * (2 if has_res else 1))
+        fl += 2.0 * m * cout * kh * kw * cin
+        ms += t_ms
+        n += 1
+    return fl, by, ms, n
 
 
 def main():
     if "--cpu-baseline-only" in sys.argv:
-        print(json.dumps(cpu_baseline()))
+        i = sys.argv.index("--cpu-baseline-only")
+        print(json.dumps(cpu_baseline(sys.argv[i + 1] if len(sys.argv) > i + 1 else "c3")))
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
-    ap.add_argument("--arch", default="tbsrn")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3", "c5"])
+    ap.add_argument("--arch", default=None, help="tbsrn | tsrn (c1 = --arch tsrn)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16x3-allsplit", "bf16x3-dgrad16", "fp32"],
-                    help="contraction arithmetic: split-bf16 MFMA with single-bf16 gradient accumulations in the "
-                         "attention backward (library default, focr_set_precision(2)); the same with split "
-                         "products everywhere (mode 1); or exact fp32 MFMA (mode 0)")
+    ap.add_argument("--precision", default="bf16x3-dgrad16",
+                    choices=["bf16x3-dgrad16", "bf16x3", "bf16x3-allsplit", "fp32"],
+                    help="contraction arithmetic (csrc/focr_core.hip): forward always split-bf16 ('bf16x3': hi/lo "
+                         "operands, 3 products, fp32 accumulate = fp32-equivalent); bf16x3-dgrad16 (mode 3, default) "
+                         "additionally runs the halo-kernel data-gradient convolutions and the attention-backward "
+                         "accumulations as single bf16 products; bf16x3 = mode 2; bf16x3-allsplit = mode 1; fp32 = "
+                         "exact fp32 MFMA (mode 0)")
     args = ap.parse_args()
+    cfg = args.config
+    if args.arch == "tsrn" and cfg == "c3":
+        cfg = "c1"
+    arch = "tsrn" if cfg == "c1" else "tbsrn"
+    batch = args.batch or DEFAULT_BATCH[cfg]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -110,16 +217,36 @@ def main():
             dist.init_process_group(backend)
 
     from fudanocr_amd import _lib
-    from fudanocr_amd.engine import TrainStep
-    from fudanocr_amd.smoke import build_models
-    from fudanocr_amd.utils.synth import make_batch
     _lib.load()
-    _lib.set_precision({"bf16x3": 2, "bf16x3-allsplit": 1, "bf16x3-dgrad16": 3, "fp32": 0}[args.precision])
-    net, rec, crit = build_models(dev, args.arch)
-    step = TrainStep(net, crit, dropout=True, wgrad_side_stream=os.environ.get("FOCR_WGRAD_SIDE", "1") != "0")
-    lr, hr, labels = make_batch(args.batch, 1234 + rank)
-    lr, hr = lr.to(dev), hr.to(dev)
-    enc = crit.encode(labels, dev)
+    mode = {"bf16x3-dgrad16": 3, "bf16x3": 2, "bf16x3-allsplit": 1, "fp32": 0}[args.precision]
+    _lib.set_precision(mode)
+    side = os.environ.get("FOCR_WGRAD_SIDE", "1") != "0"
+    if cfg == "c5":
+        from fudanocr_amd.sld import util as sld_util
+        from fudanocr_amd.sld.engine import SLDTrainStep
+        from fudanocr_amd.sld.model.transformer import Transformer
+        from fudanocr_amd.sld.synth import make_sld_batch
+        from fudanocr_amd.utils.weight_fill import fill_module_
+        net = fill_module_(Transformer("stroke")).to(dev)
+        step_ = SLDTrainStep(net, dropout=True, wgrad_side_stream=side)
+        image, labels = make_sld_batch(batch, 1234 + rank)
+        image = image.to(dev)
+        length, text_input, text_gt, _ = sld_util.converter("stroke", labels, device=dev, strokes=True)
+
+        def step():
+            return step_(image, length, text_input, text_gt)
+    else:
+        from fudanocr_amd.engine import TrainStep
+        from fudanocr_amd.smoke import build_models
+        from fudanocr_amd.utils.synth import make_batch
+        net, rec, crit = build_models(dev, arch, with_crnn=(cfg != "c2"))
+        step_ = TrainStep(net, crit, dropout=True, wgrad_side_stream=side)
+        lr, hr, labels = make_batch(batch, 1234 + rank)
+        lr, hr = lr.to(dev), hr.to(dev)
+        enc = crit.encode(labels, dev) if cfg != "c2" else None
+
+        def step():
+            return step_(lr, hr, encoded=enc)
 
     def sync():
         if world > 1:
@@ -127,17 +254,16 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step(lr, hr, encoded=enc)
-    timed = ["focr_attention_fwd", "focr_attention_bwd"]          # 10 launches per step
-    conv_steps = min(2, args.steps)      # the ~107 conv launches/step are event-timed in the last steps only (each
-                                         # event pair costs host time: keeps the perturbation of `value` < 0.5 %)
+        step()
+    conv_steps = min(2, args.steps)      # the conv / linear launches are event-timed in the last steps only (each event
+                                         # pair costs host time: keeps the perturbation of `value` < 0.5 %)
     sync()
-    _lib.start_timing(timed)
+    _lib.start_timing(["focr_attention_fwd", "focr_attention_bwd"])
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i == args.steps - conv_steps:
-            _lib.add_timing(["focr_conv2d_fwd", "focr_conv3x3_frag_fwd"])
-        out = step(lr, hr, encoded=enc)
+            _lib.add_timing(["focr_conv3x3_frag_fwd", "focr_conv2d_fwd", "focr_conv2d_wgrad"])
+        out = step()
     sync()
     dt = time.perf_counter() - t0
     kt = _lib.stop_timing_with_args()
@@ -147,86 +273,96 @@ def main():
         dt = t.item()
     loss = out["loss"].item()
     if rank == 0:
-        imgs = args.batch * world * args.steps
-        value = imgs / dt
-        bx3 = args.precision != "fp32"
-        # ---- roofline of the dominant kernel: conv_fwd_bx3_kernel (implicit-GEMM conv / linear, forward AND
-        # data-gradient launches; 28 % of the step in profiles/r01j).  Every C-ABI call = one kernel launch, timed with
-        # events on its stream inside the timed region; algorithmic bytes = each input / weight / output (and
-        # residual) element once, algorithmic flops = 2*M*K*N (DESIGN.md "Measurement").
-        nbytes = nflops = ms = 0.0
-        ncalls = 0
-        for t_ms, a in kt["focr_conv2d_fwd"]:
-            n, h, w, cin, cout, kh, kw, ph, pw = (int(v) for v in a[5:14])
-            if bx3 and cin % 32:
-                continue                              # tiny-Cin first layers run on the fp32 kernel
-            oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
-            m = n * oh * ow
-            has_res = bool(getattr(a[3], "value", a[3]))
-            nbytes += 4.0 * (n * h * w * cin + cout * kh * kw * cin + m * cout * (2 if has_res else 1))
-            nflops += 2.0 * m * cout * kh * kw * cin
-            ms += t_ms
-            ncalls += 1
-        conv_gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        conv_tf = nflops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        value = batch * world * args.steps / dt
+        bx3 = mode != 0
         peak = PEAK_BF16_MFMA_TFLOPS if bx3 else PEAK_F32_MFMA_TFLOPS
-        fwd = [t for t, _ in kt["focr_attention_fwd"]]
-        bwd = [t for t, _ in kt["focr_attention_bwd"]]
-        fwd_ms = sum(fwd) / max(1, len(fwd))
-        bwd_ms = sum(bwd) / max(1, len(bwd))
-        flops_launch = 4.0 * args.batch * 4 * 1024 * 1024 * 32
-        ach = flops_launch / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
-        # HBM bytes per launch from the PMC passes (profiles/README.md, r01p): (2*FETCH_SIZE + WRITE_SIZE) KB averaged
-        # over the 107 focr_conv2d_fwd launches of a step (conv_fwd_bx3<1|2> + linear_stream kernels), measured at
-        # per-GPU batch 128 only
-        traffic = None
-        if args.batch == 128 and bx3:
-            traffic = 167.6e6
+
+        def row(kernel, fl, by, ms, n, executed_mult, extra=None):
+            tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            gbs = by / (ms * 1e-3) / 1e9 if ms > 0 and by else 0.0
+            r = {"kernel": kernel, "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+                 "frac": round(tf / peak, 4), "executed_frac": round(executed_mult * tf / peak, 4),
+                 "launches_per_step": n // max(1, conv_steps), "avg_launch_ms": round(ms / max(1, n), 4),
+                 "algorithmic_flops_per_launch": round(fl / max(1, n), 0)}
+            if by:
+                r["algorithmic_bytes_per_launch"] = round(by / max(1, n), 0)
+                r["hbm_view"] = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": round(gbs / PEAK_HBM_GBS, 4)}
+            if extra:
+                r.update(extra)
+            return r
+
+        # ---- dominant kernel: conv3x3_halo_kernel (focr_conv3x3_frag_fwd: every 3x3 / C % 64 convolution, forward
+        # and data-gradient launches).  Each C-ABI call = one launch, timed with events on its stream inside the
+        # timed region; algorithmic flops = 2*M*K*N, algorithmic bytes = every input / weight / output / residual
+        # element once (DESIGN.md "Measurement").  executed multiplier: 3 products (planes = 2) or 1 (planes = 1).
+        frag = kt.get("focr_conv3x3_frag_fwd", [])
+        fl, by, ms, n = _gemm_rows(frag, "frag")
+        ex = sum((3 if int(a[13]) == 2 else 1) * t for t, a in frag) / ms if ms > 0 else (3 if bx3 else 1)
+        traffic, prov = _pmc("conv3x3_halo_kernel", batch) if cfg == "c3" else (None, None)
+        roof = row("conv3x3_halo_kernel (focr_conv3x3_frag_fwd: input tile resident in LDS, pre-split fragment-ordered "
+                   "weights by LDS-DMA; forward + data-gradient launches of every 3x3 conv with C % 64 == 0)",
+                   fl, by, ms, n, ex, {"traffic": traffic, "traffic_provenance": prov})
+        also = []
+        f2, b2, m2, n2 = _gemm_rows(kt.get("focr_conv2d_fwd", []), "fwd")
+        if n2:
+            also.append(row("conv_fwd_bx3_kernel / linear_stream_bx3_kernel (focr_conv2d_fwd: remaining implicit-GEMM "
+                            "convs + streaming linears, forward and data gradient)", f2, b2, m2, n2, 3 if bx3 else 1))
+        f3, b3, m3, n3 = _gemm_rows(kt.get("focr_conv2d_wgrad", []), "wgrad")
+        if n3:
+            also.append(row("weight-gradient kernels (focr_conv2d_wgrad; side stream, overlapped with the data-"
+                            "gradient chain: their own durations are inflated by the overlap)", f3, b3, m3, n3,
+                            3 if bx3 else 1))
+        fwd = [t for t, _ in kt.get("focr_attention_fwd", [])]
+        bwd = [t for t, _ in kt.get("focr_attention_bwd", [])]
+        if fwd:
+            fa = 4.0 * batch * 4 * 1024 * 1024 * 32
+            r = row("attn_fwd2_bx3_kernel (fused QK^T-softmax-dropout-PV, incl. the keep-bit pre-pass)",
+                    fa * len(fwd), 0.0, sum(fwd), len(fwd), 3 if bx3 else 1)
+            r["launches_per_step"] = len(fwd) // args.steps
+            also.append(r)
+            r = row("attention backward (prep + dK/dV + dQ launches; 2.5x the forward flops)", 2.5 * fa * len(bwd), 0.0,
+                    sum(bwd), len(bwd), 3 if bx3 else 1)
+            r["launches_per_step"] = len(bwd) // args.steps
+            also.append(r)
+        roof["also"] = also
+        roof["step_algorithmic_tflops"] = round(value * FLOP_PER_IMG[cfg] / world / 1e12, 2)
+        roof["step_frac_of_bf16_peak"] = round(value * FLOP_PER_IMG[cfg] / world / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)
+        arith = {3: "forward: split-bf16 MFMA (hi/lo operands, 3 products, fp32 accumulate = fp32-equivalent, the 1e-3 "
+                    "parity gate); backward: halo-kernel data-gradient convolutions and the dV/dK/dQ accumulations of the "
+                    "attention backward as single bf16 products (fp32 accumulate), everything else split-bf16",
+                 2: "split-bf16 MFMA (hi/lo operands, 3 products, fp32 accumulate); dV/dK/dQ accumulations of the "
+                    "attention backward in single bf16 products",
+                 1: "split-bf16 MFMA (hi/lo operands, 3 products, fp32 accumulate) everywhere",
+                 0: "exact fp32 MFMA"}[mode]
+        workload = {"c3": "TBSRN + frozen CRNN-CTC train step (BASELINE configs[2]; x8 ranks = configs[3]), STN on, "
+                          "dropout on, 16x64->32x128",
+                    "c1": "TSRN + frozen CRNN-CTC train step (architecture variant of configs[2]; configs[0] is its "
+                          "CPU-plumbing form), STN on, 16x64->32x128",
+                    "c2": "TBSRN SR forward-backward only (BASELINE configs[1]): MSE loss, clip + Adam, STN on, "
+                          "dropout on, 16x64->32x128",
+                    "c5": "stroke-level-decomposition transformer recognizer train step (BASELINE configs[4]): "
+                          "ResNet-[3,4,6,3] encoder + attention decoder, cross-entropy over ragged stroke sequences, "
+                          "Adadelta, 3x32x32 inputs"}[cfg]
         res = {
-            "metric": "training images/sec (16x64->32x128 SR+CTC step)", "value": round(value, 2),
-            "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16x3" if bx3 else "f32", "data": "synthetic",
-            "config": {"workload": "%s + frozen CRNN-CTC train step (BASELINE configs[2]%s), STN on, "
-                                   "dropout on, 16x64->32x128" % (args.arch.upper(), "" if args.arch == "tbsrn"
-                                                                  else "; architecture variant"),
-                       "per_gpu_batch": args.batch,
-                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "arch": args.arch,
+            "metric": "training images/sec (16x64->32x128 SR+CTC step)" if cfg != "c5"
+                      else "training images/sec (stroke-level-decomposition recognizer step)",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": {3: "bf16x3 (fwd) / bf16 (dgrad)", 2: "bf16x3", 1: "bf16x3", 0: "f32"}[mode], "data": "synthetic",
+            "config": {"workload": workload, "name": cfg, "per_gpu_batch": batch, "global_batch": batch * world,
+                       "parallelism": "dp%d" % world, "arch": arch if cfg != "c5" else "sld-transformer",
                        "collective_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
-                       "arithmetic": ("split-bf16 MFMA (hi/lo operands, 3 products, fp32 accumulate)" +
-                                      ("; dV/dK/dQ accumulations of the attention backward in single bf16 products"
-                                       if args.precision == "bf16x3" else "")) if bx3
-                       else "exact fp32 MFMA"},
+                       "arithmetic": arith},
             # the bounding roofline of this path is the dense-contraction (MFMA) one; `achieved` is the
-            # ALGORITHMIC flop rate of the dominant kernel's launches (bf16x3 executes 3 MFMA flops per algorithmic
-            # flop: executed_frac).  hbm_view: the same launches against HBM -- the roof that is actually closer
-            # for these layers.
-            "roofline": {"bound": "mfma",
-                         "kernel": ("conv_fwd_bx3_kernel / linear_stream_bx3_kernel" if bx3 else "conv_fwd_kernel") +
-                                   " (focr_conv2d_fwd: implicit-GEMM conv + streaming linear, forward and "
-                                   "data-gradient launches)",
-                         "achieved": round(conv_tf, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(conv_tf / peak, 4), "traffic": traffic,
-                         "executed_frac": round((3 if bx3 else 1) * conv_tf / peak, 4),
-                         "hbm_view": {"achieved": round(conv_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                      "frac": round(conv_gbs / PEAK_HBM_GBS, 4)},
-                         "launches_per_step": ncalls // max(1, conv_steps),
-                         "avg_launch_ms": round(ms / max(1, ncalls), 4),
-                         "algorithmic_bytes_per_launch": round(nbytes / max(1, ncalls), 0),
-                         "algorithmic_flops_per_launch": round(nflops / max(1, ncalls), 0),
-                         "also": [{"kernel": ("attn_fwd_bx3_kernel" if bx3 else "attn_fwd_kernel") +
-                                             " (fused QK^T-softmax-dropout-PV, incl. keep-bit pre-pass)",
-                                   "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                                   "frac": round(ach / peak, 4), "avg_launch_ms": round(fwd_ms, 4),
-                                   "executed_frac": round((3 if bx3 else 1) * ach / peak, 4)},
-                                  {"kernel": "attention backward (prep + dK/dV + dQ launches)", "bound": "mfma",
-                                   "achieved": round(2.5 * flops_launch / (bwd_ms * 1e-3) / 1e12, 2) if bwd_ms else 0.0,
-                                   "peak": peak, "unit": "TFLOP/s", "avg_launch_ms": round(bwd_ms, 4)}],
-                         "step_algorithmic_tflops": round(value * FLOP_PER_IMG / world / 1e12, 2)},
+            # ALGORITHMIC flop rate of the dominant kernel's launches, `executed_frac` counts the MFMA flops actually
+            # issued (3 per algorithmic flop for split products).  hbm_view: the same launches against HBM.
+            "roofline": roof,
             "final_loss": round(loss, 5),
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline_guarded()
+            res["cpu_baseline"] = cpu_baseline_guarded(cfg)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
