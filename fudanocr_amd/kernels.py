@@ -417,6 +417,7 @@ class _Conv2d(torch.autograd.Function):
                 _lib.call("focr_relu_bwd", _p(dy4), _p(y), _p(g), dy4.numel(), _stream())
             dy4 = g
         dres = dy4.reshape(dy.shape) if has_res else None
+        residual_shares_dy = has_res and not (ctx.defer_residual and ctx.needs_input_grad[3])
         if has_res and ctx.defer_residual and ctx.needs_input_grad[3]:
             if ctx.res_key in step.deferred:
                 raise RuntimeError("two deferred gradients for the same tensor")
@@ -441,6 +442,10 @@ class _Conv2d(torch.autograd.Function):
             # side stream, concurrently with the data-gradient chain on the main stream (both kinds of kernels are
             # latency/occupancy bound, not throughput bound).  The engine joins the streams before the optimiser.
             side = step.side_stream() if (tw is not None and (db is None or tb is not None)) else None
+            if side is not None and residual_shares_dy:
+                # the residual's gradient IS dy4's storage and leaves this backward: autograd may accumulate into it in
+                # place on the main stream while the side-stream weight-gradient kernel still reads it -> hand out a copy
+                dres = dres.clone()
             if side is not None:
                 ev = torch.cuda.Event()
                 ev.record()

@@ -155,3 +155,18 @@ def test_main_py_under_two_ranks(tmp_path):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
     assert os.path.exists(tmp_path / "checkpoint" / "dp" / "model_best.pth")
     assert "log.txt" in os.listdir(tmp_path / "checkpoint" / "dp")
+
+
+@pytest.mark.parametrize("config", ["c3", "c5"])
+def test_dp_selfcheck_tool(config):
+    """tools/dp_selfcheck.py (what the 8-GPU driver run can invoke) under 2 ranks on one GPU (gloo): checks world
+    size, overlap launches, reduced gradient == sum of locals (checksums), bit-identical parameters"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541" if config == "c3" else "29543", WORLD_SIZE="2",
+               FOCR_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "dp_selfcheck.py"), "--config", config, "--steps", "3",
+           "--batch", "4"]
+    procs, outs = _run_two([(cmd, dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)])
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
+    line = [l for l in outs[0].splitlines() if l.startswith("{")]
+    assert json.loads(line[-1])["dp_selfcheck"] == "ok"
