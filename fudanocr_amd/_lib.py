@@ -79,7 +79,10 @@ SIGNATURES = {
     "focr_cross_entropy_fwd": [P, P, P, P, P, L, I, P],
     "focr_adadelta": [P, P, P, P, L, F, F, F, F, P],
     "focr_small_attention_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, F, U, P],
-    "focr_small_attention_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, P],
+    "focr_small_attention_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, P],
+    "focr_l1_fwd": [P, P, P, P, L, P],
+    "focr_l1_bwd": [P, P, P, P, L, P],
+    "focr_weight_cross_entropy_fwd": [P, P, P, P, P, P, L, I, P],
     "focr_set_precision": [I],
     "focr_get_precision": [],
     "focr_clip_adam": [P, P, P, P, P, L, F, F, F, F, I, F, F, P],

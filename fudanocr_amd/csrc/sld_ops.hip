@@ -296,6 +296,7 @@ template <int DK>
 __global__ __launch_bounds__(256) void small_attn_bwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                              const float* __restrict__ V, const float* __restrict__ dO,
                                                              const float* __restrict__ P, const float* __restrict__ Pd,
+                                                             const float* __restrict__ dMap,   // nullable: d loss / d Pd
                                                              float* __restrict__ dQ, float* __restrict__ dK,
                                                              float* __restrict__ dV, float* __restrict__ dS, int H,
                                                              int Lq, int Lk, int ldq, int ldk, int ldo, float scale,
@@ -325,6 +326,7 @@ __global__ __launch_bounds__(256) void small_attn_bwd_kernel(const float* __rest
         acc += gs[4 * d4] * vv.x + gs[4 * d4 + 1] * vv.y + gs[4 * d4 + 2] * vv.z + gs[4 * d4 + 3] * vv.w;
       }
       dpd = acc;
+      if (dMap) dpd += dMap[pbase + (size_t)i * Lk + tid];      // the attention map is an output too (text-focus L1 term)
       p = P[pbase + (size_t)i * Lk + tid];
       pd = Pd[pbase + (size_t)i * Lk + tid];
     }
@@ -358,25 +360,103 @@ extern "C" int focr_small_attention_fwd(const float* q, const float* k, const fl
                                         int B, int H, int Lq, int Lk, int Dk, int ldq, int ldk, int ldo, float scale,
                                         int causal, float p_drop, uint64_t seed, hipStream_t stream) {
   FOCR_CHECK_ARG(q && k && v && o && p && pd, "null pointer");
-  FOCR_CHECK_ARG(Dk == 256 && Lk > 0 && Lk <= SA_LKMAX && Lq > 0 && ldk % 4 == 0, "need Dk == 256, Lk <= 256");
+  FOCR_CHECK_ARG((Dk == 256 || Dk == 64) && Lk > 0 && Lk <= SA_LKMAX && Lq > 0 && ldk % 4 == 0,
+                 "need Dk in {64, 256}, Lk <= 256");
   FOCR_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "bad dropout probability");
   const uint32_t thr = (uint32_t)(p_drop * 65536.f + 0.5f);
   FOCR_CHECK_ARG(thr < 65536u, "dropout probability rounds to 1");
   const float ks = thr ? 65536.f / (65536.f - (float)thr) : 1.f;
-  hipLaunchKernelGGL((small_attn_fwd_kernel<256>), dim3(B * H), 256, 0, stream, q, k, v, o, p, pd, H, Lq, Lk, ldq, ldk,
-                     ldo, scale, causal, thr, ks, seed);
+  if (Dk == 64)
+    hipLaunchKernelGGL((small_attn_fwd_kernel<64>), dim3(B * H), 256, 0, stream, q, k, v, o, p, pd, H, Lq, Lk, ldq, ldk,
+                       ldo, scale, causal, thr, ks, seed);
+  else
+    hipLaunchKernelGGL((small_attn_fwd_kernel<256>), dim3(B * H), 256, 0, stream, q, k, v, o, p, pd, H, Lq, Lk, ldq, ldk,
+                       ldo, scale, causal, thr, ks, seed);
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }
 // ws: B*H*Lq*Lk floats
 extern "C" int focr_small_attention_bwd(const float* q, const float* k, const float* v, const float* d_o,
-                                        const float* p, const float* pd, float* dq, float* dk, float* dv, float* ws,
-                                        int B, int H, int Lq, int Lk, int Dk, int ldq, int ldk, int ldo, float scale,
-                                        int causal, hipStream_t stream) {
+                                        const float* p, const float* pd, const float* dmap, float* dq, float* dk,
+                                        float* dv, float* ws, int B, int H, int Lq, int Lk, int Dk, int ldq, int ldk,
+                                        int ldo, float scale, int causal, hipStream_t stream) {
   FOCR_CHECK_ARG(q && k && v && d_o && p && pd && dq && dk && dv && ws, "null pointer");
-  FOCR_CHECK_ARG(Dk == 256 && Lk > 0 && Lk <= SA_LKMAX && Lq > 0 && ldk % 4 == 0, "need Dk == 256, Lk <= 256");
-  hipLaunchKernelGGL((small_attn_bwd_kernel<256>), dim3(B * H), 256, 0, stream, q, k, v, d_o, p, pd, dq, dk, dv, ws, H,
-                     Lq, Lk, ldq, ldk, ldo, scale, causal);
+  FOCR_CHECK_ARG((Dk == 256 || Dk == 64) && Lk > 0 && Lk <= SA_LKMAX && Lq > 0 && ldk % 4 == 0,
+                 "need Dk in {64, 256}, Lk <= 256");
+  if (Dk == 64)
+    hipLaunchKernelGGL((small_attn_bwd_kernel<64>), dim3(B * H), 256, 0, stream, q, k, v, d_o, p, pd, dmap, dq, dk, dv,
+                       ws, H, Lq, Lk, ldq, ldk, ldo, scale, causal);
+  else
+    hipLaunchKernelGGL((small_attn_bwd_kernel<256>), dim3(B * H), 256, 0, stream, q, k, v, d_o, p, pd, dmap, dq, dk, dv,
+                       ws, H, Lq, Lk, ldq, ldk, ldo, scale, causal);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- text-focus loss
+// nn.L1Loss (mean |a - b|) between two attention maps (loss/text_focus_loss.py:92) and its gradient w.r.t. b
+// (the HR map is a constant); fixed-order reduction.
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         float* __restrict__ part, long n) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += fabsf(a[i] - b[i]);
+  s = block_sum256(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(64) void l1_fold_kernel(const float* __restrict__ part, float* __restrict__ out, int nb,
+                                                     float inv_n) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 64) s += part[i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) out[0] = s * inv_n;
+}
+__global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                     const float* __restrict__ g, float* __restrict__ db, long n) {
+  const float k = g[0] / (float)n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float d = b[i] - a[i];
+    db[i] = d > 0.f ? k : (d < 0.f ? -k : 0.f);
+  }
+}
+#define L1_BLOCKS 256
+extern "C" int focr_l1_fwd(const float* a, const float* b, float* out, float* ws, long n, hipStream_t stream) {
+  FOCR_CHECK_ARG(a && b && out && ws && n > 0, "bad argument (ws: 256 floats)");
+  hipLaunchKernelGGL(l1_partial_kernel, dim3(L1_BLOCKS), 256, 0, stream, a, b, ws, n);
+  hipLaunchKernelGGL(l1_fold_kernel, dim3(1), 64, 0, stream, (const float*)ws, out, L1_BLOCKS, 1.f / (float)n);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+extern "C" int focr_l1_bwd(const float* a, const float* b, const float* g, float* db, long n, hipStream_t stream) {
+  FOCR_CHECK_ARG(a && b && g && db && n > 0, "bad argument");
+  long gr = (n + 255) / 256;
+  if (gr > 2048) gr = 2048;
+  hipLaunchKernelGGL(l1_bwd_kernel, dim3((int)gr), 256, 0, stream, a, b, g, db, n);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+
+// weight_cross_entropy (loss/weight_ce_loss.py:38-45): -mean_r log( w[t_r][t_r] e^{x[r][t_r]} / sum_c w[t_r][c] e^{x[r][c]} )
+// with a [C][C] confusion-derived weight table; grad[r][c] = (w[t][c] e^{x_c} / S - [c == t]) / rows.
+__global__ __launch_bounds__(64) void wce_rows_kernel(const float* __restrict__ x, const long long* __restrict__ target,
+                                                      const float* __restrict__ table, float* __restrict__ nll,
+                                                      float* __restrict__ grad, long rows, int C) {
+  const long r = blockIdx.x;
+  const int c = threadIdx.x, t = (int)target[r];
+  const float v = c < C ? x[r * C + c] : -1e30f;
+  const float mx = wave_max(v);                                     // stabilised: the ratio is shift-invariant
+  const float e = c < C ? table[t * C + c] * expf(v - mx) : 0.f;
+  const float sum = wave_sum(e);
+  if (c < C) grad[r * C + c] = (e / sum - (c == t ? 1.f : 0.f)) / (float)rows;
+  const float picked = wave_sum(c == t ? e : 0.f);
+  if (c == 0) nll[r] = -logf(picked / sum);
+}
+extern "C" int focr_weight_cross_entropy_fwd(const float* logits, const long long* target, const float* table,
+                                             float* loss, float* nll_ws, float* grad, long rows, int C,
+                                             hipStream_t stream) {
+  FOCR_CHECK_ARG(logits && target && table && loss && nll_ws && grad && rows > 0 && C > 1 && C <= 64, "need 2 <= C <= 64");
+  hipLaunchKernelGGL(wce_rows_kernel, dim3((int)rows), 64, 0, stream, logits, target, table, nll_ws, grad, rows, C);
+  hipLaunchKernelGGL(ce_fold_kernel, dim3(1), 64, 0, stream, (const float*)nll_ws, loss, rows);
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }

@@ -31,9 +31,6 @@ class TextBase(object):
         self.voc_type = config.TRAIN.voc_type
         if not torch.cuda.is_available():
             raise RuntimeError("fudanocr_amd needs an MI355X: there is no CPU fallback (the CPU oracle is test-only)")
-        if getattr(args, "text_focus", False):
-            raise NotImplementedError("--text_focus (the text-focus loss recognizer, reference loss/text_focus_loss.py"
-                                      ":54-99) is not built; the measured step trains with MSE + CRNN-CTC")
         # one process per GPU (replaces nn.DataParallel, reference base.py:178-179): bind this process to its device
         # BEFORE any kernel runs (kernels launch on torch's current stream of the current device) and join the RCCL
         # process group, so that engine.TrainStep sees world > 1 and all-reduces the gradients
@@ -151,6 +148,11 @@ class TextBase(object):
         para_num = sum(p.numel() for p in model.parameters())
         self.logging.info("Total Parameters {}".format(para_num))
         rec, _ = self.CRNN_init() if getattr(a, "ctc", True) else (None, None)
+        if getattr(a, "text_focus", False):
+            # the reference's criterion for tbsrn / tsrn (interfaces/base.py:143-150): MSE + text-focus terms.  The
+            # CRNN stays the eval-time recognizer only, exactly as in the reference.
+            from ..loss.text_focus_loss import TextFocusLoss
+            return {"model": model, "crit": TextFocusLoss(a, device=self.device), "recognizer": rec}
         return {"model": model, "crit": CTCFocusLoss(rec), "recognizer": rec}
 
     def optimizer_init(self, model, crit):

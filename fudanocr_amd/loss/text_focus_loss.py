@@ -1,0 +1,121 @@
+"""TextFocusLoss of the reference (scene-text-telescope/loss/text_focus_loss.py:41-104) on the HIP path:
+
+    loss = mse(sr, hr) + 10 * L1(attention_map(hr), attention_map(sr)) + 0.0005 * weight_cross_entropy(pred(sr), gt)
+
+with the frozen, eval-mode transformer recognizer (loss/transformer.py) applied to the luma of HR (no gradient) and of
+SR (data gradient only, back into the SR network).  Returns the reference's 4-tuple (loss, mse_loss, attention_loss,
+recognition_loss), `-1` sentinels when `args.text_focus` is off.
+
+The reference loads ./dataset/mydata/pretrain_transformer.pth and ./dataset/mydata/confuse.pkl; neither ships with
+it.  When the files are absent the recognizer gets the name-keyed deterministic weights (the same rule as every parity
+fixture) and the confusion weight table is all ones (= plain cross-entropy): the maths, shapes and cost of the step are
+the reference's, only the learned content is missing -- and that is logged."""
+import logging
+import os
+import pickle
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import kernels as K
+from ..sld import ops
+from ..utils.util import str_filt as _str_filt
+from ..utils.weight_fill import fill_module_
+from .transformer import Transformer
+
+standard_alphebet = "-0123456789abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ"
+
+
+def to_gray_tensor(tensor):
+    """0.299 R + 0.587 G + 0.114 B (text_focus_loss.py:17-22): the luma kernel of parse_crnn_data at unchanged width"""
+    return K.bicubic_gray(tensor, tensor.shape[3])
+
+
+def str_filt(str_, voc_type):
+    return _str_filt(str_, voc_type).lower()          # text_focus_loss.py:25-38 lower-cases once more at the end
+
+
+def load_confuse_matrix(path="./dataset/mydata/confuse.pkl"):
+    """weight table of loss/weight_ce_loss.py:10-33 ([37, 37]; inverse confusion counts, lower/upper case merged)"""
+    if not os.path.isfile(path):
+        logging.getLogger(__name__).warning("confuse.pkl not found (%s): weight_cross_entropy uses unit weights", path)
+        return torch.ones(37, 37)
+    data = pickle.load(open(path, "rb"))
+    number, upper, lower = data[:10], data[10:36], data[36:]
+    rearr = np.concatenate((np.ones((1, 62)), number, lower, upper), axis=0)
+    rearr = np.concatenate((np.ones((63, 1)), rearr), axis=1)
+    with np.errstate(divide="ignore"):
+        rearr = 1 / rearr
+    rearr[rearr == np.inf] = 1
+    t = torch.Tensor(rearr)
+    lower_alpha = "abcdefghijklmnopqrstuvwxyz"
+    for i in range(63):
+        for j in range(63):
+            if i != j and standard_alphebet[j] in lower_alpha:
+                t[i][j] = max(t[i][j], t[i][j + 26])
+    return t[:37, :37].contiguous()
+
+
+class TextFocusLoss(nn.Module):
+    def __init__(self, args, transformer=None, weight_table=None, device="cuda"):
+        super().__init__()
+        self.args = args
+        self.english_alphabet = standard_alphebet
+        self.english_dict = {c: i for i, c in enumerate(self.english_alphabet)}
+        self.device = torch.device(device)
+        self._transformer = [transformer]                 # not registered: stays out of state_dict / parameters()
+        self._table = weight_table
+        if getattr(args, "text_focus", False) and transformer is None:
+            self.build_up_transformer()
+
+    @property
+    def transformer(self):
+        return self._transformer[0]
+
+    def build_up_transformer(self, path="./dataset/mydata/pretrain_transformer.pth"):
+        t = Transformer()
+        if os.path.isfile(path):
+            sd = torch.load(path, map_location="cpu")
+            t.load_state_dict({k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()})
+        else:
+            logging.getLogger(__name__).warning("pretrain_transformer.pth not found (%s): name-keyed weights", path)
+            fill_module_(t)
+        t = t.to(self.device).eval()
+        for p in t.parameters():
+            p.requires_grad = False
+        self._transformer[0] = t
+
+    def weight_table(self):
+        if self._table is None:
+            self._table = load_confuse_matrix()
+        if self._table.device != self.device:
+            self._table = self._table.to(self.device).contiguous()
+        return self._table
+
+    def label_encoder(self, label):
+        """text_focus_loss.py:62-81: teacher-forcing input shifted right by one, flat targets; CUDA tensors"""
+        length = [len(i) for i in label]
+        input_tensor = np.zeros((len(label), max(length)), dtype=np.int64)
+        for i, s in enumerate(label):
+            for j in range(length[i] - 1):
+                input_tensor[i][j + 1] = self.english_dict[s[j]]
+        text_gt = torch.tensor([self.english_dict[c] for s in label for c in s], dtype=torch.long)
+        length_tensor = torch.tensor(length, dtype=torch.long).to(self.device)
+        length_tensor._focr_host = length
+        return length_tensor, torch.from_numpy(input_tensor).to(self.device), text_gt.to(self.device)
+
+    def forward(self, sr_img, hr_img, label, encoded=None):
+        mse_loss = K.mse_loss(sr_img, hr_img)
+        if not getattr(self.args, "text_focus", False):
+            return mse_loss, mse_loss, -1, -1
+        label = [str_filt(i, "lower") + "-" for i in label]
+        length_tensor, input_tensor, text_gt = self.label_encoder(label)
+        tr = self.transformer
+        with torch.no_grad():
+            _, word_attention_map_gt, _ = tr(to_gray_tensor(hr_img), length_tensor, input_tensor, test=False)
+        sr_pred, word_attention_map_pred, _ = tr(to_gray_tensor(sr_img), length_tensor, input_tensor, test=False)
+        attention_loss = ops.l1_loss(word_attention_map_gt, word_attention_map_pred)
+        recognition_loss = ops.weight_cross_entropy(sr_pred, text_gt, self.weight_table())
+        loss = mse_loss + attention_loss * 10 + recognition_loss * 0.0005
+        return loss, mse_loss, attention_loss, recognition_loss

@@ -25,7 +25,7 @@ def main(config, args):
 def parse(argv=None):
     p = argparse.ArgumentParser(description="")
     p.add_argument("--arch", default="tbsrn", choices=["tbsrn", "tsrn"])
-    p.add_argument("--text_focus", action="store_true", help="reference flag (text-focus loss recognizer, SURVEY 8f N1): not built -- raises instead of silently training without it")
+    p.add_argument("--text_focus", action="store_true", help="train with the text-focus loss (loss/text_focus_loss.py) instead of MSE + CRNN-CTC")
     p.add_argument("--exp_name", required=True, help="Type your experiment name")
     p.add_argument("--test", action="store_true", default=False)
     p.add_argument("--test_data_dir", type=str, default="")

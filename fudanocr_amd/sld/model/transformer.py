@@ -35,8 +35,11 @@ class BasicBlock(nn.Module):
 
 
 class ResNet(nn.Module):
-    def __init__(self, num_in, block, layers):
+    def __init__(self, num_in, block, layers, pool_before_layer1=False):
+        """pool_before_layer1: the text-focus recognizer's ResNet (scene-text-telescope/loss/transformer.py:141) applies
+        `layer1_pool`; the stroke-level-decomposition one constructs it but never calls it"""
         super().__init__()
+        self.pool_before_layer1 = bool(pool_before_layer1)
         self.conv1 = Conv2d(num_in, 64, kernel_size=3, stride=1, padding=1)
         self.bn1 = BatchNorm2d(64)
         self.relu1 = ReLUTag(inplace=True)
@@ -78,6 +81,8 @@ class ResNet(nn.Module):
         """x NHWC [B,32,32,3] -> NHWC [B,16,16,1024]"""
         x = self.pool(K.conv_bn(x, self.conv1, self.bn1, act=K.ACT_RELU))
         x = K.conv_bn(x, self.conv2, self.bn2, act=K.ACT_RELU)
+        if self.pool_before_layer1:
+            x = self.layer1_pool(x)
         for layer, conv, bn in ((self.layer1, self.layer1_conv, self.layer1_bn),
                                 (self.layer2, self.layer2_conv, self.layer2_bn),
                                 (self.layer3, self.layer3_conv, self.layer3_bn),

@@ -140,18 +140,19 @@ class _SmallAttention(torch.autograd.Function):
                   scale, int(causal), float(p_drop), seed, _stream())
         ctx.cfg = (b, heads, lq, lk, dk, dm, scale, int(causal))
         ctx.save_for_backward(q, k, v, p, pd)
-        ctx.mark_non_differentiable(pd)
         return o, pd
 
     @staticmethod
-    def backward(ctx, do, _dmap):
+    def backward(ctx, do, dmap):
+        """dmap: gradient arriving through the returned attention map (the text-focus loss' L1 term); None otherwise"""
         q, k, v, p, pd = ctx.saved_tensors
         b, heads, lq, lk, dk, dm, scale, causal = ctx.cfg
-        do = do.contiguous()
+        do = torch.zeros_like(q) if do is None else do.contiguous()
+        dmap = None if dmap is None else dmap.contiguous()
         dq, dk_, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         ws = torch.empty_like(p)
-        _lib.call("focr_small_attention_bwd", _p(q), _p(k), _p(v), _p(do), _p(p), _p(pd), _p(dq), _p(dk_), _p(dv), _p(ws),
-                  b, heads, lq, lk, dk, dm, dm, dm, scale, causal, _stream())
+        _lib.call("focr_small_attention_bwd", _p(q), _p(k), _p(v), _p(do), _p(p), _p(pd), _p(dmap), _p(dq), _p(dk_),
+                  _p(dv), _p(ws), b, heads, lq, lk, dk, dm, dm, dm, scale, causal, _stream())
         return dq, dk_, dv, None, None, None, None
 
 
@@ -163,3 +164,55 @@ def small_attention(q, k, v, heads=4, causal=False, p_drop=0.0):
 def adadelta(p, g, sq, acc, lr, rho, eps, gscale=1.0):
     _lib.call("focr_adadelta", _p(p), _p(g), _p(sq), _p(acc), p.numel(), float(lr), float(rho), float(eps),
               float(gscale), _stream())
+
+
+class _L1(torch.autograd.Function):
+    """nn.L1Loss(mean) with the gradient flowing to the second argument only (the first is the no-grad HR map)"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        _chk(a, b)
+        out = torch.empty(1, device=a.device)
+        ws = torch.empty(256, device=a.device)
+        _lib.call("focr_l1_fwd", _p(a), _p(b), _p(out), _p(ws), a.numel(), _stream())
+        ctx.save_for_backward(a, b)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        db = torch.empty_like(b)
+        _lib.call("focr_l1_bwd", _p(a), _p(b), _p(g.contiguous().reshape(1)), _p(db), b.numel(), _stream())
+        return None, db
+
+
+def l1_loss(a_const, b):
+    return _L1.apply(a_const, b)
+
+
+class _WeightCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, table):
+        logits = logits.contiguous()
+        _chk(logits, table)
+        rows, c = logits.shape
+        loss = torch.empty(1, device=logits.device)
+        ws = torch.empty(rows, device=logits.device)
+        grad = torch.empty_like(logits)
+        _lib.call("focr_weight_cross_entropy_fwd", _p(logits), _ip(target.contiguous()), _p(table), _p(loss), _p(ws),
+                  _p(grad), rows, c, _stream())
+        ctx.save_for_backward(grad)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        out = torch.empty_like(grad)
+        _lib.call("focr_scale_dev", _p(grad), _p(g.contiguous().reshape(1)), _p(out), grad.numel(), _stream())
+        return out, None, None
+
+
+def weight_cross_entropy(logits, target, table):
+    """loss/weight_ce_loss.py:38-45 with the [C, C] weight table as an argument"""
+    return _WeightCE.apply(logits, target, table)

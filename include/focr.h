@@ -278,15 +278,24 @@ int focr_cross_entropy_fwd(const float* logits, const long long* target, float* 
 /* torch.optim.Adadelta(lr, rho, eps) fused over flat buffers (train.py:36-38); gscale = 1/world */
 int focr_adadelta(float* p, const float* g, float* sq, float* acc, long n, float lr, float rho, float eps,
                   float gscale, focr_stream_t stream);
-/* attention with few queries and 256-wide heads (MultiHeadedAttention/attention, transformer.py:184-238): q [B,Lq,H*Dk],
+/* attention with few queries and 64- or 256-wide heads (MultiHeadedAttention/attention, transformer.py:184-238): q [B,Lq,H*Dk],
  * k/v [B,Lk,H*Dk] (row pitches ldq/ldk, o: ldo), optional causal mask, dropout on the probabilities.  p / pd
  * [B,H,Lq,Lk]: softmax before / after dropout (pd is the reference's returned attention map); ws: B*H*Lq*Lk floats. */
 int focr_small_attention_fwd(const float* q, const float* k, const float* v, float* o, float* p, float* pd, int B, int H,
                              int Lq, int Lk, int Dk, int ldq, int ldk, int ldo, float scale, int causal, float p_drop,
                              uint64_t seed, focr_stream_t stream);
 int focr_small_attention_bwd(const float* q, const float* k, const float* v, const float* d_o, const float* p,
-                             const float* pd, float* dq, float* dk, float* dv, float* ws, int B, int H, int Lq, int Lk,
-                             int Dk, int ldq, int ldk, int ldo, float scale, int causal, focr_stream_t stream);
+                             const float* pd, const float* dmap, float* dq, float* dk, float* dv, float* ws, int B,
+                             int H, int Lq, int Lk, int Dk, int ldq, int ldk, int ldo, float scale, int causal,
+                             focr_stream_t stream);
+/* ---- text-focus loss (scene-text-telescope/loss/text_focus_loss.py:84-99, loss/weight_ce_loss.py:38-45) ------------
+ * the frozen recognizer (loss/transformer.py) reuses the convolution / BatchNorm / attention (Dk = 64, dmap = the
+ * gradient arriving through the returned attention map) / LayerNorm entries; these are the criterion's own ops:
+ * mean |a - b| (ws: 256 floats) and its gradient w.r.t. b; weighted cross-entropy with a [C][C] weight table. */
+int focr_l1_fwd(const float* a, const float* b, float* out, float* ws, long n, focr_stream_t stream);
+int focr_l1_bwd(const float* a, const float* b, const float* g, float* db, long n, focr_stream_t stream);
+int focr_weight_cross_entropy_fwd(const float* logits, const long long* target, const float* table, float* loss,
+                                  float* nll_ws, float* grad, long rows, int C, focr_stream_t stream);
 
 #ifdef __cplusplus
 }

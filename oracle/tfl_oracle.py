@@ -1,0 +1,123 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+
+Functional fp32 PyTorch-CPU restatement of the text-focus loss: the frozen transformer recognizer of
+scene-text-telescope/loss/transformer.py:82-389 and the three-term criterion of loss/text_focus_loss.py:54-104 with
+loss/weight_ce_loss.py:38-45.  Pure functions of a flat {state_dict key: tensor} dict in the reference's schema
+(tests/golden/tfl_schema.json); shared building blocks come from oracle/sld_oracle.py (the two transformers are
+siblings).  Pinned by tests/test_text_focus.py against fixture tfl_step.npz (tools/make_golden_tfl.py)."""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+from . import sld_oracle as S
+
+ALPHABET = "-0123456789abcdefghijklmnopqrstuvwxyz"          # loss/transformer.py:8
+ENGLISH = "-0123456789abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ"   # text_focus_loss.py:47
+LAYERS = (1, 2, 5, 3)                                       # transformer.py:333
+
+
+def schema(n_class=37, max_len=5000):
+    d = OrderedDict()
+    d["embedding_word.lut.weight"] = torch.zeros(n_class, 512)
+    d["pe.pe"] = S.positional_table(512, max_len)[None]
+    e = "encoder.cnn."
+    S._conv(d, e + "conv1.", 64, 1)
+    S._bn(d, e + "bn1.", 64)
+    S._conv(d, e + "conv2.", 128, 64)
+    S._bn(d, e + "bn2.", 128)
+    plan = ((1, 128, 256, 256), (2, 256, 256, 256), (3, 256, 512, 512), (4, 512, 512, 1024))
+    for (li, cin, planes, cout), nb in zip(plan, LAYERS):
+        S._layer(d, e + "layer%d." % li, cin, planes, nb)
+        tail = "layer%d_conv." % li if li < 4 else "layer4_conv2."
+        tbn = "layer%d_bn." % li if li < 4 else "layer4_conv2_bn."
+        S._conv(d, e + tail, cout, planes)
+        S._bn(d, e + tbn, cout)
+    out = d                                                  # decoder in the reference's registration order
+    S._mha(out, "decoder.mask_multihead.", 1024, 16)
+    out["decoder.mul_layernorm1.a_2"], out["decoder.mul_layernorm1.b_2"] = torch.ones(1024), torch.zeros(1024)
+    S._mha(out, "decoder.multihead.", 1024, 16)
+    out["decoder.mul_layernorm2.a_2"], out["decoder.mul_layernorm2.b_2"] = torch.ones(1024), torch.zeros(1024)
+    S._lin(out, "decoder.pff.w_1.", 2048, 1024)
+    S._lin(out, "decoder.pff.w_2.", 1024, 2048)
+    out["decoder.mul_layernorm3.a_2"], out["decoder.mul_layernorm3.b_2"] = torch.ones(1024), torch.zeros(1024)
+    S._lin(out, "generator_word.proj.", n_class, 1024)
+    return out
+
+
+def make_params():
+    return OrderedDict((k, v.clone()) for k, v in schema().items())          # frozen: nothing requires grad
+
+
+def to_gray(x):
+    """text_focus_loss.py:17-22"""
+    return 0.299 * x[:, 0:1] + 0.587 * x[:, 1:2] + 0.114 * x[:, 2:3]
+
+
+def label_encoder(labels):
+    """text_focus_loss.py:62-81 on labels already str_filt'ed + '-'"""
+    a2n = {c: i for i, c in enumerate(ENGLISH)}
+    length = torch.tensor([len(s) for s in labels], dtype=torch.long)
+    text_input = torch.zeros(len(labels), int(length.max()), dtype=torch.long)
+    for i, s in enumerate(labels):
+        for j in range(len(s) - 1):
+            text_input[i, j + 1] = a2n[s[j]]
+    text_gt = torch.tensor([a2n[c] for s in labels for c in s], dtype=torch.long)
+    return length, text_input, text_gt
+
+
+def encoder(P, x):
+    """loss/transformer.py:133-163: TWO max-pools (after conv1 and in front of layer1): 32x128 -> 8x32; eval-mode BN"""
+    e = "encoder.cnn."
+    x = F.max_pool2d(F.relu(S._bnf(P, e + "bn1.", S._cv(P, e + "conv1.", x), False)), 2, 2)
+    x = F.relu(S._bnf(P, e + "bn2.", S._cv(P, e + "conv2.", x), False))
+    x = F.max_pool2d(x, 2, 2)
+    for li, nb in zip((1, 2, 3, 4), LAYERS):
+        for i in range(nb):
+            x = S.basic_block(P, "%slayer%d.%d." % (e, li, i), x, False)
+        tail = "layer%d_conv." % li if li < 4 else "layer4_conv2."
+        tbn = "layer%d_bn." % li if li < 4 else "layer4_conv2_bn."
+        x = F.relu(S._bnf(P, e + tbn, S._cv(P, e + tail, x), False))
+    return x
+
+
+def recognizer(P, gray, text_length, text_input):
+    """loss/transformer.py:354-389 (test=False branch), eval mode (build_up_transformer: transformer.eval())"""
+    conv = encoder(P, gray)
+    emb = F.embedding(text_input, P["embedding_word.lut.weight"]) * math.sqrt(512)
+    pos = P["pe.pe"][:, :emb.shape[1]].expand(emb.shape[0], -1, -1)
+    x = torch.cat([emb, pos], 2)
+    L = x.shape[1]
+    mask = torch.tril(torch.ones(1, L, L, dtype=torch.bool))
+    r = S.layernorm(x + S.mha(P, "decoder.mask_multihead.", x, x, x, mask, 0.0, h=16)[0],
+                    P["decoder.mul_layernorm1.a_2"], P["decoder.mul_layernorm1.b_2"])
+    b, c, hh, ww = conv.shape
+    mem = conv.view(b, c, hh * ww).permute(0, 2, 1).contiguous()
+    align, amap = S.mha(P, "decoder.multihead.", r, mem, mem, None, 0.0, h=16)
+    r = S.layernorm(r + align, P["decoder.mul_layernorm2.a_2"], P["decoder.mul_layernorm2.b_2"])
+    ff = F.linear(F.relu(F.linear(r, P["decoder.pff.w_1.weight"], P["decoder.pff.w_1.bias"])),
+                  P["decoder.pff.w_2.weight"], P["decoder.pff.w_2.bias"])
+    r = S.layernorm(r + ff, P["decoder.mul_layernorm3.a_2"], P["decoder.mul_layernorm3.b_2"])
+    logits = F.linear(r, P["generator_word.proj.weight"], P["generator_word.proj.bias"])
+    pred = torch.cat([logits[i, :int(n)] for i, n in enumerate(text_length)], 0)
+    return pred, amap, conv
+
+
+def weight_cross_entropy(pred, gt, table):
+    """loss/weight_ce_loss.py:38-45: -mean log( w[gt][gt] e^pred[gt] / sum_c w[gt][c] e^pred[c] )"""
+    w = table[gt]
+    pe = w * torch.exp(pred)
+    return -(torch.log(pe.gather(1, gt[:, None])[:, 0] / pe.sum(1))).sum() / gt.shape[0]
+
+
+def text_focus_loss(P, sr, hr, labels_filtered, table):
+    """text_focus_loss.py:84-99: mse + 10 L1(attention maps) + 0.0005 weighted CE; labels already filtered + '-'"""
+    mse = F.mse_loss(sr, hr)
+    length, text_input, text_gt = label_encoder(labels_filtered)
+    with torch.no_grad():
+        _, map_gt, _ = recognizer(P, to_gray(hr), length, text_input)
+    pred, map_pred, conv = recognizer(P, to_gray(sr), length, text_input)
+    att = F.l1_loss(map_gt, map_pred)
+    rec = weight_cross_entropy(pred, text_gt, table)
+    return mse + att * 10 + rec * 0.0005, mse, att, rec, pred, map_pred, conv

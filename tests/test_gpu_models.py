@@ -269,8 +269,7 @@ def test_harness_train_eval_checkpoint(tmp_path, monkeypatch):
 
 def test_harness_demo_and_dispatch(tmp_path, monkeypatch):
     """main.py dispatches --demo to TextSR.demo() (reference main.py:8-15, interfaces/super_resolution.py:331-420):
-    every image of the demo directory is resized to 64 x 16, super-resolved and recognised from LR and from SR;
-    --text_focus (not built) refuses loudly instead of silently training without it."""
+    every image of the demo directory is resized to 64 x 16, super-resolved and recognised from LR and from SR."""
     import os
     import yaml
     from PIL import Image
@@ -290,8 +289,6 @@ def test_harness_demo_and_dispatch(tmp_path, monkeypatch):
         assert [r[0] for r in res["results"]] == ["im0.png", "im1.png", "im2.png"]
         assert all(isinstance(a, str) and isinstance(b, str) for _, a, b in res["results"]) and res["fps"] > 0
     assert not (tmp_path / "checkpoint").exists()              # a demo run never touches the checkpoint directory
-    with pytest.raises(NotImplementedError):
-        M.main(cfg, M.parse(["--arch", "tbsrn", "--exp_name", "d", "--text_focus"]))
 
 
 def test_eval_metrics_on_device(golden_dir):
