@@ -84,6 +84,8 @@ SIGNATURES = {
     "focr_l1_bwd": [P, P, P, P, L, P],
     "focr_weight_cross_entropy_fwd": [P, P, P, P, P, P, L, I, P],
     "focr_set_precision": [I],
+    "focr_set_tuning": [I, I],
+    "focr_get_tuning": [I],
     "focr_get_precision": [],
     "focr_clip_adam": [P, P, P, P, P, L, F, F, F, F, I, F, F, P],
 }

@@ -600,14 +600,10 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_bx3_kernel(
 
 // launchers used by the dispatching C ABI entry points in attention.hip
 // 0: one query tile per wave (128-query blocks); 1: two tiles per wave (256-query blocks, needs Ntok % 256 == 0)
-#ifndef FOCR_ATTN_FWD_VARIANT
-#define FOCR_ATTN_FWD_VARIANT 1
-#endif
-int g_attn_fwd_variant = FOCR_ATTN_FWD_VARIANT;
 int focr_attn_fwd_bx3(const float* q, const float* k, const float* v, float* o, float* lse, uint32_t* mask,
                       int B, int H, int Ntok, int ld, int ldo, float scale, float p_drop, uint64_t seed,
                       hipStream_t stream) {
-  if (g_attn_fwd_variant == 1 && Ntok % 256 == 0) {
+  if (focr_get_tuning(FOCR_TUNE_ATTN_FWD_VARIANT) == 1 && Ntok % 256 == 0) {
     dim3 grid2(B * H * (Ntok / 256));
     if (p_drop > 0.f)
       hipLaunchKernelGGL((attn_fwd2_bx3_kernel<true>), grid2, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ld, ldo,

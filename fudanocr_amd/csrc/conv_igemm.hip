@@ -394,6 +394,11 @@ int focr_conv3x3_c64_wgrad(const float* x, const float* dy, float* dw, float* db
                            int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW, int ldd, int ldx,
                            hipStream_t stream);
 long focr_conv3x3_c64_ws_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW);
+// linear_wgrad.hip
+int focr_linear_wgrad_eligible(long M, int K, int Cout, int ldx, int ldd);
+long focr_linear_wgrad_ws_floats(long M, int K, int Cout);
+int focr_linear_wgrad(const float* x, const float* dy, float* dw, float* dbias, float* ws, long ws_floats, long M, int K,
+                      int Cout, int ldx, int ldd, int accumulate, hipStream_t stream);
 
 int focr_conv9x9_cin3_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y, int N,
                           int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW, int ldx, int ldy,
@@ -478,6 +483,8 @@ extern "C" int focr_linear_relu_dropout_fwd(const float* x, const float* w, cons
 extern "C" long focr_conv2d_wgrad_ws_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int padH,
                                             int padW) {
   if (focr_get_precision() == 0) return 0;
+  if (KH == 1 && KW == 1 && padH == 0 && padW == 0 && focr_linear_wgrad_eligible((long)N * H * W, Cin, Cout, 4, 4))
+    return focr_linear_wgrad_ws_floats((long)N * H * W, Cin, Cout);
   long n = focr_conv3x3_c64_ws_floats(N, H, W, Cin, Cout, KH, KW, padH, padW);
   if (n > 0) return n;
   ConvGeom g;
@@ -495,6 +502,15 @@ extern "C" int focr_conv2d_wgrad(const float* x, const float* dy, float* dw, flo
   if (ldd <= 0) ldd = Cout;
   if (ldx > 0) g.ldx = ldx;
   FOCR_CHECK_ARG(ldd >= Cout && g.ldx >= Cin, "row pitch too small");
+  // the transformer linears (1x1, 128-multiples, many rows): streaming kernel + fixed-order slot reduction
+  // (linear_wgrad.hip), no memset and no atomics
+  if (KH == 1 && KW == 1 && padH == 0 && padW == 0 && focr_get_precision() != 0 && ws &&
+      focr_get_tuning(FOCR_TUNE_LINEAR_WGRAD_STREAM) && focr_linear_wgrad_eligible(g.M, Cin, Cout, g.ldx, ldd) &&
+      ws_floats >= focr_linear_wgrad_ws_floats(g.M, Cin, Cout)) {
+    focr_linear_wgrad(x, dy, dw, dbias, ws, ws_floats, g.M, Cin, Cout, g.ldx, ldd, prezeroed, stream);
+    FOCR_LAUNCH_CHECK();
+    return FOCR_OK;
+  }
   if (!prezeroed && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cout * g.Ktot, stream) != hipSuccess) {
     focr_set_error("focr_conv2d_wgrad: memset failed");
     return FOCR_EHIP;

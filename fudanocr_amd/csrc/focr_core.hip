@@ -34,3 +34,18 @@ extern "C" int focr_set_precision(int mode) {
   return FOCR_OK;
 }
 extern "C" int focr_get_precision(void) { return g_precision; }
+
+// Kernel-selection switches for A/B measurements (tools/dev, tools/ubench): every switch has ONE production value (the
+// default); results are the same either way, only the kernel that computes them changes.
+//   0 "linear_wgrad_stream"  1: transformer-linear weight gradients on linear_wgrad.hip   0: generic split kernel
+//   1 "attn_fwd_variant"     1: 256-query attention forward blocks                        0: 128-query blocks
+int g_tuning[FOCR_TUNING_COUNT] = {1, 1};
+extern "C" int focr_set_tuning(int key, int value) {
+  if (key < 0 || key >= FOCR_TUNING_COUNT) {
+    focr_set_error("focr_set_tuning: unknown key %d", key);
+    return FOCR_EINVAL;
+  }
+  g_tuning[key] = value;
+  return FOCR_OK;
+}
+extern "C" int focr_get_tuning(int key) { return (key >= 0 && key < FOCR_TUNING_COUNT) ? g_tuning[key] : -1; }

@@ -42,6 +42,11 @@ int focr_version(void);
  *   gradient accumulations in the attention backward; 3 = 2 with single-bf16 data-gradient convolutions on the halo
  *   kernel.  Forward results are identical in modes 1-3 (csrc/focr_core.hip). */
 int focr_set_precision(int mode);
+/* A/B kernel-selection switches for measurements (results do not depend on them; defaults are the production
+ * kernels).  key 0: transformer-linear weight gradients on the streaming kernel (1, default) or the generic split
+ * kernel (0); key 1: attention forward with 256-query (1, default) or 128-query (0) blocks. */
+int focr_set_tuning(int key, int value);
+int focr_get_tuning(int key);
 int focr_get_precision(void);
 
 /* ---- convolution / linear: nn.Conv2d, nn.Linear (stride 1) --------------------------------

@@ -219,7 +219,10 @@ def test_linear(rows, nin, nout, alpha, precision):
 
 
 @pytest.mark.parametrize("rows,nin,nout", [(20011, 128, 128), (16500, 128, 64), (16390, 64, 128), (17000, 128, 384),
-                                           (16384, 64, 64)])
+                                           (16384, 64, 64),
+                                           # rows % 16 == 0, 128-multiples: weight gradient on linear_wgrad.hip (row
+                                           # splits of unequal length, 3 output-column tiles for the packed QKV)
+                                           (20000, 128, 128), (16016, 128, 384), (1024, 128, 128)])
 def test_linear_streaming(rows, nin, nout, precision):
     """large-M short-K linears take the streaming kernel (linear_stream.hip) in the bf16x3 modes: ragged row count,
     residual + alpha epilogue, data gradient through the same kernel on transposed weights.  (No relu here: with

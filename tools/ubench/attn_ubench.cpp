@@ -13,7 +13,8 @@
 extern "C" void focr_set_error(const char* fmt, ...) { va_list a; va_start(a, fmt); vfprintf(stderr, fmt, a); va_end(a); fputc('\n', stderr); }
 static int g_prec = 2;
 extern "C" int focr_get_precision(void) { return g_prec; }
-extern int g_attn_fwd_variant;
+static int g_tune[FOCR_TUNING_COUNT] = {1, 1};
+extern "C" int focr_get_tuning(int key) { return g_tune[key]; }
 extern int g_attn_bwd_variant;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -55,10 +56,10 @@ int main(int argc, char** argv) {
   const float scale = 1.f / sqrtf(32.f);
   const double fl = 4.0 * B * H * (double)N * N * 32;
   for (float p : {0.1f, 0.0f}) {
-    g_attn_fwd_variant = 0;
+    g_tune[FOCR_TUNE_ATTN_FWD_VARIANT] = 0;
     focr_attention_fwd(q, k, v, o0, lse0, mask, B, H, N, D, D, scale, p, 1234, 0);
     float t0 = timeit([&]() { focr_attention_fwd(q, k, v, o0, lse0, mask, B, H, N, D, D, scale, p, 1234, 0); });
-    g_attn_fwd_variant = 1;
+    g_tune[FOCR_TUNE_ATTN_FWD_VARIANT] = 1;
     focr_attention_fwd(q, k, v, o1, lse1, mask, B, H, N, D, D, scale, p, 1234, 0);
     float t1 = timeit([&]() { focr_attention_fwd(q, k, v, o1, lse1, mask, B, H, N, D, D, scale, p, 1234, 0); });
     float tm = p > 0 ? timeit([&]() { hipLaunchKernelGGL(attn_mask_kernel, dim3(262144), 256, 0, 0, mask, (long)B * H * N * (N / 32), p, (uint64_t)1234); }) : 0.f;

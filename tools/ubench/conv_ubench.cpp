@@ -13,6 +13,7 @@
 
 extern "C" void focr_set_error(const char* fmt, ...) { va_list a; va_start(a, fmt); vfprintf(stderr, fmt, a); va_end(a); fputc('\n', stderr); }
 extern "C" int focr_get_precision(void) { return 1; }
+extern "C" int focr_get_tuning(int) { return 1; }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
