@@ -26,6 +26,8 @@ SIGNATURES = {
     "focr_conv3x3_frag_tiles": [I, I, I],
     "focr_conv3x3_frag_fwd": [P, P, P, P, P, P, I, I, I, I, I, F, I, I, I, I, I, P],
     "focr_attention_fwd": [P, P, P, P, P, P, I, I, I, I, I, F, F, U, P],
+    "focr_attention_dropout_mask": [P, I, I, I, F, U, P],
+    "focr_attention_fwd_premasked": [P, P, P, P, P, P, I, I, I, I, I, F, F, P],
     "focr_attention_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, F, P],
     "focr_bn_train_fwd": [P, P, P, P, P, P, P, P, P, P, P, L, I, F, F, I, P],
     "focr_bn_train_fwd_stats": [P, P, I, P, P, P, P, P, P, P, P, P, L, I, F, F, I, P],

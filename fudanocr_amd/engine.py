@@ -141,7 +141,9 @@ class TrainStep:
         self.flips = K.FlipTable()               # one batched weight flip per step for all data-gradient GEMMs
         self.frags = K.FragTable(managed=True)   # pre-split fragment-ordered weights of the halo-kernel layers: one
                                                  # batched preparation launch per step (forward + data-gradient forms)
-        self.ctx = K.StepContext()               # this engine's deferred gradients / tables / side stream (the autograd
+        self.ctx = K.StepContext()
+        self.ctx.mask_prefetch = True            # attention keep bits of step k + 1 are drawn on the side stream
+        #                                          this engine's deferred gradients / tables / side stream (the autograd
                                                  # nodes recorded during its forward carry it into their backward)
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         if self.world > 1:
@@ -259,6 +261,7 @@ class TrainStep:
         c.frags = self.frags if on_gpu else None
         if on_gpu:
             self.frags.refresh()
+            c.prefetch_masks()
         try:
             with K.use_context(c):
                 sr = self.model(images_lr)

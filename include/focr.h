@@ -128,6 +128,14 @@ int focr_conv9x9_small_cout_wgrad(const float* x, const float* dy, float* dw, fl
 int focr_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse,
                        uint32_t* mask, int B, int H, int Ntok, int ld, int ldo, float scale, float p_drop,
                        uint64_t seed, focr_stream_t stream);
+/* The keep bits depend on (B, H, Ntok, p_drop, seed) only: focr_attention_dropout_mask draws them (on any stream, e.g.
+ * ahead of time beside other work), focr_attention_fwd_premasked is the forward on bits that are already in `mask`
+ * (same results as focr_attention_fwd with that seed). */
+int focr_attention_dropout_mask(uint32_t* mask, int B, int H, int Ntok, float p_drop, uint64_t seed,
+                                focr_stream_t stream);
+int focr_attention_fwd_premasked(const float* q, const float* k, const float* v, float* o, float* lse,
+                                 const uint32_t* mask, int B, int H, int Ntok, int ld, int ldo, float scale,
+                                 float p_drop, focr_stream_t stream);
 /* dwork: B*H*Ntok floats */
 int focr_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o,
                        const float* lse, const uint32_t* mask, float* dq, float* dk, float* dv,

@@ -797,3 +797,51 @@ def test_mish_threshold_branch(golden_dir=None):
     (xr * torch.tanh(F.softplus(xr, threshold=20))).sum().backward()
     z.sum().backward()
     close(pre.grad[0, 0, :, 0], xr.grad, 1e-5, what="mish gradient")
+
+
+def test_attention_premasked_equals_seeded():
+    """keep bits drawn ahead of time (focr_attention_dropout_mask on another stream) + focr_attention_fwd_premasked
+    = focr_attention_fwd with the same seed, bit for bit; the engine context hands the pre-drawn bits out in call order
+    and falls back to drawing inline when the shape changes"""
+    import ctypes
+    from fudanocr_amd import _lib
+    k_ = K()
+    b, t, d, heads, p, seed = 2, 256, 128, 4, 0.1, 987654321
+    qkv = dev(rnd(b, t, 3 * d, seed=1, scale=1.5))
+    outs = []
+    for pre in (False, True):
+        o = torch.empty(b, t, d, device="cuda")
+        lse = torch.empty(b, heads, t, device="cuda")
+        mask = torch.zeros(b, heads, t // 32, t // 32, 32, device="cuda", dtype=torch.int32)
+        P = lambda x, off=0: ctypes.c_void_p(x.data_ptr() + 4 * off)                     # noqa: E731
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if pre:
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                _lib.call("focr_attention_dropout_mask", P(mask), b, heads, t, p, seed,
+                          ctypes.c_void_p(side.cuda_stream))
+            torch.cuda.current_stream().wait_stream(side)
+            _lib.call("focr_attention_fwd_premasked", P(qkv), P(qkv, d), P(qkv, 2 * d), P(o), P(lse), P(mask), b, heads,
+                      t, 3 * d, d, 1 / math.sqrt(32), p, st)
+        else:
+            _lib.call("focr_attention_fwd", P(qkv), P(qkv, d), P(qkv, 2 * d), P(o), P(lse), P(mask), b, heads, t, 3 * d,
+                      d, 1 / math.sqrt(32), p, seed, st)
+        outs.append((o.cpu(), lse.cpu(), mask.cpu()))
+    assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # context protocol
+    c = k_.StepContext()
+    c.mask_prefetch = True
+    with k_.use_context(c):
+        c.prefetch_masks()                                         # nothing recorded yet
+        o1 = k_.attention_packed(qkv, heads=4, p_drop=p)           # inline draw, records the request
+        assert len(c._masks) == 1 and c._masks[0]["event"] is None
+        c.prefetch_masks()
+        assert c._masks[0]["event"] is not None
+        o2 = k_.attention_packed(qkv, heads=4, p_drop=p)           # pre-drawn bits (new seed)
+        assert c._masks[0]["event"] is None and not torch.equal(o1, o2)
+        c.prefetch_masks()
+        q2 = dev(rnd(1, 128, 3 * d, seed=2))
+        o3 = k_.attention_packed(q2, heads=4, p_drop=p)            # other shape: falls back to the inline draw
+        assert o3.shape == (1, 128, d) and torch.isfinite(o3).all()
+    kept = (o2 != 0).float().mean().item()
+    assert kept > 0.99                                             # outputs are sums over keys: dropout never zeroes them all
