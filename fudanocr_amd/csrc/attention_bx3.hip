@@ -212,6 +212,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_bx3_kernel(const float* __res
 //   softmax of tile A sits next to the S / PV MFMAs of tile B in the same instruction stream, every K / V fragment
 //   read from LDS feeds two MFMA triples instead of one, and the per-block K/V staging is shared by 256 queries.
 // =======================================================================================
+__device__ __forceinline__ void hi_regs(const f32x16& s, int m, bf16x8& hi);
 template <bool DROPOUT>
 __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                             const float* __restrict__ V, float* __restrict__ O,
@@ -251,10 +252,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __re
   const int ntiles = Ntok / 64;
   LOAD_KV(0);
   for (int kt = 0; kt < ntiles; ++kt) {
-    put_rows(Kh, Kl, rp, c0, k0, k1);
-    put_cols(Vth, Vtl, rp, c0, v0, v1);
+#ifdef ATTN_ABL_STAGE
+    if (kt == 0)
+#endif
+    {
+      put_rows(Kh, Kl, rp, c0, k0, k1);
+      put_cols(Vth, Vtl, rp, c0, v0, v1);
+    }
     __syncthreads();
+#ifndef ATTN_ABL_STAGE
     if (kt + 1 < ntiles) LOAD_KV(kt + 1);
+#endif
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       // keep-bit lane masks of both tiles (wave-uniform -> scalar loads), requested before the score MFMAs so that
@@ -278,9 +286,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __re
       for (int m = 0; m < 2; ++m) {
         bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Kh[(sub * 32 + li) * RP + 16 * m + 8 * lh]);
         bf16x8 al = *reinterpret_cast<const bf16x8*>(&Kl[(sub * 32 + li) * RP + 16 * m + 8 * lh]);
+#ifdef ATTN_ABL_MFMA_S
+        s[0][0] += (float)ah[0] + (float)al[1]; s[1][0] += (float)ah[2];
+#else
         MFMA3(s[0], ah, al, qh[0][m], ql[0][m]);
         MFMA3(s[1], ah, al, qh[1][m], ql[1][m]);
+#endif
       }
+#ifndef ATTN_ABL_SOFTMAX
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         float mx = s[t][0];
@@ -293,7 +306,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __re
         float ls = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+#ifdef ATTN_ABL_EXP
+          const float p = s[t][r] - mn;
+#else
           const float p = __builtin_amdgcn_exp2f(s[t][r] - mn);
+#endif
           ls += p;
           s[t][r] = p;
         }
@@ -305,6 +322,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
       }
+#endif
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         const int kc = sub * 32 + 16 * m + 4 * lh;
@@ -315,12 +333,228 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __re
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           bf16x8 ph, pl;
+#ifdef ATTN_ABL_SPLIT
+          hi_regs(s[t], m, ph);
+          pl = ph;
+#else
           split_regs(s[t], m, ph, pl);
+#endif
+#ifdef ATTN_ABL_MFMA_PV
+          oacc[t][0] += (float)ph[0] + (float)pl[1] + (float)vh[0] + (float)vl[0];
+#else
           MFMA3(oacc[t], vh, vl, ph, pl);
+#endif
         }
       }
     }
     __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    float lt = l[t] + __shfl_xor(l[t], 32, 64);
+    const float inv = inv_keep / lt;
+    const int q = q0 + 32 * t;
+    float* orow = O + baseo + (size_t)q * ldo;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(orow + 8 * g + 4 * lh) = make_float4(
+          oacc[t][4 * g] * inv, oacc[t][4 * g + 1] * inv, oacc[t][4 * g + 2] * inv, oacc[t][4 * g + 3] * inv);
+    if (lh == 0) LSE[(size_t)(b * H + h) * Ntok + q] = (mrun[t] + __builtin_amdgcn_logf(lt)) * LN2;   // natural log
+  }
+}
+
+// =======================================================================================
+// forward, two query tiles per wave, score products ONE key group ahead (variant 2)
+//   In attn_fwd2 the S MFMAs of a key group are followed immediately by the softmax that consumes them: the wave
+//   waits out the matrix pipe, then the pipe idles through ~300 VALU instructions (ablation: removing the 12 S MFMAs
+//   saves 121 us of 248, removing the 12 PV MFMAs only 64).  Here the scores of group g + 1 are issued BEFORE the
+//   softmax of group g, so the softmax VALU work runs under independent MFMAs; K/V tiles are triple-buffered in LDS
+//   so that the look-ahead may cross into the next 64-key tile with ONE barrier per tile.  The running-max rescale of
+//   O / l is taken only when some query's max grew by more than 2^ATTN_RESCALE_THR (wave-uniform branch): P is then
+//   bounded by 2^THR instead of 1, harmless in fp32 accumulation with split operands, and the 16 multiplies + exp of
+//   the common no-change case disappear.
+// =======================================================================================
+#ifndef ATTN_RESCALE_THR
+#define ATTN_RESCALE_THR 8.0f
+#endif
+#define F3_KB (64 * RP)
+#define F3_VB (32 * TP)
+
+__device__ __forceinline__ void f3_scores(f32x16 (&s)[2], const __bf16* Kh, const __bf16* Kl, int sub, int li, int lh,
+                                          const bf16x8 (&qh)[2][2], const bf16x8 (&ql)[2][2]) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Kh[(sub * 32 + li) * RP + 16 * m + 8 * lh]);
+    const bf16x8 al = *reinterpret_cast<const bf16x8*>(&Kl[(sub * 32 + li) * RP + 16 * m + 8 * lh]);
+    MFMA3(s[0], ah, al, qh[0][m], ql[0][m]);
+    MFMA3(s[1], ah, al, qh[1][m], ql[1][m]);
+  }
+}
+// running max of one tile + the (rare, wave-uniform) rescale of its O / l
+__device__ __forceinline__ void f3_rowmax(const f32x16& s, f32x16& oacc, float& mrun, float& l) {
+  float mx = s[0];
+#pragma unroll
+  for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  if (__builtin_amdgcn_ballot_w64(mx > mrun + ATTN_RESCALE_THR) != 0ull) {     // wave-uniform
+    const float mn = fmaxf(mrun, mx);
+    const float alpha = __builtin_amdgcn_exp2f(mrun - mn);
+    mrun = mn;
+    l *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+  }
+}
+// ONE basic block: the 12 score MFMAs of the NEXT key group (sn) interleaved with the exponentials / sums / keep-bit
+// selects of the CURRENT one (sc): 12 x 32 matrix-pipe cycles beside ~130 VALU + 32 transcendental issues
+template <bool DROPOUT, bool NEXT>
+__device__ __forceinline__ void f3_exp_scores(f32x16 (&sc)[2], f32x16 (&sn)[2], const float (&mrun)[2], float (&l)[2],
+                                              const uint64_t* mp0, const uint64_t* mp1, const __bf16* Kh,
+                                              const __bf16* Kl, int sub, int li, int lh, const bf16x8 (&qh)[2][2],
+                                              const bf16x8 (&ql)[2][2]) {
+  uint64_t mk[2][16];
+  if (DROPOUT) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { mk[0][r] = mp0[r]; mk[1][r] = mp1[r]; }
+  }
+  bf16x8 ah[2], al[2];
+  if (NEXT) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      ah[m] = *reinterpret_cast<const bf16x8*>(&Kh[(sub * 32 + li) * RP + 16 * m + 8 * lh]);
+      al[m] = *reinterpret_cast<const bf16x8*>(&Kl[(sub * 32 + li) * RP + 16 * m + 8 * lh]);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sn[t][r] = 0.f;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (NEXT) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      MFMA3(sn[0], ah[m], al[m], qh[0][m], ql[0][m]);
+      MFMA3(sn[1], ah[m], al[m], qh[1][m], ql[1][m]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    float ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float p = __builtin_amdgcn_exp2f(sc[t][r] - mrun[t]);
+      ls += p;
+      if (DROPOUT) p = keep_lanes(p, mk[t][r]);      // 1/(1-p) at the end
+      sc[t][r] = p;
+    }
+    l[t] += ls;
+  }
+  if (NEXT) {
+    // MFMA = 0x8, VALU = 0x2, TRANS = 0x400
+// same-accumulator MFMA triples stay back to back (an issue slot between two MFMAs on one accumulator costs ~43
+    // cycles, MI355X_MICROARCH.md); the VALU / transcendental work goes between triples on different accumulators
+#define F3_GROUP                                                   \
+  __builtin_amdgcn_sched_group_barrier(0x8, 3, 0);                  \
+  __builtin_amdgcn_sched_group_barrier(0x2, DROPOUT ? 24 : 18, 0);  \
+  __builtin_amdgcn_sched_group_barrier(0x400, 8, 0);
+    F3_GROUP F3_GROUP F3_GROUP F3_GROUP
+#undef F3_GROUP
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void f3_pv(f32x16 (&oacc)[2], const f32x16 (&s)[2], const __bf16* Vth, const __bf16* Vtl,
+                                      int sub, int li, int lh) {
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int kc = sub * 32 + 16 * m + 4 * lh;
+    const bf16x8 vh = cat44(*reinterpret_cast<const bf16x4*>(&Vth[li * TP + kc]),
+                            *reinterpret_cast<const bf16x4*>(&Vth[li * TP + kc + 8]));
+    const bf16x8 vl = cat44(*reinterpret_cast<const bf16x4*>(&Vtl[li * TP + kc]),
+                            *reinterpret_cast<const bf16x4*>(&Vtl[li * TP + kc + 8]));
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bf16x8 ph, pl;
+      split_regs(s[t], m, ph, pl);
+      MFMA3(oacc[t], vh, vl, ph, pl);
+    }
+  }
+}
+
+template <bool DROPOUT>
+__global__ __launch_bounds__(256, 2) void attn_fwd3_bx3_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                            const float* __restrict__ V, float* __restrict__ O,
+                                                            float* __restrict__ LSE, const uint32_t* __restrict__ MASK,
+                                                            int Ntok, int ld, int ldo, float scale, float p_drop,
+                                                            uint64_t seed, int nheads) {
+  __shared__ __attribute__((aligned(16))) __bf16 Kh[3 * F3_KB], Kl[3 * F3_KB];
+  __shared__ __attribute__((aligned(16))) __bf16 Vth[3 * F3_VB], Vtl[3 * F3_VB];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  int bh_, qb_;
+  attn_block_decode(blockIdx.x, gridDim.x / (Ntok / 256), Ntok / 256, bh_, qb_);
+  const int H = nheads, h = bh_ % nheads, b = bh_ / nheads;
+  const size_t base = (size_t)b * Ntok * ld + h * 32;
+  const size_t baseo = (size_t)b * Ntok * ldo + h * 32;
+  const int q0 = qb_ * 256 + wave * 64 + li;                 // tile t: query q0 + 32 t
+
+  bf16x8 qh[2][2], ql[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+      row_frag(Q + base + (size_t)(q0 + 32 * t) * ld + 16 * m + 8 * lh, scale * LOG2E, qh[t][m], ql[t][m]);
+  f32x16 oacc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+  float mrun[2] = {-1e30f, -1e30f}, l[2] = {0.f, 0.f};
+  const uint32_t thr = DROPOUT ? attn_drop_thr16(p_drop) : 0u;
+  const float inv_keep = DROPOUT ? 1.f / (1.f - (float)thr / 65536.f) : 1.f;
+  const int NG = Ntok / 32;
+  const int qg = __builtin_amdgcn_readfirstlane(qb_ * 8 + wave * 2);
+  const uint64_t* mgrp = reinterpret_cast<const uint64_t*>(MASK) + ((size_t)bh_ * NG + qg) * NG * 16;
+
+  const int rp = tid >> 3, c0 = (tid & 7) * 4;         // key pair, first of 4 d columns
+  float4 k0, k1, v0, v1;
+  const int ntiles = Ntok / 64;
+  LOAD_KV(0);
+  put_rows(Kh, Kl, rp, c0, k0, k1);
+  put_cols(Vth, Vtl, rp, c0, v0, v1);
+  __syncthreads();
+  if (ntiles > 1) LOAD_KV(1);
+  f32x16 sa[2], sb[2];
+  f3_scores(sa, Kh, Kl, 0, li, lh, qh, ql);
+  int buf = 0;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const __bf16 *kh = Kh + buf * F3_KB, *kl = Kl + buf * F3_KB, *vth = Vth + buf * F3_VB, *vtl = Vtl + buf * F3_VB;
+    // ---- key group 0 of the tile: its scores (sa) were issued one group ago; group 1's go out under its softmax
+    f3_rowmax(sa[0], oacc[0], mrun[0], l[0]);
+    f3_rowmax(sa[1], oacc[1], mrun[1], l[1]);
+    f3_exp_scores<DROPOUT, true>(sa, sb, mrun, l, mgrp + ((size_t)0 * NG + (kt * 2 + 0)) * 16,
+                                 mgrp + ((size_t)1 * NG + (kt * 2 + 0)) * 16, kh, kl, 1, li, lh, qh, ql);
+    f3_pv(oacc, sa, vth, vtl, 0, li, lh);
+    // ---- key group 1: the next tile goes into the third buffer (the one nobody can still be reading), one barrier
+    const int nbuf = buf == 2 ? 0 : buf + 1;
+    f3_rowmax(sb[0], oacc[0], mrun[0], l[0]);
+    f3_rowmax(sb[1], oacc[1], mrun[1], l[1]);
+    if (kt + 1 < ntiles) {
+      put_rows(Kh + nbuf * F3_KB, Kl + nbuf * F3_KB, rp, c0, k0, k1);
+      put_cols(Vth + nbuf * F3_VB, Vtl + nbuf * F3_VB, rp, c0, v0, v1);
+      __syncthreads();
+      if (kt + 2 < ntiles) LOAD_KV(kt + 2);
+      f3_exp_scores<DROPOUT, true>(sb, sa, mrun, l, mgrp + ((size_t)0 * NG + (kt * 2 + 1)) * 16,
+                                   mgrp + ((size_t)1 * NG + (kt * 2 + 1)) * 16, Kh + nbuf * F3_KB, Kl + nbuf * F3_KB,
+                                   0, li, lh, qh, ql);
+    } else {
+      f3_exp_scores<DROPOUT, false>(sb, sa, mrun, l, mgrp + ((size_t)0 * NG + (kt * 2 + 1)) * 16,
+                                    mgrp + ((size_t)1 * NG + (kt * 2 + 1)) * 16, kh, kl, 0, li, lh, qh, ql);
+    }
+    f3_pv(oacc, sb, vth, vtl, 1, li, lh);
+    buf = nbuf;
   }
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -603,6 +837,16 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_bx3_kernel(
 int focr_attn_fwd_bx3(const float* q, const float* k, const float* v, float* o, float* lse, uint32_t* mask,
                       int B, int H, int Ntok, int ld, int ldo, float scale, float p_drop, uint64_t seed,
                       hipStream_t stream) {
+  if (focr_get_tuning(FOCR_TUNE_ATTN_FWD_VARIANT) == 2 && Ntok % 256 == 0) {
+    dim3 grid2(B * H * (Ntok / 256));
+    if (p_drop > 0.f)
+      hipLaunchKernelGGL((attn_fwd3_bx3_kernel<true>), grid2, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ld, ldo,
+                         scale, p_drop, seed, H);
+    else
+      hipLaunchKernelGGL((attn_fwd3_bx3_kernel<false>), grid2, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ld, ldo,
+                         scale, p_drop, seed, H);
+    return 0;
+  }
   if (focr_get_tuning(FOCR_TUNE_ATTN_FWD_VARIANT) == 1 && Ntok % 256 == 0) {
     dim3 grid2(B * H * (Ntok / 256));
     if (p_drop > 0.f)

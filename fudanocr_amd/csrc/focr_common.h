@@ -15,7 +15,8 @@ extern "C" int focr_get_precision(void);
 // A/B kernel-selection switches (focr_core.hip focr_set_tuning)
 #define FOCR_TUNE_LINEAR_WGRAD_STREAM 0
 #define FOCR_TUNE_ATTN_FWD_VARIANT 1
-#define FOCR_TUNING_COUNT 2
+#define FOCR_TUNE_LSTM_PERSISTENT 2
+#define FOCR_TUNING_COUNT 3
 extern "C" int focr_get_tuning(int key);
 
 #define FOCR_CHECK_ARG(cond, msg)                          \

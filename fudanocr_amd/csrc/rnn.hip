@@ -578,12 +578,266 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_bx3_kernel(
   }
 }
 
+// =======================================================================================
+// Persistent variants: ONE launch walks all T steps (a BiLSTM layer = 1 launch instead of T).
+//   * block (jx, by, dir) owns 32 hidden units x 32 sequences of one direction for the whole scan; its slice of
+//     W_hh (4 gates x 32 units x 256, bf16 hi + lo = 128 KB) is read ONCE into LDS and stays there;
+//   * c_{t-1} / the carried dc live in registers of the thread that owns the cell element (ownership is fixed);
+//   * step t needs h_{t-1} of ALL 256 units of its 32 sequences = the output of the 8 blocks (jx = 0..7) that share
+//     (by, dir): those 8 blocks meet at a counter in global memory once per step -- release increment after the block's
+//     h / gate-gradient rows are written, acquire spin before they are read (agent scope: the 8 blocks may sit on
+//     different XCDs, whose L2s are not coherent with each other).  Block ids are laid out so that the 8 partners
+//     have the same id mod 8 (= the same XCD under round-robin dispatch), which keeps the exchange inside one L2;
+//   * the inputs of the cell update that do not depend on the partners (gx, bias; gates, c, dh in the backward) are
+//     requested BEFORE the wait;
+//   * a bounded spin (LSTM_SPIN_LIMIT polls) turns a scheduling surprise into an error word instead of a hung GPU.
+// All 8 x (B/32) x 2 blocks must be resident at once (64 blocks of 512 threads / 152 KB LDS at B = 128; the launcher
+// falls back to the per-step kernels beyond 256 blocks).
+// =======================================================================================
+#define LP_WP 264                       // bf16 pitch of a 256-long W row (528 B: conflict-free ds_read_b128)
+#define LP_WTP 1032                     // bf16 pitch of a 1024-long W^T row
+#ifndef LSTM_SPIN_LIMIT
+#define LSTM_SPIN_LIMIT (1 << 22)
+#endif
+
+__device__ __forceinline__ void lp_wait(unsigned* flag, unsigned target, unsigned* err) {
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > LSTM_SPIN_LIMIT) {
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void lp_arrive(unsigned* flag) {
+  __syncthreads();                      // every thread's rows of this step are written (and acknowledged by L2)
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
+    const float* __restrict__ gx, const __bf16* __restrict__ whh2, const float* __restrict__ bhh,
+    float* __restrict__ hseq, __bf16* __restrict__ hseq2, float* __restrict__ gates, float* __restrict__ cseq,
+    unsigned* __restrict__ flags, int T, int B, int st_t, int st_b, int ngroups) {
+  constexpr int H = 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lp_smem[];
+  __bf16* Wh = reinterpret_cast<__bf16*>(lp_smem);              // [128][LP_WP]
+  __bf16* Wl = Wh + 128 * LP_WP;
+  float(*part)[32][33] = reinterpret_cast<float(*)[32][33]>(Wl + 128 * LP_WP);   // [4 gates][32][33]
+  const int tid = threadIdx.x, wave = tid >> 6, g = wave & 3, kq = wave >> 2;
+  const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int group = blockIdx.x % ngroups, jx = blockIdx.x / ngroups;
+  const int dir = group & 1, j0 = jx * 32, b0 = (group >> 1) * 32;
+  const long nh = (long)T * B * 2 * H;
+  const long nw = (long)2 * 4 * H * H;
+  unsigned* flag = flags + group;
+  unsigned* err = flags + ngroups;
+  for (int i = tid; i < 128 * 32; i += 512) {                   // 16-byte pieces of the 128 rows x 256 k slice
+    const int row = i >> 5, ch = i & 31, gg = row >> 5, u = row & 31;
+    const __bf16* src = whh2 + ((size_t)dir * 4 * H + gg * H + j0 + u) * H + 8 * ch;
+    *reinterpret_cast<uint4*>(Wh + row * LP_WP + 8 * ch) = *reinterpret_cast<const uint4*>(src);
+    *reinterpret_cast<uint4*>(Wl + row * LP_WP + 8 * ch) = *reinterpret_cast<const uint4*>(src + nw);
+  }
+  // the two cell elements of this thread: (sequence ebl, unit eu), ebl = e >> 5 for e = tid, tid + 512
+  float cprev[2] = {0.f, 0.f};
+  const int eu = tid & 31;
+  const float4 bias = make_float4(bhh[(size_t)dir * 4 * H + j0 + eu], bhh[(size_t)dir * 4 * H + H + j0 + eu],
+                                  bhh[(size_t)dir * 4 * H + 2 * H + j0 + eu], bhh[(size_t)dir * 4 * H + 3 * H + j0 + eu]);
+  __syncthreads();
+  const int br = min(b0 + li, B - 1);
+  for (int step = 0; step < T; ++step) {
+    const int t = dir == 0 ? step : T - 1 - step;
+    const int tp = dir == 0 ? t - 1 : t + 1;
+    float gxv[2][4];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int eb = b0 + (tid >> 5) + 16 * e;
+      const float* gp = gx + ((size_t)t * st_t + (size_t)min(eb, B - 1) * st_b) * 8 * H + dir * 4 * H + j0 + eu;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gxv[e][q] = gp[q * H];
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (step > 0) {
+      lp_wait(flag, 8u * (unsigned)step, err);
+      const __bf16* arow = hseq2 + ((size_t)tp * B + br) * 2 * H + dir * H + 128 * kq + 8 * lh;
+      const __bf16* brow = Wh + (g * 32 + li) * LP_WP + 128 * kq + 8 * lh;
+      rbf16x8 ah[8], al[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        ah[i] = *reinterpret_cast<const rbf16x8*>(arow + 16 * i);
+        al[i] = *reinterpret_cast<const rbf16x8*>(arow + nh + 16 * i);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const rbf16x8 wh = *reinterpret_cast<const rbf16x8*>(brow + 16 * i);
+        const rbf16x8 wl = *reinterpret_cast<const rbf16x8*>(brow + 128 * LP_WP + 16 * i);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], wh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], wl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], wh, acc, 0, 0, 0);
+      }
+    }
+    if (kq == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[g][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = acc[r];
+    }
+    __syncthreads();
+    if (kq == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int bl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        part[g][bl][li] = acc[r] + part[g][bl][li];             // fixed order: low K half + high K half
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int ebl = (tid >> 5) + 16 * e, eb = b0 + ebl;
+      if (eb < B) {
+        const float ig = sigmoidf_(part[0][ebl][eu] + gxv[e][0] + bias.x);
+        const float fg = sigmoidf_(part[1][ebl][eu] + gxv[e][1] + bias.y);
+        const float gg = tanhf(part[2][ebl][eu] + gxv[e][2] + bias.z);
+        const float og = sigmoidf_(part[3][ebl][eu] + gxv[e][3] + bias.w);
+        const float c = fg * cprev[e] + ig * gg;
+        const float h = og * tanhf(c);
+        cprev[e] = c;
+        const size_t gb = (((size_t)t * B + eb) * 2 + dir) * 4 * H + j0 + eu;
+        gates[gb] = ig;
+        gates[gb + H] = fg;
+        gates[gb + 2 * H] = gg;
+        gates[gb + 3 * H] = og;
+        cseq[(((size_t)t * B + eb) * 2 + dir) * H + j0 + eu] = c;
+        const size_t ho = ((size_t)t * B + eb) * 2 * H + dir * H + j0 + eu;
+        hseq[ho] = h;
+        const __bf16 hh = (__bf16)h;
+        hseq2[ho] = hh;
+        hseq2[nh + ho] = (__bf16)(h - (float)hh);
+      }
+    }
+    if (step + 1 < T) lp_arrive(flag);          // (the barrier inside also protects `part` for the next step)
+  }
+}
+
+__global__ __launch_bounds__(512) void lstm_bwd_persist_bx3_kernel(
+    const float* __restrict__ dhseq, const __bf16* __restrict__ whhT2, const float* __restrict__ gates,
+    const float* __restrict__ cseq, float* __restrict__ dgx, __bf16* __restrict__ dgx2, unsigned* __restrict__ flags,
+    int T, int B, int st_t, int st_b, long ndg, int ngroups) {
+  constexpr int H = 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lp_smem[];
+  __bf16* Wh = reinterpret_cast<__bf16*>(lp_smem);              // [32 units][LP_WTP]  (W_hh^T rows: n over 4H)
+  __bf16* Wl = Wh + 32 * LP_WTP;
+  float(*part)[32][33] = reinterpret_cast<float(*)[32][33]>(Wl + 32 * LP_WTP);   // [4][32][33]
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int group = blockIdx.x % ngroups, jx = blockIdx.x / ngroups;
+  const int dir = group & 1, j0 = jx * 32, b0 = (group >> 1) * 32;
+  const long nwt = (long)2 * H * 4 * H;
+  unsigned* flag = flags + group;
+  unsigned* err = flags + ngroups;
+  for (int i = tid; i < 32 * 128; i += 512) {                   // 16-byte pieces of 32 rows x 1024 n
+    const int row = i >> 7, ch = i & 127;
+    const __bf16* src = whhT2 + ((size_t)dir * H + j0 + row) * 4 * H + 8 * ch;
+    *reinterpret_cast<uint4*>(Wh + row * LP_WTP + 8 * ch) = *reinterpret_cast<const uint4*>(src);
+    *reinterpret_cast<uint4*>(Wl + row * LP_WTP + 8 * ch) = *reinterpret_cast<const uint4*>(src + nwt);
+  }
+  float carry[2] = {0.f, 0.f};
+  const int eu = tid & 31;
+  __syncthreads();
+  const int br = min(b0 + li, B - 1);
+  for (int step = 0; step < T; ++step) {
+    const int t = dir == 0 ? T - 1 - step : step;
+    const int tn = dir == 0 ? t + 1 : t - 1;
+    const int tp = dir == 0 ? t - 1 : t + 1;
+    const bool first = dir == 0 ? t == 0 : t == T - 1;
+    float dh0[2], ig[2], fg[2], gg[2], og[2], c[2], cp[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int eb = min(b0 + (tid >> 5) + 16 * e, B - 1);
+      dh0[e] = dhseq[((size_t)t * B + eb) * 2 * H + dir * H + j0 + eu];
+      const size_t gb = (((size_t)t * B + eb) * 2 + dir) * 4 * H + j0 + eu;
+      ig[e] = gates[gb], fg[e] = gates[gb + H], gg[e] = gates[gb + 2 * H], og[e] = gates[gb + 3 * H];
+      c[e] = cseq[(((size_t)t * B + eb) * 2 + dir) * H + j0 + eu];
+      cp[e] = first ? 0.f : cseq[(((size_t)tp * B + eb) * 2 + dir) * H + j0 + eu];
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (step > 0) {
+      lp_wait(flag, 8u * (unsigned)step, err);
+      // wave w contracts n in [128 w, 128 w + 128) of the 4H gate-gradient row
+      const __bf16* arow = dgx2 + ((size_t)tn * st_t + (size_t)br * st_b) * 8 * H + dir * 4 * H + 128 * wave + 8 * lh;
+      const __bf16* brow = Wh + li * LP_WTP + 128 * wave + 8 * lh;
+      rbf16x8 ah[8], al[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        ah[i] = *reinterpret_cast<const rbf16x8*>(arow + 16 * i);
+        al[i] = *reinterpret_cast<const rbf16x8*>(arow + ndg + 16 * i);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const rbf16x8 wh = *reinterpret_cast<const rbf16x8*>(brow + 16 * i);
+        const rbf16x8 wl = *reinterpret_cast<const rbf16x8*>(brow + 32 * LP_WTP + 16 * i);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], wh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], wl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], wh, acc, 0, 0, 0);
+      }
+    }
+    // fold the 8 partial tiles in a fixed order: (w + (w + 4)) per slot, then slots 0..3 in the epilogue
+    if (wave >= 4) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[wave - 4][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = acc[r];
+    }
+    __syncthreads();
+    if (wave < 4) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int bl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        part[wave][bl][li] = acc[r] + part[wave][bl][li];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int ebl = (tid >> 5) + 16 * e, eb = b0 + ebl;
+      if (eb < B) {
+        const float dh = dh0[e] + (((part[0][ebl][eu] + part[1][ebl][eu]) + part[2][ebl][eu]) + part[3][ebl][eu]);
+        const float tc = tanhf(c[e]);
+        const float dc = dh * og[e] * (1.f - tc * tc) + carry[e];
+        carry[e] = dc * fg[e];
+        const size_t ob = ((size_t)t * st_t + (size_t)eb * st_b) * 8 * H + dir * 4 * H + j0 + eu;
+        const float d4[4] = {dc * gg[e] * ig[e] * (1.f - ig[e]), dc * cp[e] * fg[e] * (1.f - fg[e]),
+                             dc * ig[e] * (1.f - gg[e] * gg[e]), dh * tc * og[e] * (1.f - og[e])};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          dgx[ob + q * H] = d4[q];
+          const __bf16 hh = (__bf16)d4[q];
+          dgx2[ob + q * H] = hh;
+          dgx2[ndg + ob + q * H] = (__bf16)(d4[q] - (float)hh);
+        }
+      }
+    }
+    if (step + 1 < T) lp_arrive(flag);
+  }
+}
+
+#define LP_FWD_LDS (2 * 128 * LP_WP * 2 + 4 * 32 * 33 * 4)       // 152064 B
+#define LP_BWD_LDS (2 * 32 * LP_WTP * 2 + 4 * 32 * 33 * 4)       // 148992 B
+#define LP_FLAG_BYTES 1024                                      // step counters of the groups + error word
+static bool lp_usable(int B, int H) {
+  return H == 256 && 8 * cdiv(B, 32) * 2 <= 256 && focr_get_tuning(FOCR_TUNE_LSTM_PERSISTENT) != 0 &&
+         cdiv(B, 32) * 2 + 1 <= LP_FLAG_BYTES / 4;
+}
+
 // ws (forward): bf16 elements: 2*2*4H*H (whh hi/lo) + 2*T*B*2H (h hi/lo)          -> bytes = 2 * that
 // ws (backward): bf16 elements: 2*2*H*4H (whh^T hi/lo) + 2*rows*8H (dgx hi/lo)
 extern "C" long focr_lstm_ws_bytes(int T, int B, int H, int backward) {
   long w = (long)2 * 2 * 4 * H * H;
   long s = backward ? (long)2 * T * B * 8 * H : (long)2 * T * B * 2 * H;
-  return 2 * (w + s);
+  return 2 * (w + s) + LP_FLAG_BYTES;          // + the step counters of the persistent kernels (at the end)
 }
 
 int focr_lstm_fwd_bx3(const float* gx, const float* whh, const float* bhh, float* hseq, float* gates, float* cseq,
@@ -592,6 +846,21 @@ int focr_lstm_fwd_bx3(const float* gx, const float* whh, const float* bhh, float
   long nw = (long)2 * 4 * H * H;
   __bf16* hseq2 = whh2 + 2 * nw;
   hipLaunchKernelGGL(split_bf16_kernel, dim3(512), 256, 0, stream, whh, whh2, nw, 1, 1, 0);
+  if (lp_usable(B, H)) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)lstm_fwd_persist_bx3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                LP_FWD_LDS);
+      attr = true;
+    }
+    unsigned* flags = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + focr_lstm_ws_bytes(T, B, H, 0) -
+                                                  LP_FLAG_BYTES);
+    (void)hipMemsetAsync(flags, 0, LP_FLAG_BYTES, stream);
+    const int ngroups = cdiv(B, 32) * 2;
+    hipLaunchKernelGGL(lstm_fwd_persist_bx3_kernel, dim3(8 * ngroups), 512, LP_FWD_LDS, stream, gx,
+                       (const __bf16*)whh2, bhh, hseq, hseq2, gates, cseq, flags, T, B, st_t, st_b, ngroups);
+    return 0;
+  }
   dim3 grid(H / 32, (B + 31) / 32, 2);
   for (int s = 0; s < T; ++s)
     hipLaunchKernelGGL(lstm_fwd_step_bx3_kernel, grid, 1024, 0, stream, gx, (const __bf16*)whh2, bhh, hseq, hseq2, gates,
@@ -606,6 +875,21 @@ int focr_lstm_bwd_bx3(const float* dhseq, const float* whh, const float* gates, 
   long ndg = (long)T * B * 8 * H;
   // whh [2][4H][H] -> whhT [2][H][4H] (hi plane then lo plane)
   hipLaunchKernelGGL(split_bf16_kernel, dim3(512), 256, 0, stream, whh, whhT2, nw, 4 * H, H, 1);
+  if (lp_usable(B, H)) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)lstm_bwd_persist_bx3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                LP_BWD_LDS);
+      attr = true;
+    }
+    unsigned* flags = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + focr_lstm_ws_bytes(T, B, H, 1) -
+                                                  LP_FLAG_BYTES);
+    (void)hipMemsetAsync(flags, 0, LP_FLAG_BYTES, stream);
+    const int ngroups = cdiv(B, 32) * 2;
+    hipLaunchKernelGGL(lstm_bwd_persist_bx3_kernel, dim3(8 * ngroups), 512, LP_BWD_LDS, stream, dhseq,
+                       (const __bf16*)whhT2, gates, cseq, dgx, dgx2, flags, T, B, st_t, st_b, ndg, ngroups);
+    return 0;
+  }
   dim3 grid(H / 32, (B + 31) / 32, 2);
   for (int s = 0; s < T; ++s)
     hipLaunchKernelGGL(lstm_bwd_step_bx3_kernel, grid, 1024, 0, stream, dhseq, (const __bf16*)whhT2, gates, cseq, dgx,

@@ -567,6 +567,33 @@ def test_lstm(b, precision):
     close(xb.grad.transpose(0, 1), x.grad, ptol(precision), what="lstm dx (batch-major rows)")
 
 
+@pytest.mark.parametrize("b", [128, 70])
+def test_lstm_persistent_scan_equals_per_step_launches(b):
+    """rnn.hip persistent kernels (one launch walks all T steps; the 8 blocks that share a sequence block meet at a
+    global counter every step) against the per-step launches of the same arithmetic: forward h and the data gradient
+    agree to rounding (the K reduction is folded 2-way instead of 4-way), run twice = bit-identical (deterministic)"""
+    from fudanocr_amd import _lib
+    k = K()
+    t, hid = 26, 256
+    gx0 = dev(rnd(t * b, 8 * hid, seed=1, scale=0.5))
+    whh = dev(rnd(2, 4 * hid, hid, seed=2, scale=1 / 16))
+    bhh = dev(rnd(2, 4 * hid, seed=3, scale=0.1))
+    gy = dev(rnd(t, b, 2 * hid, seed=4))
+    outs = []
+    for persistent in (0, 1, 1):
+        _lib.call("focr_set_tuning", 2, persistent)
+        try:
+            gx = gx0.clone().requires_grad_(True)
+            y = k.lstm_recurrence(gx, whh, bhh, t, b, b, 1)
+            y.backward(gy)
+            outs.append((y.detach().cpu(), gx.grad.cpu()))
+        finally:
+            _lib.call("focr_set_tuning", 2, 1)
+    close(outs[1][0], outs[0][0], 1e-5, what="persistent lstm fwd")
+    close(outs[1][1], outs[0][1], 1e-5, what="persistent lstm bwd")
+    assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])
+
+
 def test_ctc():
     from oracle import sr_oracle as O
     t, c = 26, 37
