@@ -742,6 +742,15 @@ extern "C" int focr_bn_bwd(const float* dz, const float* x, const float* gamma, 
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), 256, 0, stream, dz, x, gamma, beta, mean,
                        invstd, (const float*)dbeta, (const float*)dgamma, dx, total4, rows, C, act);
   } else {
+    if (dgamma && dbeta && ws) {        // eval-mode statistics, trainable affine: the same two sums, no mean terms in dx
+      const int slabs = bwd_slabs(rows);
+      float* pg = ws;
+      float* pgx = ws + (size_t)slabs * C;
+      dim3 g(cdiv(C, 1024), slabs);
+      hipLaunchKernelGGL(bn_bwd_reduce_kernel, g, 256, 0, stream, dz, x, gamma, beta, mean, invstd, pg, pgx, rows, C, act);
+      hipLaunchKernelGGL(bn_fold2_kernel, dim3(C / 4, 2), 256, 0, stream, (const float*)pg, dbeta, (const float*)pgx,
+                         dgamma, slabs, C);
+    }
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), 256, 0, stream, dz, x, gamma, beta, mean,
                        invstd, (const float*)nullptr, (const float*)nullptr, dx, total4, rows, C, act);
   }

@@ -597,6 +597,15 @@ class _BatchNormAct(torch.autograd.Function):
                       _p(db), _p(ws), rows, c, act, 1, _stream())
             dg = None if tg is not None else dg
             db = None if tb is not None else db
+        elif ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:       # eval statistics, trainable affine parameters
+            tg, tb = ctx.targets
+            dg = tg if tg is not None else torch.empty(c, device=x.device)
+            db = tb if tb is not None else torch.empty(c, device=x.device)
+            ws = torch.empty(_lib.load().focr_bn_bwd_ws_floats(rows, c), device=x.device)
+            _lib.call("focr_bn_bwd", _p(dz), _p(x), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(dx), _p(dg),
+                      _p(db), _p(ws), rows, c, act, 0, _stream())
+            dg = None if tg is not None else dg
+            db = None if tb is not None else db
         else:
             _lib.call("focr_bn_bwd", _p(dz), _p(x), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(dx), _NULL,
                       _NULL, _NULL, rows, c, act, 0, _stream())
@@ -1067,7 +1076,9 @@ def bicubic_gray(x, ow=100):
 # ----------------------------------------------------------------------------------------
 class _LSTMRecur(torch.autograd.Function):
     """gx: [rows, 2*4H] with row(t,b) = t*st_t + b*st_b;  returns hseq [T,B,2H].
-    Gradient flows to gx only (recurrent weights of the frozen recognizer get no gradient)."""
+    Gradients: gx always; W_hh / b_hh when they require one (trainable recognizer):
+    dW_hh[d] = sum_t dgates_t[d]^T h_{t -/+ 1}[d] as ONE strided GEMM per direction over the (T-1) B row pairs,
+    db_hh = column sums of the gate gradients."""
 
     @staticmethod
     def forward(ctx, gx, whh, bhh, t_len, batch, st_t, st_b):
@@ -1080,12 +1091,12 @@ class _LSTMRecur(torch.autograd.Function):
         _lib.call("focr_lstm_bidir_fwd", _p(gx), _p(whh), _p(bhh), _p(hseq), _p(gates), _p(cseq), _p(ws), t_len,
                   batch, hid, st_t, st_b, _stream())
         ctx.cfg = (t_len, batch, hid, st_t, st_b, tuple(gx.shape))
-        ctx.save_for_backward(whh, gates, cseq)
+        ctx.save_for_backward(whh, gates, cseq, hseq if (whh.requires_grad or bhh.requires_grad) else None)
         return hseq
 
     @staticmethod
     def backward(ctx, dh):
-        whh, gates, cseq = ctx.saved_tensors
+        whh, gates, cseq, hseq = ctx.saved_tensors
         t_len, batch, hid, st_t, st_b, gshape = ctx.cfg
         dh = dh.contiguous()
         dgx = torch.empty(gshape, device=dh.device)
@@ -1093,7 +1104,28 @@ class _LSTMRecur(torch.autograd.Function):
         ws = torch.empty(_lib.load().focr_lstm_ws_bytes(t_len, batch, hid, 1), device=dh.device, dtype=torch.uint8)
         _lib.call("focr_lstm_bidir_bwd", _p(dh), _p(whh), _p(gates), _p(cseq), _p(dgx), _p(carry), _p(ws), t_len,
                   batch, hid, st_t, st_b, _stream())
-        return dgx, None, None, None, None, None, None
+        dwhh = dbhh = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            rows = t_len * batch
+            # gate gradients in the row order of hseq (t-major); the CRNN's first layer addresses them batch-major
+            dg = dgx if (st_t == batch and st_b == 1) else \
+                dgx.view(batch, t_len, 8 * hid).transpose(0, 1).contiguous().view(rows, 8 * hid)
+            if ctx.needs_input_grad[2]:
+                dbhh = torch.empty((2, 4 * hid), device=dh.device)
+                _lib.call("focr_colsum", _p(dg), _p(dbhh), rows, 8 * hid, 8 * hid, _stream())
+            if ctx.needs_input_grad[1]:
+                dwhh = torch.zeros((2, 4 * hid, hid), device=dh.device)
+                if t_len > 1:
+                    m = (t_len - 1) * batch
+                    nws = _lib.load().focr_conv2d_wgrad_ws_floats(m, 1, 1, hid, 4 * hid, 1, 1, 0, 0)
+                    wsw = torch.empty(max(nws, 1), device=dh.device)
+                    # forward direction: rows t = 1.. pair with h of t - 1;  reverse: rows t = ..T-2 with h of t + 1
+                    _lib.call("focr_conv2d_wgrad", _po(hseq, 0), _po(dg, batch * 8 * hid), _po(dwhh, 0), _NULL, m, 1,
+                              1, hid, 4 * hid, 1, 1, 0, 0, 8 * hid, 2 * hid, 1, _p(wsw), nws, _stream())
+                    _lib.call("focr_conv2d_wgrad", _po(hseq, batch * 2 * hid + hid), _po(dg, 4 * hid),
+                              _po(dwhh, 4 * hid * hid), _NULL, m, 1, 1, hid, 4 * hid, 1, 1, 0, 0, 8 * hid, 2 * hid, 1,
+                              _p(wsw), nws, _stream())
+        return dgx, dwhh, dbhh, None, None, None, None
 
 
 def lstm_recurrence(gx, whh, bhh, t_len, batch, st_t, st_b):

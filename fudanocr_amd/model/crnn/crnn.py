@@ -1,7 +1,9 @@
 """CRNN recognizer on HIP kernels; same classes / state_dict keys as the reference
 (scene-text-telescope/model/crnn/crnn.py:6-80).  Input NCHW [B, nc, 32, 100], output logits
-[T=26, B, nclass].  The recognizer is used frozen (eval-mode BN, no weight gradients) exactly as
-the reference uses it (interfaces/super_resolution.py:168-171); gradients flow to its input."""
+[T=26, B, nclass].  The training step uses the recognizer frozen (eval-mode BN, no weight gradients) exactly as
+the reference does (interfaces/super_resolution.py:168-171): gradients flow to its input.  With requires_grad left on
+it trains like any other module (convolution / BatchNorm / Linear weight gradients as everywhere, LSTM weight
+gradients from kernels._LSTMRecur)."""
 import torch
 from torch import nn
 
@@ -37,9 +39,16 @@ class BidirectionalLSTM(nn.Module):
             t_len, batch = input.shape[0], input.shape[1]
             st_t, st_b = batch, 1
             input = input.reshape(t_len * batch, -1)
-        if any(p.requires_grad for p in self.rnn.parameters()):
-            raise RuntimeError("training the recognizer's LSTM weights is not built yet (frozen CRNN only)")
-        wih, whh, bih, bhh = self._pack()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.rnn.parameters()):
+            # trainable recognizer (optimise the CRNN together with the SR net): pack through autograd so
+            # the gradients of the packed operands flow back to the eight nn.LSTM parameters
+            r = self.rnn
+            wih = torch.cat([r.weight_ih_l0, r.weight_ih_l0_reverse], 0)
+            whh = torch.stack([r.weight_hh_l0, r.weight_hh_l0_reverse], 0)
+            bih = torch.cat([r.bias_ih_l0, r.bias_ih_l0_reverse], 0)
+            bhh = torch.stack([r.bias_hh_l0, r.bias_hh_l0_reverse], 0)
+        else:
+            wih, whh, bih, bhh = self._pack()
         gx = K.linear(input, wih, bih)
         rec = K.lstm_recurrence(gx, whh, bhh, t_len, batch, st_t, st_b)     # [T,B,2H]
         out = self.embedding(rec.view(t_len * batch, -1))

@@ -162,7 +162,9 @@ int focr_bn_eval_fwd(const float* x, const float* gamma, const float* beta, cons
 int focr_bn_bwd(const float* dz, const float* x, const float* gamma, const float* beta, const float* mean,
                 const float* invstd, float* dx, float* dgamma, float* dbeta, float* ws, long rows, int C,
                 int act, int train, focr_stream_t stream);
-long focr_bn_bwd_ws_floats(long rows, int C); /* workspace size (floats) of focr_bn_bwd (train) */
+/* train = 0 (statistics were the running ones): dx = gamma * invstd * act'(.) dz; dgamma / dbeta / ws may be null
+ * (frozen layer) or all given (trainable affine parameters under eval statistics). */
+long focr_bn_bwd_ws_floats(long rows, int C); /* workspace size (floats) of focr_bn_bwd */
 
 /* ---- the reference's own LayerNorm (unbiased std, eps on std): model/tbsrn.py:23-36 ---------- */
 int focr_layernorm_fwd(const float* x, const float* residual, const float* a, const float* b, float* y,

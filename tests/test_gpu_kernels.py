@@ -565,6 +565,27 @@ def test_lstm(b, precision):
     close(yb, y, ptol(precision, 5e-5), what="lstm fwd (batch-major rows)")
     yb.backward(dev(gy))
     close(xb.grad.transpose(0, 1), x.grad, ptol(precision), what="lstm dx (batch-major rows)")
+    # trainable recognizer: recurrent weight / bias gradients (both row layouts), input projection through `linear`
+    for P_ in P.values():
+        P_.requires_grad_(True)
+    x2 = rnd(t, b, nin, seed=9)
+    y2 = O.lstm_bidir(P, "", x2)
+    y2.backward(gy)
+    ref_dwhh = torch.stack([P["weight_hh_l0"].grad, P["weight_hh_l0_reverse"].grad], 0)
+    ref_dbhh = torch.stack([P["bias_hh_l0"].grad, P["bias_hh_l0_reverse"].grad], 0)
+    ref_dwih = torch.cat([P["weight_ih_l0"].grad, P["weight_ih_l0_reverse"].grad], 0)
+    for layout in ("seq", "batch"):
+        wih_t, whh_t, bhh_t = (w.clone().requires_grad_(True) for w in (wih, whh, bhh))
+        if layout == "seq":
+            gx = k.linear(dev(x2).view(t * b, nin), wih_t, bih)
+            yt = k.lstm_recurrence(gx, whh_t, bhh_t, t, b, b, 1)
+        else:
+            gx = k.linear(dev(x2.transpose(0, 1)).reshape(b * t, nin), wih_t, bih)
+            yt = k.lstm_recurrence(gx, whh_t, bhh_t, t, b, 1, t)
+        yt.backward(dev(gy))
+        close(whh_t.grad, ref_dwhh, ptol(precision, 5e-5), what="lstm dW_hh (%s rows)" % layout)
+        close(bhh_t.grad, ref_dbhh, ptol(precision, 5e-5), what="lstm db_hh (%s rows)" % layout)
+        close(wih_t.grad, ref_dwih, ptol(precision, 5e-5), what="lstm dW_ih (%s rows)" % layout)
 
 
 @pytest.mark.parametrize("b", [128, 70])

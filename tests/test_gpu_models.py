@@ -149,6 +149,42 @@ def test_crnn_leg_golden(golden_dir):
     assert rel_to_max(logits, g["logits"]) < 1e-3
 
 
+def test_crnn_trainable_weight_gradients():
+    """the recognizer with requires_grad left on (SURVEY 3.3 'switch to train them'): every parameter gradient of
+    CTC(CRNN(gray)) -- convolutions, eval-mode BatchNorm affine, both BiLSTM layers (W_ih, W_hh, b_ih, b_hh of both
+    directions), the two embeddings -- against torch autograd on the functional oracle with the same weights"""
+    from oracle import sr_oracle as O
+    from fudanocr_amd import kernels as K
+    from fudanocr_amd.loss.ctc_focus_loss import CTCFocusLoss
+    from fudanocr_amd.model.crnn import crnn
+    from fudanocr_amd.utils.weight_fill import fill_dict_, fill_module_
+    rec = fill_module_(crnn.CRNN(32, 1, 37, 256)).cuda().eval()            # eval: BatchNorm uses its running statistics
+    P = fill_dict_(O.make_params(O.schema_crnn(), requires_grad=False))
+    for k, v in P.items():
+        if not O.is_buffer(k):
+            v.requires_grad_(True)
+    img = torch.rand(4, 3, 32, 128, generator=torch.Generator().manual_seed(78))
+    labels = ["ab1", "hello", "zz", "0123456"]
+    tg, tl = O.encode_labels(labels)
+    ref_loss = O.ctc_from_logits(O.crnn_forward(P, O.parse_crnn_data(img), training=False), tg, tl)
+    ref_loss.backward()
+    crit = CTCFocusLoss(rec)
+    logits = rec(K.bicubic_gray(img.cuda(), 100))
+    enc = crit.encode(labels, logits.device)
+    loss = K.ctc_loss(logits, enc[0], enc[1])
+    assert abs(loss.item() - ref_loss.item()) < 1e-3 * abs(ref_loss.item())
+    loss.backward()
+    bad = []
+    for k, p_ in rec.named_parameters():
+        ref = P[k].grad
+        assert p_.grad is not None, k
+        err = rel_to_max(p_.grad, ref)
+        if not err < 2e-2:
+            bad.append((k, err))
+    assert not bad, bad
+    assert sum(1 for k, _ in rec.named_parameters() if ".rnn.weight_hh" in k) == 4
+
+
 @pytest.mark.parametrize("arch", ["tbsrn", "tsrn"])
 def test_e2e_ctc_golden(arch, golden_dir, prec_mode):
     skip_dup(arch, prec_mode)
