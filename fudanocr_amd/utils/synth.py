@@ -23,3 +23,13 @@ def make_batch(batch, seed=1234, in_planes=3, height=16, width=64, scale=2):
         idx = torch.randint(0, len(ALPHABET), (n,), generator=g).tolist()
         labels.append("".join(ALPHABET[i] for i in idx))
     return lr, hr, labels
+
+
+def with_mask(img):
+    """append the `--mask` channel to an RGB batch the way the reference's resizeNormalize(mask=True) derives it from
+    the image (dataset/dataset.py:146-151): luma, threshold at the image's mean luma, 1.0 where NOT brighter.
+    (Exact-in-fp32 integer luma, so every host builds the identical 4-channel synthetic batch.)"""
+    u8 = torch.floor(img * 255 + 0.5)
+    luma = torch.floor((u8[:, 0] * 299 + u8[:, 1] * 587 + u8[:, 2] * 114 + 500) / 1000)
+    thr = luma.mean(dim=(1, 2), keepdim=True)
+    return torch.cat([img, (luma <= thr).to(img.dtype).unsqueeze(1)], 1)

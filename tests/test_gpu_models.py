@@ -22,6 +22,15 @@ def rel_to_max(got, ref):
     return ((got - ref).abs().max() / ref.abs().max()).item()
 
 
+def rel_q(got, ref, q=0.98):
+    """q-quantile of |got - ref| over max |ref| (for gradients that pass through max-pool / bilinear-cell decisions on
+    inputs with exact ties, e.g. the binary mask channel: a tie decided by the last bit moves the gradient of one
+    receptive field; the quantile bounds everything else tightly, rel_to_max bounds the patches loosely)"""
+    got = torch.as_tensor(np.asarray(got.detach().cpu() if torch.is_tensor(got) else got)).double()
+    ref = torch.as_tensor(np.asarray(ref)).double()
+    return (torch.quantile((got - ref).abs().flatten(), q) / ref.abs().max()).item()
+
+
 def build(arch="tbsrn"):
     from fudanocr_amd.smoke import build_models
     return build_models(torch.device("cuda:0"), arch)
@@ -147,6 +156,78 @@ def test_crnn_leg_golden(golden_dir):
     with torch.no_grad():
         logits = rec(gray)
     assert rel_to_max(logits, g["logits"]) < 1e-3
+
+
+@pytest.mark.parametrize("arch", ["tbsrn", "tsrn"])
+def test_mask_variant_golden(arch, golden_dir):
+    """--mask (in_planes = 4, reference main.py:31; the 9x9 layers with 4 channels run on the generic kernels): schema,
+    train-mode forward + MSE backward and eval forward against the reference built with mask=True"""
+    from fudanocr_amd import kernels as K
+    from fudanocr_amd.model import tbsrn, tsrn
+    from fudanocr_amd.utils.synth import with_mask
+    from fudanocr_amd.utils.weight_fill import fill_module_
+    g = np.load(os.path.join(golden_dir, "%s_mask_train_mse.npz" % arch))
+    gn = json.load(open(os.path.join(golden_dir, "%s_mask_gradnorms.json" % arch)))
+    schema = json.load(open(os.path.join(golden_dir, "mask_schema.json")))[arch]
+    mod = tbsrn.TBSRN if arch == "tbsrn" else tsrn.TSRN
+    net = fill_module_(mod(STN=True, mask=True))
+    assert [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in net.state_dict().items()] == schema
+    net = net.cuda().train()
+    eval_dropout(net)
+    lr, hr, _ = make_batch(4, 1234)
+    lr4, hr4 = with_mask(lr), with_mask(hr)
+    x = lr4.cuda().requires_grad_(True)
+    sr = net(x)
+    mse = K.mse_loss(sr, hr4.cuda())
+    (mse * 100).backward()
+    assert sr.shape == (4, 4, 32, 128) and rel_to_max(sr, g["sr"]) < 1e-3
+    assert abs(mse.item() - float(g["mse"])) < 1e-3 * float(g["mse"])
+    # d loss / d LR goes through the STN head's max-pools and the TPS bilinear cells; the binary mask channel puts exact
+    # ties in front of both
+    assert rel_q(x.grad[:, :, ::2, ::4], g["dlr_sub"]) < 2e-2 and rel_to_max(x.grad[:, :, ::2, ::4], g["dlr_sub"]) < 0.15
+    P = dict(net.named_parameters())
+    assert rel_to_max(P["block1.0.weight"].grad, g["g_block1_w"]) < 2e-2
+    assert rel_to_max(P["block8.1.weight"].grad[:, ::8], g["g_block8_w_sub"]) < 2e-2
+    assert rel_to_max(P["block8.1.bias"].grad, g["g_block8_b"]) < 2e-2
+    top = max(v for v in gn.values() if v is not None)
+    bad = [(k, float(P[k].grad.norm()), v) for k, v in gn.items()
+           if v is not None and not abs(float(P[k].grad.norm()) - v) <= 2e-2 * v + 1e-4 * top]
+    assert not bad, bad[:10]
+    net2 = fill_module_(mod(STN=True, mask=True)).cuda().eval()
+    with torch.no_grad():
+        assert rel_to_max(net2(lr4.cuda()), np.load(os.path.join(golden_dir, "%s_mask_eval.npz" % arch))["sr"]) < 1e-3
+
+
+def test_feature_enhancer_block_golden(golden_dir, prec_mode):
+    """one FeatureEnhancer block in isolation (packed QKV projection, fused attention, std-LayerNorm with
+    deferred residual gradients, FFN, 128 -> 64 linear) against the reference block: tokens, d/d feature map, every
+    parameter-gradient norm.  Product layout is channel-last [B, 1024, 64]; the reference's is [B, 64, 1024]."""
+    from fudanocr_amd.model.tbsrn import FeatureEnhancer
+    from fudanocr_amd.utils.weight_fill import fill_module_
+    g = np.load(os.path.join(golden_dir, "feature_enhancer_block.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "feature_enhancer_block.json")))
+    fe = fill_module_(FeatureEnhancer())
+    assert [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in fe.state_dict().items()] == meta["schema"]
+    fe = fe.cuda().train()
+    eval_dropout(fe)
+    gen = torch.Generator().manual_seed(4242)
+    feat = (torch.randint(0, 1 << 16, (4, 64, 1024), generator=gen).float() / float(1 << 16) - 0.5) * 2.0
+    go = None
+    x = feat.transpose(1, 2).contiguous().cuda().requires_grad_(True)
+    out = fe(x)
+    go = torch.randint(0, 1 << 16, (4, 64, 1024), generator=gen).float() / float(1 << 16) - 0.5
+    out.backward(go.transpose(1, 2).contiguous().cuda())
+    from fudanocr_amd import kernels as K
+    K.check_deferred()
+    assert rel_to_max(out.transpose(1, 2)[:, ::2, ::4], g["out_sub"]) < 1e-3
+    assert rel_to_max(x.grad.transpose(1, 2)[:, ::4, ::8], g["dfeat_sub"]) < 2e-2
+    P = dict(fe.named_parameters())
+    # (the key-projection bias has a mathematically zero gradient -- softmax is invariant to a per-query constant --
+    # so both sides hold rounding noise there: absolute floor relative to the largest norm, as in the model tests)
+    top = max(v for v in meta["gradnorms"].values() if v is not None)
+    bad = [(k, float(P[k].grad.norm()), v) for k, v in meta["gradnorms"].items()
+           if v is not None and not abs(float(P[k].grad.norm()) - v) <= 2e-2 * v + 1e-4 * top]
+    assert not bad, bad
 
 
 def test_crnn_trainable_weight_gradients():
