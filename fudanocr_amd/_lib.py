@@ -87,6 +87,11 @@ SIGNATURES = {
     "focr_weight_cross_entropy_fwd": [P, P, P, P, P, P, L, I, P],
     "focr_set_precision": [I],
     "focr_set_tuning": [I, I],
+    "focr_comm_unique_id": [P],
+    "focr_comm_init": [I, I, P],
+    "focr_allreduce_async": [P, L, I, P],
+    "focr_comm_nranks": [],
+    "focr_comm_destroy": [],
     "focr_get_tuning": [I],
     "focr_get_precision": [],
     "focr_clip_adam": [P, P, P, P, P, L, F, F, F, F, I, F, F, P],

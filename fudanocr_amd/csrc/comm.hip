@@ -1,0 +1,93 @@
+// Data-parallel gradient exchange behind the C ABI (focr_comm_init / focr_allreduce_async /
+// focr_comm_destroy): one RCCL communicator per process (= per GPU), in-place sum all-reduce of a gradient range on a
+// caller-chosen stream.  This replaces what nn.DataParallel's replicate / scatter / gather does for the gradients
+// (reference interfaces/base.py:178-179) and is the same call torch.distributed's "nccl" backend ends in; the engine
+// uses torch.distributed by default and this entry when FOCR_COMM=native.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1): a process that already holds RCCL (PyTorch loads its own copy)
+// gets THAT instance back, and the library has no link-time dependency on it -- single-GPU users never load it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include "focr_common.h"
+
+namespace {
+struct Rccl {
+  void* h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+} g_rccl;
+ncclComm_t g_comm = nullptr;
+int g_nranks = 0;
+
+int load_rccl() {
+  if (g_rccl.h) return FOCR_OK;
+  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!h) {
+    focr_set_error("focr_comm: cannot load librccl.so (%s)", dlerror());
+    return FOCR_EUNSUPPORTED;
+  }
+  g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+  g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+  g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(h, "ncclAllReduce"));
+  g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+  g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
+    focr_set_error("focr_comm: librccl.so lacks an expected symbol");
+    dlclose(h);
+    return FOCR_EUNSUPPORTED;
+  }
+  g_rccl.h = h;
+  return FOCR_OK;
+}
+int check(ncclResult_t r, const char* what) {
+  if (r == ncclSuccess) return FOCR_OK;
+  focr_set_error("focr_comm: %s failed: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "rccl error");
+  return FOCR_EHIP;
+}
+}  // namespace
+
+// rank 0 draws the id (FOCR_COMM_ID_BYTES = sizeof(ncclUniqueId) = 128 bytes) and hands it to the other ranks by any
+// host channel (the engine broadcasts it through the process group's store)
+extern "C" int focr_comm_unique_id(void* id_out) {
+  FOCR_CHECK_ARG(id_out, "null pointer");
+  int rc = load_rccl();
+  if (rc != FOCR_OK) return rc;
+  return check(g_rccl.GetUniqueId(reinterpret_cast<ncclUniqueId*>(id_out)), "ncclGetUniqueId");
+}
+// collective over all ranks; the calling thread's current HIP device is the rank's GPU
+extern "C" int focr_comm_init(int rank, int nranks, const void* unique_id) {
+  FOCR_CHECK_ARG(unique_id && nranks >= 1 && rank >= 0 && rank < nranks, "bad argument");
+  if (g_comm) {
+    focr_set_error("focr_comm_init: a communicator already exists (focr_comm_destroy first)");
+    return FOCR_EINVAL;
+  }
+  int rc = load_rccl();
+  if (rc != FOCR_OK) return rc;
+  ncclUniqueId id;
+  memcpy(&id, unique_id, sizeof(id));
+  rc = check(g_rccl.CommInitRank(&g_comm, nranks, id, rank), "ncclCommInitRank");
+  if (rc == FOCR_OK) g_nranks = nranks;
+  return rc;
+}
+// buf[0..n) <- sum over ranks, in place, asynchronous on `stream`.  dtype: 0 = fp32 (the gradient buffers).
+extern "C" int focr_allreduce_async(void* buf, size_t n, int dtype, hipStream_t stream) {
+  FOCR_CHECK_ARG(buf && n > 0, "bad argument");
+  FOCR_CHECK_ARG(dtype == 0, "only fp32 (dtype 0) gradient buffers are exchanged");
+  if (!g_comm) {
+    focr_set_error("focr_allreduce_async: no communicator (focr_comm_init first)");
+    return FOCR_EINVAL;
+  }
+  return check(g_rccl.AllReduce(buf, buf, n, ncclFloat32, ncclSum, g_comm, stream), "ncclAllReduce");
+}
+extern "C" int focr_comm_nranks(void) { return g_comm ? g_nranks : 0; }
+extern "C" int focr_comm_destroy(void) {
+  if (!g_comm) return FOCR_OK;
+  int rc = check(g_rccl.CommDestroy(g_comm), "ncclCommDestroy");
+  g_comm = nullptr;
+  g_nranks = 0;
+  return rc;
+}

@@ -13,6 +13,9 @@ restated for one process per GPU.
 * clip + Adam: two HIP kernels over the flat buffers, clip coefficient computed on the device,
   no host synchronisation in the step.
 """
+import ctypes
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -151,6 +154,21 @@ class TrainStep:
             # one broadcast they stay bit-identical without any per-step parameter traffic
             dist.broadcast(self.flat.flat_param, src=dist.get_global_rank(process_group, 0) if process_group else 0,
                            group=process_group)
+        # FOCR_COMM=native: the gradient ranges go through the library's own RCCL communicator (include/focr.h
+        # focr_comm_init / focr_allreduce_async) instead of torch.distributed's; the process group is then only the host
+        # channel for the 128-byte unique id and the initial parameter broadcast
+        self.native_comm = False
+        if self.world > 1 and os.environ.get("FOCR_COMM", "") == "native" and self.flat.flat_grad.is_cuda:
+            from . import _lib
+            ident = [None]
+            if dist.get_rank(process_group) == 0:
+                buf = ctypes.create_string_buffer(128)
+                _lib.call("focr_comm_unique_id", buf)
+                ident[0] = bytes(buf.raw)
+            dist.broadcast_object_list(ident, src=dist.get_global_rank(process_group, 0) if process_group else 0,
+                                       group=process_group)
+            _lib.call("focr_comm_init", dist.get_rank(process_group), self.world, ctypes.c_char_p(ident[0]))
+            self.native_comm = True
         n = self.flat.numel
         edges = [n * i // n_buckets // 4 * 4 for i in range(n_buckets)] + [n]
         self.buckets = [(edges[i], edges[i + 1]) for i in range(n_buckets) if edges[i + 1] > edges[i]]
@@ -226,7 +244,12 @@ class TrainStep:
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
                 self.ctx.join_side_stream(self.comm_stream)    # ... once the side-stream weight gradients are in too
-                self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                if self.native_comm:
+                    from . import _lib
+                    _lib.call("focr_allreduce_async", ctypes.c_void_p(view.data_ptr()), view.numel(), 0,
+                              ctypes.c_void_p(self.comm_stream.cuda_stream))
+                else:
+                    self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         else:
             self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
@@ -246,6 +269,8 @@ class TrainStep:
                 self._launch((a, min(hi, a + step)))
         for w in self._works:
             w.wait()
+        if self.native_comm:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
         self._works, self._sent = [], []
 
     def __call__(self, images_lr, images_hr, label_strs=None, encoded=None):

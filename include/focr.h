@@ -313,6 +313,19 @@ int focr_l1_bwd(const float* a, const float* b, const float* g, float* db, long 
 int focr_weight_cross_entropy_fwd(const float* logits, const long long* target, const float* table, float* loss,
                                   float* nll_ws, float* grad, long rows, int C, focr_stream_t stream);
 
+/* ---- data-parallel gradient exchange (RCCL over xGMI; replaces nn.DataParallel's gather of the gradients,
+ * reference interfaces/base.py:178-179).  One communicator per process = per GPU.  RCCL is bound at run time.
+ * focr_comm_unique_id: rank 0 draws the 128-byte id (sizeof(ncclUniqueId)) and gives it to every rank by a host channel;
+ * focr_comm_init: collective, on the thread whose current device is the rank's GPU;
+ * focr_allreduce_async: buf[0..n) <- sum over ranks, in place, on `stream` (dtype 0 = fp32);
+ * focr_comm_nranks: 0 when there is no communicator. */
+#define FOCR_COMM_ID_BYTES 128
+int focr_comm_unique_id(void* id_out);
+int focr_comm_init(int rank, int nranks, const void* unique_id);
+int focr_allreduce_async(void* buf, size_t n, int dtype, focr_stream_t stream);
+int focr_comm_nranks(void);
+int focr_comm_destroy(void);
+
 #ifdef __cplusplus
 }
 #endif

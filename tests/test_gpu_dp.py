@@ -170,3 +170,39 @@ def test_dp_selfcheck_tool(config):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
     line = [l for l in outs[0].splitlines() if l.startswith("{")]
     assert json.loads(line[-1])["dp_selfcheck"] == "ok"
+
+
+@pytest.mark.gpu
+def test_c_abi_rccl_communicator_single_rank():
+    """include/focr.h focr_comm_*: the library's own RCCL communicator (bound with dlopen).  One GPU can host one rank
+    only (RCCL refuses two ranks on a device), so this exercises the full call sequence at world size 1: unique id ->
+    init -> in-place sum all-reduce on a side stream (identity at one rank) -> destroy; plus the error paths."""
+    import ctypes
+    from fudanocr_amd import _lib
+    lib = _lib.load()
+    assert lib.focr_comm_nranks() == 0
+    x = torch.arange(1 << 20, device="cuda", dtype=torch.float32)
+    with pytest.raises(RuntimeError):                       # no communicator yet
+        _lib.call("focr_allreduce_async", ctypes.c_void_p(x.data_ptr()), x.numel(), 0, ctypes.c_void_p(0))
+    ident = ctypes.create_string_buffer(128)
+    _lib.call("focr_comm_unique_id", ident)
+    assert any(ident.raw)
+    _lib.call("focr_comm_init", 0, 1, ident)
+    try:
+        assert lib.focr_comm_nranks() == 1
+        with pytest.raises(RuntimeError):                   # a second communicator is refused
+            _lib.call("focr_comm_init", 0, 1, ident)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        ref = x.clone()
+        for _ in range(3):
+            _lib.call("focr_allreduce_async", ctypes.c_void_p(x.data_ptr()), x.numel(), 0,
+                      ctypes.c_void_p(side.cuda_stream))
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert torch.equal(x, ref)
+        with pytest.raises(RuntimeError):                   # only fp32 gradient buffers
+            _lib.call("focr_allreduce_async", ctypes.c_void_p(x.data_ptr()), x.numel(), 1, ctypes.c_void_p(0))
+    finally:
+        _lib.call("focr_comm_destroy")
+    assert lib.focr_comm_nranks() == 0
