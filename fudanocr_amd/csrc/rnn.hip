@@ -375,14 +375,237 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// bf16x3 variants (precision modes >= 1): the same wavefront scan with the recurrent product on the bf16 pipe.
+// The f32 32x32x2 MFMA costs 16 passes per 2 k: 48 of them per step (3072 cycles) dominate the scan.  With split
+// operands the step needs 3 gates x 2 k-steps x 3 products = 18 v_mfma_f32_32x32x16_bf16 (576 cycles).  The
+// "state never leaves the registers" identity survives because the ORDER of the contraction index is free: k-slot
+// (m, half, e) of the 16-wide fragment is defined as hidden unit u(8 m + e, half), which is exactly the unit held by
+// accumulator register 8 m + e of the lane half -- a lane's B fragment is its own eight accumulator values (split to
+// bf16 hi / lo in registers), and W_hh is laid out once per wave in the matching order.
+// One wave per block (64 threads): the 2 * nseq / 32 waves of a launch spread over as many CUs as possible.
+// ---------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 gbf16x8;
+__device__ __forceinline__ void g_split8(const float* v, gbf16x8& hi, gbf16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 h = (__bf16)v[e];
+    hi[e] = h;
+    lo[e] = (__bf16)(v[e] - (float)h);
+  }
+}
+#define G_MFMA3(acc, ah, al, bh, bl)                                        \
+  do {                                                                      \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);    \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);    \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);    \
+  } while (0)
+
+__global__ __launch_bounds__(64) void gru_fwd_bx3_kernel(const float* __restrict__ gx, const float* __restrict__ whh,
+                                                         const float* __restrict__ bhh, float* __restrict__ hseq,
+                                                         float* __restrict__ gates, int nseq, int T, int IC, int OS,
+                                                         int IS, int TS) {
+  const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  const int wid = blockIdx.x;
+  const int dir = wid & 1, grp = wid >> 1;
+  if (grp * 32 >= nseq) return;
+  const int seq = grp * 32 + li;
+  const bool valid = seq < nseq;
+  const int sc = valid ? seq : nseq - 1;
+  const long base_row = (long)(sc / IC) * OS + (long)(sc % IC) * IS;
+
+  gbf16x8 wah[3][2], wal[3][2];            // A[gate unit li][k-slot (m, lh, e)] = W_hh[g*32 + li][u(8m + e, lh)]
+  float4 bh[3][4];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = whh[((size_t)dir * 96 + g * 32 + li) * GH + unit_of(8 * m + e, lh)];
+      g_split8(v, wah[g][m], wal[g][m]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      bh[g][q] = *reinterpret_cast<const float4*>(bhh + (size_t)dir * 96 + g * 32 + 8 * q + 4 * lh);
+  }
+  float h[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) h[r] = 0.f;
+
+  for (int step = 0; step < T; ++step) {
+    const int t = dir ? T - 1 - step : step;
+    const long row = base_row + (long)t * TS;
+    const float* gxr = gx + (size_t)row * 192 + dir * 96;
+    float4 xg[3][4];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xg[g][q] = *reinterpret_cast<const float4*>(gxr + g * 32 + 8 * q + 4 * lh);
+    gbf16x8 hh[2], hl[2];
+    g_split8(h, hh[0], hl[0]);
+    g_split8(h + 8, hh[1], hl[1]);
+    f32x16 ar, az, an;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ar[r] = 0.f; az[r] = 0.f; an[r] = 0.f; }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      G_MFMA3(ar, wah[0][m], wal[0][m], hh[m], hl[m]);
+      G_MFMA3(az, wah[1][m], wal[1][m], hh[m], hl[m]);
+      G_MFMA3(an, wah[2][m], wal[2][m], hh[m], hl[m]);
+    }
+    float* grow = gates + ((size_t)row * 2 + dir) * 128;
+    float* hrow = hseq + (size_t)row * 64 + dir * 32;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float xr[4] = {xg[0][q].x, xg[0][q].y, xg[0][q].z, xg[0][q].w};
+      const float xz[4] = {xg[1][q].x, xg[1][q].y, xg[1][q].z, xg[1][q].w};
+      const float xn[4] = {xg[2][q].x, xg[2][q].y, xg[2][q].z, xg[2][q].w};
+      const float br[4] = {bh[0][q].x, bh[0][q].y, bh[0][q].z, bh[0][q].w};
+      const float bz[4] = {bh[1][q].x, bh[1][q].y, bh[1][q].z, bh[1][q].w};
+      const float bn[4] = {bh[2][q].x, bh[2][q].y, bh[2][q].z, bh[2][q].w};
+      float rr[4], zz[4], nn[4], hn[4], hv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int s = 4 * q + e;
+        rr[e] = fast_sigmoid(xr[e] + ar[s] + br[e]);
+        zz[e] = fast_sigmoid(xz[e] + az[s] + bz[e]);
+        hn[e] = an[s] + bn[e];
+        nn[e] = fast_tanh(xn[e] + rr[e] * hn[e]);
+        hv[e] = (1.f - zz[e]) * nn[e] + zz[e] * h[s];
+        h[s] = hv[e];
+      }
+      if (valid) {
+        const int u = 8 * q + 4 * lh;
+        *reinterpret_cast<float4*>(grow + u) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+        *reinterpret_cast<float4*>(grow + 32 + u) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+        *reinterpret_cast<float4*>(grow + 64 + u) = make_float4(nn[0], nn[1], nn[2], nn[3]);
+        *reinterpret_cast<float4*>(grow + 96 + u) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+        *reinterpret_cast<float4*>(hrow + u) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void gru_bwd_bx3_kernel(const float* __restrict__ dhseq, const float* __restrict__ whh,
+                                                         const float* __restrict__ gates,
+                                                         const float* __restrict__ hseq, float* __restrict__ dgx,
+                                                         float* __restrict__ dgh, float* __restrict__ hprev, int nseq,
+                                                         int T, int IC, int OS, int IS, int TS) {
+  const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  const int wid = blockIdx.x;
+  const int dir = wid & 1, grp = wid >> 1;
+  if (grp * 32 >= nseq) return;
+  const int seq = grp * 32 + li;
+  const bool valid = seq < nseq;
+  const int sc = valid ? seq : nseq - 1;
+  const long base_row = (long)(sc / IC) * OS + (long)(sc % IC) * IS;
+
+  // dh_prev^T[k][seq] = sum_j W_hh[j][k] dg[seq][j], j = (gate g, unit): A[k = li][k-slot (g, m, lh, e)] =
+  // W_hh[g*32 + u(8m + e, lh)][li]; the B fragment of (g, m) = this lane's gate-gradient registers 8m .. 8m + 7
+  gbf16x8 wth[3][2], wtl[3][2];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = whh[((size_t)dir * 96 + g * 32 + unit_of(8 * m + e, lh)) * GH + li];
+      g_split8(v, wth[g][m], wtl[g][m]);
+    }
+  float dh[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dh[r] = 0.f;
+
+  // operands of one step (24 float4): requested one step ahead, right before the MFMA chain of the current step
+  float4 ld[4][6];
+  auto request = [&](int step) {
+    const int t = dir ? step : T - 1 - step;
+    const bool has_prev = dir ? (t < T - 1) : (t > 0);
+    const long row = base_row + (long)t * TS;
+    const long prow = base_row + (long)(dir ? t + 1 : t - 1) * TS;
+    const float* grow = gates + ((size_t)row * 2 + dir) * 128;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int u = 8 * q + 4 * lh;
+      ld[q][0] = *reinterpret_cast<const float4*>(dhseq + (size_t)row * 64 + dir * 32 + u);
+      ld[q][1] = *reinterpret_cast<const float4*>(grow + u);
+      ld[q][2] = *reinterpret_cast<const float4*>(grow + 32 + u);
+      ld[q][3] = *reinterpret_cast<const float4*>(grow + 64 + u);
+      ld[q][4] = *reinterpret_cast<const float4*>(grow + 96 + u);
+      ld[q][5] = has_prev ? *reinterpret_cast<const float4*>(hseq + (size_t)prow * 64 + dir * 32 + u)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  request(0);
+  for (int step = 0; step < T; ++step) {
+    const int t = dir ? step : T - 1 - step;               // reverse of the forward order
+    const long row = base_row + (long)t * TS;
+    float dar[16], daz[16], dhn[16], dhp[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int u = 8 * q + 4 * lh;
+      const float4 g4 = ld[q][0], r4 = ld[q][1], z4 = ld[q][2], n4 = ld[q][3], h4 = ld[q][4], p4 = ld[q][5];
+      const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
+      const float zz[4] = {z4.x, z4.y, z4.z, z4.w}, nn[4] = {n4.x, n4.y, n4.z, n4.w};
+      const float hn[4] = {h4.x, h4.y, h4.z, h4.w}, hp[4] = {p4.x, p4.y, p4.z, p4.w};
+      float o_r[4], o_z[4], o_n[4], o_h[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int s = 4 * q + e;
+        const float dht = gg[e] + dh[s];
+        const float dn = dht * (1.f - zz[e]);
+        const float dz = dht * (hp[e] - nn[e]);
+        dhp[s] = dht * zz[e];
+        const float dan = dn * (1.f - nn[e] * nn[e]);
+        o_n[e] = dan;
+        o_r[e] = dan * hn[e] * rr[e] * (1.f - rr[e]);
+        o_h[e] = dan * rr[e];
+        o_z[e] = dz * zz[e] * (1.f - zz[e]);
+        dar[s] = o_r[e]; daz[s] = o_z[e]; dhn[s] = o_h[e];
+      }
+      if (valid) {
+        float* xo = dgx + (size_t)row * 192 + dir * 96;
+        float* ho = dgh + (size_t)row * 192 + dir * 96;
+        *reinterpret_cast<float4*>(xo + u) = make_float4(o_r[0], o_r[1], o_r[2], o_r[3]);
+        *reinterpret_cast<float4*>(xo + 32 + u) = make_float4(o_z[0], o_z[1], o_z[2], o_z[3]);
+        *reinterpret_cast<float4*>(xo + 64 + u) = make_float4(o_n[0], o_n[1], o_n[2], o_n[3]);
+        *reinterpret_cast<float4*>(ho + u) = make_float4(o_r[0], o_r[1], o_r[2], o_r[3]);
+        *reinterpret_cast<float4*>(ho + 32 + u) = make_float4(o_z[0], o_z[1], o_z[2], o_z[3]);
+        *reinterpret_cast<float4*>(ho + 64 + u) = make_float4(o_h[0], o_h[1], o_h[2], o_h[3]);
+        *reinterpret_cast<float4*>(hprev + ((size_t)row * 2 + dir) * 32 + u) = p4;
+      }
+    }
+    if (step + 1 < T) request(step + 1);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = dhp[r];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      gbf16x8 bh_, bl_;
+      g_split8(dar + 8 * m, bh_, bl_);
+      G_MFMA3(acc, wth[0][m], wtl[0][m], bh_, bl_);
+      g_split8(daz + 8 * m, bh_, bl_);
+      G_MFMA3(acc, wth[1][m], wtl[1][m], bh_, bl_);
+      g_split8(dhn + 8 * m, bh_, bl_);
+      G_MFMA3(acc, wth[2][m], wtl[2][m], bh_, bl_);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dh[r] = acc[r];
+  }
+}
+
 extern "C" int focr_gru_bidir_fwd(const float* gx, const float* whh, const float* bhh, float* hseq,
                                   float* gates, int nseq, int T, int IC, int OS, int IS, int TS,
                                   hipStream_t stream) {
   FOCR_CHECK_ARG(gx && whh && bhh && hseq && gates, "null pointer");
   FOCR_CHECK_ARG(nseq > 0 && T > 0 && IC > 0, "bad argument");
   int waves = cdiv(nseq, 32) * 2;
-  hipLaunchKernelGGL(gru_fwd_kernel, dim3(cdiv(waves, 4)), 256, 0, stream, gx, whh, bhh, hseq, gates, nseq, T, IC,
-                     OS, IS, TS);
+  if (focr_get_precision() != 0)
+    hipLaunchKernelGGL(gru_fwd_bx3_kernel, dim3(waves), 64, 0, stream, gx, whh, bhh, hseq, gates, nseq, T, IC, OS, IS, TS);
+  else
+    hipLaunchKernelGGL(gru_fwd_kernel, dim3(cdiv(waves, 4)), 256, 0, stream, gx, whh, bhh, hseq, gates, nseq, T, IC,
+                       OS, IS, TS);
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }
@@ -392,8 +615,12 @@ extern "C" int focr_gru_bidir_bwd(const float* dhseq, const float* whh, const fl
   FOCR_CHECK_ARG(dhseq && whh && gates && hseq && dgx && dgh && hprev, "null pointer");
   FOCR_CHECK_ARG(nseq > 0 && T > 0 && IC > 0, "bad argument");
   int waves = cdiv(nseq, 32) * 2;
-  hipLaunchKernelGGL(gru_bwd_kernel, dim3(cdiv(waves, 4)), 256, 0, stream, dhseq, whh, gates, hseq, dgx, dgh,
-                     hprev, nseq, T, IC, OS, IS, TS);
+  if (focr_get_precision() != 0)
+    hipLaunchKernelGGL(gru_bwd_bx3_kernel, dim3(waves), 64, 0, stream, dhseq, whh, gates, hseq, dgx, dgh, hprev, nseq, T,
+                       IC, OS, IS, TS);
+  else
+    hipLaunchKernelGGL(gru_bwd_kernel, dim3(cdiv(waves, 4)), 256, 0, stream, dhseq, whh, gates, hseq, dgx, dgh,
+                       hprev, nseq, T, IC, OS, IS, TS);
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }

@@ -45,6 +45,17 @@ def _qkv_adjacent_order(model):
                     out.append(by_name[g])
                     done.add(g)
                 continue
+        if name.endswith(".weight_ih_l0") and (name[:-len("weight_ih_l0")] + "weight_hh_l0_reverse") in by_name:
+            # bidirectional GRU / LSTM registry (TSRN GruBlock): forward and reverse tensors of each kind side by side,
+            # so [W_ih | W_ih_reverse], stacked W_hh and the biases are views of the flat buffers too
+            stem = name[:-len("weight_ih_l0")]
+            group = [stem + k + sfx for k in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")
+                     for sfx in ("", "_reverse")]
+            if all(g in by_name for g in group):
+                for g in group:
+                    out.append(by_name[g])
+                    done.add(g)
+                continue
         out.append(p)
         done.add(name)
     return out
@@ -138,6 +149,7 @@ class TrainStep:
         self.dropout = dropout        # False: nn.Dropout slots stay in eval (parity runs)
         self.flat = FlatBuffers(_qkv_adjacent_order(model))
         self._attach_packed_qkv()
+        self._attach_packed_gru()
         self.opt = FusedClipAdam(self.flat, lr, betas, 1e-8, max_norm)
         self.pg = process_group
         self.wgrad_side_stream = bool(wgrad_side_stream)
@@ -200,6 +212,32 @@ class TrainStep:
             w._focr_grad = self.flat.flat_grad[ow:ow + 3 * n].view(3 * rows, cols)
             b._focr_grad = self.flat.flat_grad[ob:ob + 3 * nb].view(3 * nb)
             m._packed_qkv = (w, b)
+
+    def _attach_packed_gru(self):
+        """TSRN GruBlock: the kernels want [W_ih | W_ih_reverse] (192 x 64), stacked W_hh (2 x 96 x 32) and the biases.
+        The reference-named nn.GRU parameters are laid out pairwise-adjacent in the flat buffers (_qkv_adjacent_order),
+        so the packed operands are views of the flat parameter buffer and their gradient targets views of the flat
+        gradient: no torch.cat / stack per forward, no slice-gradient accumulation kernels per backward (4 cats +
+        8 adds per GruBlock, 10 blocks per step)."""
+        off = {id(p): o for p, o in zip(self.flat.params, self.flat.offsets)}
+        for m in self.model.modules():
+            g = getattr(m, "gru", None)
+            if g is None or not hasattr(m, "_packed_gru") or not isinstance(g, torch.nn.GRU):
+                continue
+            pairs = [(g.weight_ih_l0, g.weight_ih_l0_reverse), (g.weight_hh_l0, g.weight_hh_l0_reverse),
+                     (g.bias_ih_l0, g.bias_ih_l0_reverse), (g.bias_hh_l0, g.bias_hh_l0_reverse)]
+            if any(id(a) not in off or id(b) not in off or a.numel() % 4 or off[id(b)] != off[id(a)] + a.numel()
+                   for a, b in pairs):
+                continue
+            views = []
+            for (a, _), shape in zip(pairs, ((2 * a.shape[0], a.shape[1]) if i == 0 else
+                                             ((2,) + tuple(a.shape)) if i in (1, 3) else (2 * a.shape[0],)
+                                             for i, (a, _) in enumerate(pairs))):
+                o, n = off[id(a)], 2 * a.numel()
+                v = self.flat.flat_param[o:o + n].view(shape).requires_grad_(True)
+                v._focr_grad = self.flat.flat_grad[o:o + n].view(shape)
+                views.append(v)
+            m._packed_gru = (views[0], views[2], views[1], views[3])          # wih, bih, whh, bhh
 
     # ---- overlap plan ---------------------------------------------------------------------------
     def _offset_of(self, module):

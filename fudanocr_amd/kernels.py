@@ -1149,6 +1149,7 @@ class _GRURecur(torch.autograd.Function):
         _lib.call("focr_gru_bidir_fwd", _p(gx), _p(whh), _p(bhh), _p(hseq), _p(gates), nseq, t_len, ic, os_,
                   is_, ts, _stream())
         ctx.cfg = (rows, nseq, t_len, ic, os_, is_, ts)
+        ctx.targets = (_target(whh), _target(bhh))
         ctx.save_for_backward(whh, gates, hseq)
         return hseq
 
@@ -1162,11 +1163,15 @@ class _GRURecur(torch.autograd.Function):
         hprev = torch.empty((rows, 2, 32), device=dh.device)
         _lib.call("focr_gru_bidir_bwd", _p(dh), _p(whh), _p(gates), _p(hseq), _p(dgx), _p(dgh), _p(hprev), nseq,
                   t_len, ic, os_, is_, ts, _stream())
-        dwhh = torch.empty((2, 96, 32), device=dh.device)
-        dbhh = torch.empty((2, 96), device=dh.device)
+        tw, tb = ctx.targets          # slices of the engine's flat gradient buffer (zeroed once per step): accumulate
+        pz = int(tw is not None and tb is not None)
+        dwhh = tw if pz else torch.empty((2, 96, 32), device=dh.device)
+        dbhh = tb if pz else torch.empty((2, 96), device=dh.device)
         for d in (0, 1):     # dW_hh[d] = dgh[:, d]^T hprev[:, d]  -- the generic wgrad on strided views
             _lib.call("focr_conv2d_wgrad", _po(hprev, 32 * d), _po(dgh, 96 * d), _po(dwhh, 96 * 32 * d),
-                      _po(dbhh, 96 * d), rows, 1, 1, 32, 96, 1, 1, 0, 0, 192, 64, 0, _NULL, 0, _stream())
+                      _po(dbhh, 96 * d), rows, 1, 1, 32, 96, 1, 1, 0, 0, 192, 64, pz, _NULL, 0, _stream())
+        if pz:
+            dwhh = dbhh = None
         return dgx, dwhh, dbhh, None, None, None, None, None, None
 
 

@@ -20,16 +20,20 @@ class GruBlock(nn.Module):
         assert out_channels % 2 == 0 and out_channels == 64, "the path uses 64 channels (hidden 32)"
         self.conv1 = Conv2d(in_channels, out_channels, kernel_size=1, padding=0)
         self.gru = nn.GRU(out_channels, out_channels // 2, bidirectional=True, batch_first=True)  # registry
+        self._packed_gru = None       # (wih, bih, whh, bhh) views of the engine's flat buffers (TrainStep._attach_packed_gru)
 
     def forward(self, x, vertical=False):
         """x: NHWC map.  vertical=False: sequences run along W (gru2); True: along H (gru1)."""
         g = self.gru
         b, h, w, c = x.shape
         y = self.conv1(x).view(b * h * w, c)
-        wih = torch.cat([g.weight_ih_l0, g.weight_ih_l0_reverse], 0)
-        bih = torch.cat([g.bias_ih_l0, g.bias_ih_l0_reverse], 0)
-        whh = torch.stack([g.weight_hh_l0, g.weight_hh_l0_reverse], 0)
-        bhh = torch.stack([g.bias_hh_l0, g.bias_hh_l0_reverse], 0)
+        if self._packed_gru is not None and self._packed_gru[0].data_ptr() == g.weight_ih_l0.data_ptr():
+            wih, bih, whh, bhh = self._packed_gru
+        else:
+            wih = torch.cat([g.weight_ih_l0, g.weight_ih_l0_reverse], 0)
+            bih = torch.cat([g.bias_ih_l0, g.bias_ih_l0_reverse], 0)
+            whh = torch.stack([g.weight_hh_l0, g.weight_hh_l0_reverse], 0)
+            bhh = torch.stack([g.bias_hh_l0, g.bias_hh_l0_reverse], 0)
         gx = K.linear(y, wih, bih)
         if vertical:
             out = K.gru_recurrence(gx, whh, bhh, b * w, h, w, h * w, 1, w)
