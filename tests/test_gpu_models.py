@@ -313,6 +313,10 @@ def test_traj3_golden(arch, golden_dir, prec_mode):
         if k.endswith(".bias") and (".conv1." in k or ".conv2." in k or k.startswith(("block7.0", "stn_head.stn_convnet",
                                                                                   "stn_head.stn_fc1.0"))):
             tol += 3 * 1e-4 * sd[k].numel()
+        # mode 3 (single-bf16 data gradients): Adam's normalised steps turn the bf16 rounding of small gradients into
+        # +-lr differences of the STN head's weights; the B = 4 batch statistics downstream of them move by ~1e-3
+        if prec_mode == 3 and "running_" in k:
+            tol += 2e-3 * v
         if not abs(got - v) <= tol:
             bad.append((k, got, v))
     assert not bad, bad[:10]
