@@ -828,10 +828,13 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_bx3_kernel(
 #endif
 
 __device__ __forceinline__ void lp_wait(unsigned* flag, unsigned target, unsigned* err) {
+#ifdef LSTM_ABL_NOSYNC
+  __syncthreads();
+  return;
+#endif
   if (threadIdx.x == 0) {
     int spins = 0;
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(2);
       if (++spins > LSTM_SPIN_LIMIT) {
         __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
@@ -841,6 +844,10 @@ __device__ __forceinline__ void lp_wait(unsigned* flag, unsigned target, unsigne
   __syncthreads();
 }
 __device__ __forceinline__ void lp_arrive(unsigned* flag) {
+#ifdef LSTM_ABL_NOSYNC
+  __syncthreads();
+  return;
+#endif
   __syncthreads();                      // every thread's rows of this step are written (and acknowledged by L2)
   if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -921,31 +928,40 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
       }
     }
     __syncthreads();
+    // the partners only need the bf16 hi/lo copy of h: it goes out first and the step counter right behind it; the
+    // fp32 outputs the BACKWARD pass reads (gates, c, h) are stored after the signal, off the critical path
+    float o_ig[2], o_fg[2], o_gg[2], o_og[2], o_c[2], o_h[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int ebl = (tid >> 5) + 16 * e, eb = b0 + ebl;
+      o_ig[e] = sigmoidf_(part[0][ebl][eu] + gxv[e][0] + bias.x);
+      o_fg[e] = sigmoidf_(part[1][ebl][eu] + gxv[e][1] + bias.y);
+      o_gg[e] = tanhf(part[2][ebl][eu] + gxv[e][2] + bias.z);
+      o_og[e] = sigmoidf_(part[3][ebl][eu] + gxv[e][3] + bias.w);
+      o_c[e] = o_fg[e] * cprev[e] + o_ig[e] * o_gg[e];
+      o_h[e] = o_og[e] * tanhf(o_c[e]);
+      cprev[e] = o_c[e];
+      if (eb < B) {
+        const size_t ho = ((size_t)t * B + eb) * 2 * H + dir * H + j0 + eu;
+        const __bf16 hh = (__bf16)o_h[e];
+        hseq2[ho] = hh;
+        hseq2[nh + ho] = (__bf16)(o_h[e] - (float)hh);
+      }
+    }
+    if (step + 1 < T) lp_arrive(flag);          // (the barrier inside also protects `part` for the next step)
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int ebl = (tid >> 5) + 16 * e, eb = b0 + ebl;
       if (eb < B) {
-        const float ig = sigmoidf_(part[0][ebl][eu] + gxv[e][0] + bias.x);
-        const float fg = sigmoidf_(part[1][ebl][eu] + gxv[e][1] + bias.y);
-        const float gg = tanhf(part[2][ebl][eu] + gxv[e][2] + bias.z);
-        const float og = sigmoidf_(part[3][ebl][eu] + gxv[e][3] + bias.w);
-        const float c = fg * cprev[e] + ig * gg;
-        const float h = og * tanhf(c);
-        cprev[e] = c;
         const size_t gb = (((size_t)t * B + eb) * 2 + dir) * 4 * H + j0 + eu;
-        gates[gb] = ig;
-        gates[gb + H] = fg;
-        gates[gb + 2 * H] = gg;
-        gates[gb + 3 * H] = og;
-        cseq[(((size_t)t * B + eb) * 2 + dir) * H + j0 + eu] = c;
-        const size_t ho = ((size_t)t * B + eb) * 2 * H + dir * H + j0 + eu;
-        hseq[ho] = h;
-        const __bf16 hh = (__bf16)h;
-        hseq2[ho] = hh;
-        hseq2[nh + ho] = (__bf16)(h - (float)hh);
+        gates[gb] = o_ig[e];
+        gates[gb + H] = o_fg[e];
+        gates[gb + 2 * H] = o_gg[e];
+        gates[gb + 3 * H] = o_og[e];
+        cseq[(((size_t)t * B + eb) * 2 + dir) * H + j0 + eu] = o_c[e];
+        hseq[((size_t)t * B + eb) * 2 * H + dir * H + j0 + eu] = o_h[e];
       }
     }
-    if (step + 1 < T) lp_arrive(flag);          // (the barrier inside also protects `part` for the next step)
   }
 }
 
@@ -1027,27 +1043,38 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_bx3_kernel(
       }
     }
     __syncthreads();
+    float d4[2][4];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int ebl = (tid >> 5) + 16 * e, eb = b0 + ebl;
+      const float dh = dh0[e] + (((part[0][ebl][eu] + part[1][ebl][eu]) + part[2][ebl][eu]) + part[3][ebl][eu]);
+      const float tc = tanhf(c[e]);
+      const float dc = dh * og[e] * (1.f - tc * tc) + carry[e];
+      carry[e] = dc * fg[e];
+      d4[e][0] = dc * gg[e] * ig[e] * (1.f - ig[e]);
+      d4[e][1] = dc * cp[e] * fg[e] * (1.f - fg[e]);
+      d4[e][2] = dc * ig[e] * (1.f - gg[e] * gg[e]);
+      d4[e][3] = dh * tc * og[e] * (1.f - og[e]);
       if (eb < B) {
-        const float dh = dh0[e] + (((part[0][ebl][eu] + part[1][ebl][eu]) + part[2][ebl][eu]) + part[3][ebl][eu]);
-        const float tc = tanhf(c[e]);
-        const float dc = dh * og[e] * (1.f - tc * tc) + carry[e];
-        carry[e] = dc * fg[e];
         const size_t ob = ((size_t)t * st_t + (size_t)eb * st_b) * 8 * H + dir * 4 * H + j0 + eu;
-        const float d4[4] = {dc * gg[e] * ig[e] * (1.f - ig[e]), dc * cp[e] * fg[e] * (1.f - fg[e]),
-                             dc * ig[e] * (1.f - gg[e] * gg[e]), dh * tc * og[e] * (1.f - og[e])};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          dgx[ob + q * H] = d4[q];
-          const __bf16 hh = (__bf16)d4[q];
+          const __bf16 hh = (__bf16)d4[e][q];
           dgx2[ob + q * H] = hh;
-          dgx2[ndg + ob + q * H] = (__bf16)(d4[q] - (float)hh);
+          dgx2[ndg + ob + q * H] = (__bf16)(d4[e][q] - (float)hh);
         }
       }
     }
-    if (step + 1 < T) lp_arrive(flag);
+    if (step + 1 < T) lp_arrive(flag);          // partners read the bf16 copies only; the fp32 result follows
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int eb = b0 + (tid >> 5) + 16 * e;
+      if (eb < B) {
+        const size_t ob = ((size_t)t * st_t + (size_t)eb * st_b) * 8 * H + dir * 4 * H + j0 + eu;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dgx[ob + q * H] = d4[e][q];
+      }
+    }
   }
 }
 
