@@ -613,16 +613,17 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
   const size_t sbase = (size_t)(b * H + h) * Ntok;
   const int key = qb_ * 128 + wave * 32 + li;
 
+  const float inv_keep = DROPOUT ? 1.f / (1.f - (float)attn_drop_thr16(p_drop) / 65536.f) : 1.f;
   bf16x8 kh[2], kl[2], vh[2], vl[2];
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
     row_frag(K + base + (size_t)key * ld + 16 * m + 8 * lh, 1.f, kh[m], kl[m]);
-    row_frag(V + base + (size_t)key * ld + 16 * m + 8 * lh, 1.f, vh[m], vl[m]);
+    // V carries the dropout scale 1/(1-p): dP' = dO (V/(1-p))^T is all the dS formula below needs of it
+    row_frag(V + base + (size_t)key * ld + 16 * m + 8 * lh, inv_keep, vh[m], vl[m]);
   }
   f32x16 dkacc, dvacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dkacc[r] = 0.f; dvacc[r] = 0.f; }
-  const float inv_keep = DROPOUT ? 1.f / (1.f - (float)attn_drop_thr16(p_drop) / 65536.f) : 1.f;
 
   const int rp = tid >> 3, c0 = (tid & 7) * 4;
   float4 q0, q1, g0, g1;
@@ -661,14 +662,15 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
       put_cols(Qth, Qtl, rp, c0, q0, q1);
       put_cols(Gth, Gtl, rp, c0, g0, g1);
     }
-    if (tid < 64) { Ls[tid] = lreg * LOG2E; Ds[tid] = dreg; }
+    if (tid < 64) { Ls[tid] = -lreg * LOG2E; Ds[tid] = dreg; }     // -LSE: the score accumulators START there
     __syncthreads();
     if (qt + 1 < ntiles) LOAD_QG(qt + 1);
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
+      // s starts at -LSE of its query row (register r <-> query key_of_b(r, lh)): the MFMAs deliver s - lse for free
       f32x16 s, dp;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      for (int r = 0; r < 16; ++r) { s[r] = Ls[sub * 32 + key_of_b(r, lh)]; dp[r] = 0.f; }
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         const int off = (sub * 32 + li) * RP + 16 * m + 8 * lh;
@@ -680,15 +682,15 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int qlq = sub * 32 + key_of_b(r, lh);
-        float p = __builtin_amdgcn_exp2f(s[r] - Ls[qlq]);
-        float pd = p, dpe = dp[r];
+        // dS = P (M dP' - D) = (M P) dP' - P D with M the keep mask: one AND instead of two, the rest an fma
+        const float p = __builtin_amdgcn_exp2f(s[r]);
+        float pd = p;
         if (DROPOUT) {
-          int mk = bit_sext(sub ? mcur1 : mcur0, (r & 3) + 8 * (r >> 2));   // query bit of this lane's key word
+          const int mk = bit_sext(sub ? mcur1 : mcur0, (r & 3) + 8 * (r >> 2));   // query bit of this lane's key word
           pd = __int_as_float(__float_as_int(p) & mk);              // 1/(1-p) folded into the dV store
-          dpe = __int_as_float(__float_as_int(dpe * inv_keep) & mk);
         }
         s[r] = pd;
-        dp[r] = p * (dpe - Ds[qlq]);
+        dp[r] = fmaf(pd, dp[r], -p * Ds[qlq]);
       }
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
@@ -751,18 +753,19 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_bx3_kernel(
   const size_t baseo = (size_t)b * Ntok * ldo + h * 32;
   const size_t sbase = (size_t)(b * H + h) * Ntok;
   const int q = qb_ * 128 + wave * 32 + li;
+  const float inv_keep = DROPOUT ? 1.f / (1.f - (float)attn_drop_thr16(p_drop) / 65536.f) : 1.f;
 
   bf16x8 qh[2], ql[2], gh[2], gl[2];
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
     row_frag(Q + base + (size_t)q * ld + 16 * m + 8 * lh, scale * LOG2E, qh[m], ql[m]);
-    row_frag(dO + baseo + (size_t)q * ldo + 16 * m + 8 * lh, 1.f, gh[m], gl[m]);
+    // dO carries the dropout scale 1/(1-p) (dP' = V dO'^T); D was computed from the unscaled dO by the prep kernel
+    row_frag(dO + baseo + (size_t)q * ldo + 16 * m + 8 * lh, inv_keep, gh[m], gl[m]);
   }
   const float lse = LSE[sbase + q] * LOG2E, dd = Dv[sbase + q];
   f32x16 dqacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) dqacc[r] = 0.f;
-  const float inv_keep = DROPOUT ? 1.f / (1.f - (float)attn_drop_thr16(p_drop) / 65536.f) : 1.f;
   const int NG = Ntok / 32;
   const int qg = __builtin_amdgcn_readfirstlane(qb_ * 4 + wave);
   const uint64_t* mgrp = reinterpret_cast<const uint64_t*>(MASK) + ((size_t)bh_ * NG + qg) * NG * 16;
@@ -799,9 +802,9 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_bx3_kernel(
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float p = __builtin_amdgcn_exp2f(s[r] - lse);
+        const float p = __builtin_amdgcn_exp2f(s[r] - lse);
         float dpe = dp[r];
-        if (DROPOUT) dpe = keep_lanes(dpe * inv_keep, mk[r]);
+        if (DROPOUT) dpe = keep_lanes(dpe, mk[r]);
         s[r] = p * (dpe - dd);
       }
 #pragma unroll
