@@ -204,6 +204,9 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_bx3_kernel(const float* __res
   if (lh == 0) LSE[(size_t)(b * H + h) * Ntok + q] = (mrun + __builtin_amdgcn_logf(l)) * LN2;   // natural log
 }
 
+#ifndef ATTN_RESCALE_THR
+#define ATTN_RESCALE_THR 8.0f
+#endif
 // =======================================================================================
 // forward, two query tiles per wave (block = 256 queries, wave = 2 x 32 queries)
 //   Head dim 32 makes the softmax VALU work per score (max, exp2, sum, keep-select, hi/lo split: ~9 ops) as long as the
@@ -300,9 +303,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __re
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mn = fmaxf(mrun[t], mx);
-        const float alpha = __builtin_amdgcn_exp2f(mrun[t] - mn);
-        mrun[t] = mn;
+        // Thresholded running max (wave-uniform branch): O / l are rescaled only when some query's max grew by more
+        // than 2^ATTN_RESCALE_THR since the last rescale; otherwise P is merely bounded by 2^THR instead of 1 --
+        // harmless for fp32 accumulation with split operands -- and the exp + 16 multiplies of the common case go away
+        if (__builtin_amdgcn_ballot_w64(mx > mrun[t] + ATTN_RESCALE_THR) != 0ull) {
+          const float mn = fmaxf(mrun[t], mx);
+          const float alpha = __builtin_amdgcn_exp2f(mrun[t] - mn);
+          mrun[t] = mn;
+          l[t] *= alpha;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+        }
+        const float mn = mrun[t];
         float ls = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -318,9 +330,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __re
 #pragma unroll
           for (int r = 0; r < 16; ++r) s[t][r] = keep_lanes(s[t][r], mk[t][r]);   // 1/(1-p) at the end
         }
-        l[t] = l[t] * alpha + ls;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+        l[t] += ls;
       }
 #endif
 #pragma unroll
@@ -374,9 +384,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __re
 //   bounded by 2^THR instead of 1, harmless in fp32 accumulation with split operands, and the 16 multiplies + exp of
 //   the common no-change case disappear.
 // =======================================================================================
-#ifndef ATTN_RESCALE_THR
-#define ATTN_RESCALE_THR 8.0f
-#endif
 #define F3_KB (64 * RP)
 #define F3_VB (32 * TP)
 

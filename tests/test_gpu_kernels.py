@@ -304,6 +304,28 @@ def test_attention_spiked_scores(precision):
     close(od, o, ptol(precision), what="attn spiked fwd")
 
 
+def test_attention_thresholded_rescale(precision):
+    """the forward rescales O / l only when a query's running max grew by more than 2^8 since the last rescale: a
+    RAMP of score magnitudes along the key axis makes the max creep up by a few log2 units per key tile (several tiles
+    run un-rescaled with P > 1, then the branch fires) -- forward, LSE (through the backward) and gradients must not
+    notice"""
+    b, t = 2, 512
+    q, k, v = (rnd(b, t, 128, seed=s) for s in (1, 2, 3))
+    k = k * torch.linspace(0.2, 6.0, t).view(1, t, 1)                   # later keys score higher and higher
+    q, k, v = (z.requires_grad_(True) for z in (q, k, v))
+    heads = lambda z: z.view(b, t, 4, 32).transpose(1, 2)               # noqa: E731
+    o = (torch.softmax(heads(q) @ heads(k).transpose(-1, -2) / math.sqrt(32), -1) @ heads(v)).transpose(1, 2).reshape(b, t, 128)
+    go = rnd(b, t, 128, seed=4)
+    o.backward(go)
+    qd, kd, vd = (dev(z.detach()).requires_grad_(True) for z in (q, k, v))
+    od = K().attention(qd, kd, vd, heads=4, p_drop=0.0)
+    close(od, o, ptol(precision), what="attn ramp fwd")
+    od.backward(dev(go))
+    close(qd.grad, q.grad, gtol(precision), what="attn ramp dq")
+    close(kd.grad, k.grad, gtol(precision), what="attn ramp dk")
+    close(vd.grad, v.grad, gtol(precision), what="attn ramp dv")
+
+
 def test_attention_dropout(precision):
     """dropout: expectation preserved, backward uses the same mask as forward (checked through
     linearity: with v -> ones the output equals the kept fraction / (1-p))."""
