@@ -15,6 +15,8 @@ P, I, L, F, U = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ct
 # name -> argument types (every entry point returns int and takes the stream last)
 SIGNATURES = {
     "focr_conv2d_fwd": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, I, I, P],
+    "focr_conv2d_fwd_ws": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, I, I, P, L, P],
+    "focr_conv2d_fwd_ws_floats": [I, I, I, I, I, I, I, I, I],
     "focr_conv2d_wgrad": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, L, P],
     "focr_conv2d_wgrad_ws_floats": [I, I, I, I, I, I, I, I, I],
     "focr_weight_flip_transpose": [P, P, I, I, I, I, P],
@@ -123,6 +125,7 @@ def load():
     lib.focr_lstm_ws_bytes.restype = ctypes.c_long
     lib.focr_grad_sumsq_ws_floats.restype = ctypes.c_long
     lib.focr_conv2d_wgrad_ws_floats.restype = ctypes.c_long
+    lib.focr_conv2d_fwd_ws_floats.restype = ctypes.c_long
     lib.focr_weight_frag_bytes.restype = ctypes.c_long
     lib.focr_psnr_ssim_ws_floats.restype = ctypes.c_long
     _lib = lib

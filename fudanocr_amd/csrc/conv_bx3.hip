@@ -31,13 +31,16 @@ template <int NT>
 __global__ __launch_bounds__(256) void conv_fwd_bx3_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
                                                            const float* __restrict__ bias,
                                                            const float* __restrict__ R, float* __restrict__ Y,
-                                                           ConvGeomX g, float alpha, int relu) {
+                                                           ConvGeomX g, float alpha, int relu,
+                                                           float* __restrict__ PART, int chunks_per_split) {
   constexpr int BN = 32 * NT;
   __shared__ __attribute__((aligned(16))) __bf16 Ah[XBM * XRP], Al[XBM * XRP];
   __shared__ __attribute__((aligned(16))) __bf16 Bh[BN * XRP], Bl[BN * XRP];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int m0 = blockIdx.x * XBM, n0 = blockIdx.y * BN;
-  const int nchunks = g.Ktot / XBK;
+  // split-K (PART != nullptr): block z contracts the K chunks [cbeg, cend) and stores its raw tile into slot z
+  const int cbeg = PART ? blockIdx.z * chunks_per_split : 0;
+  const int nchunks = PART ? min(g.Ktot / XBK, cbeg + chunks_per_split) : g.Ktot / XBK;
 
   // staging: thread owns float4 column c4 = tid&7 of rows (tid>>3) + 32*i
   int rbase[4], riy[4], rix[4];
@@ -109,8 +112,8 @@ __global__ __launch_bounds__(256) void conv_fwd_bx3_kernel(const float* __restri
   const int aoff = (wave * 32 + li) * XRP + 8 * lh;
   const int boff = li * XRP + 8 * lh;
 
-  load_chunk(0);
-  for (int c = 0; c < nchunks; ++c) {
+  load_chunk(cbeg);
+  for (int c = cbeg; c < nchunks; ++c) {
     store_chunk();
     __syncthreads();
     if (c + 1 < nchunks) load_chunk(c + 1);
@@ -128,6 +131,20 @@ __global__ __launch_bounds__(256) void conv_fwd_bx3_kernel(const float* __restri
       }
     }
     __syncthreads();
+  }
+  if (PART) {
+    float* slot = PART + (size_t)blockIdx.z * g.M * g.Cout;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int co = n0 + nt * 32 + li;
+      if (co >= g.Cout) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int p = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (p < g.M) slot[(size_t)p * g.Cout + co] = acc[nt][r];
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -147,20 +164,76 @@ __global__ __launch_bounds__(256) void conv_fwd_bx3_kernel(const float* __restri
   }
 }
 
+// y = epilogue(alpha * sum_z PART[z] + bias + residual): the K splits folded in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __restrict__ PART,
+                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ R, float* __restrict__ Y,
+                                                                 long M, int Cout, int ldy, int ldr, int splits,
+                                                                 float alpha, int relu) {
+  const long n4 = M * Cout / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 s = reinterpret_cast<const float4*>(PART)[i];
+    for (int z = 1; z < splits; ++z) {
+      const float4 v = reinterpret_cast<const float4*>(PART + (size_t)z * M * Cout)[i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const long p = (i * 4) / Cout;
+    const int co = (int)((i * 4) - p * Cout);
+    float o[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = alpha * o[e] + (bias ? bias[co + e] : 0.f);
+      if (R) v += R[(size_t)p * ldr + co + e];
+      if (relu) v = fmaxf(v, 0.f);
+      o[e] = v;
+    }
+    *reinterpret_cast<float4*>(Y + (size_t)p * ldy + co) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// Layers with few output tiles and a long contraction (the STN head's 1x2 .. 2x8 px maps, the CRNN tail: 8 .. 208
+// blocks walking 64-144 K chunks each) are split along K: every split writes its raw tile to a workspace slot and
+// conv_splitk_reduce_kernel folds the slots in a fixed order and applies the epilogue -- deterministic, no atomics.
+static int splitk_plan(int M, int Cout, int Ktot, int nt, int& cps) {
+  const int blocks = ((M + XBM - 1) / XBM) * ((Cout + 32 * nt - 1) / (32 * nt));
+  const int nchunks = Ktot / XBK;
+  if (blocks >= 256 || nchunks < 16 || Cout % 4) return 1;
+  int splits = (512 + blocks - 1) / blocks;             // aim at two blocks per CU
+  if (splits > nchunks / 4) splits = nchunks / 4;       // at least four chunks per block
+  if (splits > 32) splits = 32;
+  if (splits < 2) return 1;
+  cps = (nchunks + splits - 1) / splits;
+  return (nchunks + cps - 1) / cps;
+}
+long focr_conv_fwd_bx3_ws_floats(int M, int Cin, int Cout, int Ktot) {
+  int cps = 0;
+  const int splits = splitk_plan(M, Cout, Ktot, Cout > 32 ? 2 : 1, cps);
+  return splits > 1 ? (long)splits * M * Cout : 0;
+}
 // launcher used by focr_conv2d_fwd (conv_igemm.hip) when precision == bf16x3 and the layer is VEC-capable
 int focr_conv_fwd_bx3(const float* x, const float* w, const float* bias, const float* residual, float* y,
                       int N, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int padH, int padW,
-                      int M, int ldy, int ldr, int ldx, float alpha, int relu, hipStream_t stream) {
+                      int M, int ldy, int ldr, int ldx, float alpha, int relu, float* ws, long ws_floats,
+                      hipStream_t stream) {
   ConvGeomX g{N, H, W, Cin, OH, OW, Cout, KH, KW, padH, padW, KH * KW * Cin, M, ldy, ldr, ldx};
   // widest column tile that does not waste MFMA work: the A (activation) tile is re-read once per column block
   int nt = Cout > 32 ? 2 : 1;   // a 128-column tile (NT=4) was measured: no gain, these GEMMs are latency bound
-  dim3 grid((M + XBM - 1) / XBM, (Cout + 32 * nt - 1) / (32 * nt));
-  if (nt == 4)
-    hipLaunchKernelGGL((conv_fwd_bx3_kernel<4>), grid, 256, 0, stream, x, w, bias, residual, y, g, alpha, relu);
-  else if (nt == 2)
-    hipLaunchKernelGGL((conv_fwd_bx3_kernel<2>), grid, 256, 0, stream, x, w, bias, residual, y, g, alpha, relu);
+  int cps = 0;
+  int splits = ws ? splitk_plan(M, Cout, g.Ktot, nt, cps) : 1;
+  if (splits > 1 && ws_floats < (long)splits * M * Cout) splits = 1;
+  float* part = splits > 1 ? ws : nullptr;
+  dim3 grid((M + XBM - 1) / XBM, (Cout + 32 * nt - 1) / (32 * nt), splits);
+  if (nt == 2)
+    hipLaunchKernelGGL((conv_fwd_bx3_kernel<2>), grid, 256, 0, stream, x, w, bias, residual, y, g, alpha, relu, part, cps);
   else
-    hipLaunchKernelGGL((conv_fwd_bx3_kernel<1>), grid, 256, 0, stream, x, w, bias, residual, y, g, alpha, relu);
+    hipLaunchKernelGGL((conv_fwd_bx3_kernel<1>), grid, 256, 0, stream, x, w, bias, residual, y, g, alpha, relu, part, cps);
+  if (part) {
+    const long n4 = (long)M * Cout / 4;
+    int rb = (int)((n4 + 255) / 256);
+    if (rb > 1024) rb = 1024;
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(rb), 256, 0, stream, (const float*)part, bias, residual, y, (long)M,
+                       Cout, ldy, ldr, splits, alpha, relu);
+  }
   return 0;
 }
 

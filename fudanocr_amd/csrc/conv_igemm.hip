@@ -384,7 +384,9 @@ static int fill_geom(ConvGeom& g, int N, int H, int W, int Cin, int Cout, int KH
 
 int focr_conv_fwd_bx3(const float* x, const float* w, const float* bias, const float* residual, float* y,
                       int N, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int padH, int padW,
-                      int M, int ldy, int ldr, int ldx, float alpha, int relu, hipStream_t stream);
+                      int M, int ldy, int ldr, int ldx, float alpha, int relu, float* ws, long ws_floats,
+                      hipStream_t stream);
+long focr_conv_fwd_bx3_ws_floats(int M, int Cin, int Cout, int Ktot);
 
 int focr_conv_wgrad_bx3(const float* x, const float* dy, float* dw, float* dbias, float* ws, long ws_floats, int N,
                         int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int padH, int padW, int M,
@@ -408,10 +410,9 @@ int focr_linear_stream_bx3(const float* x, const float* w, const float* bias, co
                            float drop_scale, uint32_t drop_seed, hipStream_t stream);
 extern "C" int focr_dropout(const float* x, float* y, long n, float p, uint64_t seed, hipStream_t stream);
 
-extern "C" int focr_conv2d_fwd(const float* x, const float* w, const float* bias,
-                               const float* residual, float* y, int N, int H, int W, int Cin,
-                               int Cout, int KH, int KW, int padH, int padW, float alpha, int relu,
-                               int ldy, int ldr, int ldx, hipStream_t stream) {
+static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, const float* residual, float* y, int N,
+                           int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW, float alpha, int relu,
+                           int ldy, int ldr, int ldx, float* ws, long ws_floats, hipStream_t stream) {
   ConvGeom g;
   FOCR_CHECK_ARG(x && w && y, "null pointer");
   FOCR_CHECK_ARG(fill_geom(g, N, H, W, Cin, Cout, KH, KW, padH, padW) == 0, "bad geometry");
@@ -434,7 +435,7 @@ extern "C" int focr_conv2d_fwd(const float* x, const float* w, const float* bias
   }
   if (vec && focr_get_precision() != 0) {
     focr_conv_fwd_bx3(x, w, bias, residual, y, N, H, W, Cin, g.OH, g.OW, Cout, KH, KW, padH, padW, g.M, g.ldy,
-                      g.ldr, g.ldx, alpha, relu, stream);
+                      g.ldr, g.ldx, alpha, relu, ws, ws_floats, stream);
     FOCR_LAUNCH_CHECK();
     return FOCR_OK;
   }
@@ -450,6 +451,29 @@ extern "C" int focr_conv2d_fwd(const float* x, const float* w, const float* bias
     hipLaunchKernelGGL((conv_fwd_kernel<1, false>), grid, 256, 0, stream, x, w, bias, residual, y, g, alpha, relu);
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
+}
+
+extern "C" int focr_conv2d_fwd(const float* x, const float* w, const float* bias,
+                               const float* residual, float* y, int N, int H, int W, int Cin,
+                               int Cout, int KH, int KW, int padH, int padW, float alpha, int relu,
+                               int ldy, int ldr, int ldx, hipStream_t stream) {
+  return conv2d_fwd_impl(x, w, bias, residual, y, N, H, W, Cin, Cout, KH, KW, padH, padW, alpha, relu, ldy, ldr, ldx,
+                         nullptr, 0, stream);
+}
+// Same convolution with caller-provided scratch: layers with few output tiles and a long contraction are split along K
+// (deterministic slot reduction).  focr_conv2d_fwd_ws_floats returns the scratch size (0: the layer does not split).
+extern "C" long focr_conv2d_fwd_ws_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW) {
+  ConvGeom g;
+  if (focr_get_precision() == 0 || fill_geom(g, N, H, W, Cin, Cout, KH, KW, padH, padW) != 0 || Cin % BK != 0) return 0;
+  if (KH == 9 || (KH == 1 && KW == 1 && g.M >= 16384 && (Cin == 64 || Cin == 128))) return 0;   // special kernels
+  return focr_conv_fwd_bx3_ws_floats(g.M, Cin, Cout, g.Ktot);
+}
+extern "C" int focr_conv2d_fwd_ws(const float* x, const float* w, const float* bias, const float* residual, float* y,
+                                  int N, int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW,
+                                  float alpha, int relu, int ldy, int ldr, int ldx, float* ws, long ws_floats,
+                                  hipStream_t stream) {
+  return conv2d_fwd_impl(x, w, bias, residual, y, N, H, W, Cin, Cout, KH, KW, padH, padW, alpha, relu, ldy, ldr, ldx, ws,
+                         ws_floats, stream);
 }
 
 // y = Dropout_p(relu(alpha * x W^T + b)) for a Linear (rows x Cin -> rows x Cout), the FFN front half

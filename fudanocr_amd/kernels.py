@@ -384,6 +384,12 @@ def _conv_fwd_raw(x4, w_ohwi, bias, residual, cout, kh, kw, ph, pw, alpha, relu,
         _lib.call("focr_conv9x9_small_cout_fwd", _p(x4), _p(w_ohwi), _p(bias), _p(y), n, h, w, cin, cout,
                   _stream())
         return y
+    nws = _lib.load().focr_conv2d_fwd_ws_floats(n, h, w, cin, cout, kh, kw, ph, pw)
+    if nws > 0:       # few output tiles, long contraction (STN head, CRNN tail): split along K, fixed-order fold
+        ws = torch.empty(nws, device=x4.device, dtype=torch.float32)
+        _lib.call("focr_conv2d_fwd_ws", _p(x4), _p(w_ohwi), _p(bias), _p(residual), _p(y), n, h, w, cin, cout,
+                  kh, kw, ph, pw, float(alpha), int(relu), 0, 0, 0, _p(ws), nws, _stream())
+        return y
     _lib.call("focr_conv2d_fwd", _p(x4), _p(w_ohwi), _p(bias), _p(residual), _p(y), n, h, w, cin, cout,
               kh, kw, ph, pw, float(alpha), int(relu), 0, 0, 0, _stream())
     return y

@@ -59,6 +59,14 @@ int focr_get_precision(void);
 int focr_conv2d_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
                     int N, int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW,
                     float alpha, int relu, int ldy, int ldr, int ldx, focr_stream_t stream);
+/* The same convolution with caller-provided scratch: layers with few output tiles and a long contraction (the STN
+ * head's 1x2 .. 2x8 px maps, the CRNN tail) are split along K, every split writes its tile to a slot of `ws` and the
+ * slots are folded in a fixed order (deterministic, no atomics).  focr_conv2d_fwd_ws_floats: scratch size in floats,
+ * 0 = the layer does not split (then focr_conv2d_fwd_ws == focr_conv2d_fwd). */
+long focr_conv2d_fwd_ws_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW);
+int focr_conv2d_fwd_ws(const float* x, const float* w, const float* bias, const float* residual, float* y, int N,
+                       int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW, float alpha, int relu,
+                       int ldy, int ldr, int ldx, float* ws, long ws_floats, focr_stream_t stream);
 /* y = Dropout_p(relu(alpha * x W^T + b)) for a Linear [rows,Cin] -> [rows,Cout] (PositionwiseFeedForward,
  * tbsrn.py:162-163), dropout fused into the GEMM epilogue.  *keep_scale (host) receives 1/P(keep) (P quantised to
  * 1/65536): dropped elements are exactly the zeros of y, so the backward is focr_relu_bwd_scaled(dy, y, ., keep_scale). */

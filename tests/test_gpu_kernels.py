@@ -90,6 +90,8 @@ CONV_CASES = [
     (3, 8, 25, 128, 256, 3, 3, 1, 1),     # halo kernel: two input-channel slices, several output groups
     (2, 4, 26, 256, 64, 3, 3, 1, 1),      # halo kernel: four slices, one row tile
     (9, 6, 33, 64, 64, 3, 3, 1, 1),       # halo kernel: H % 4 != 0, W = 33 (one valid pixel in the last tile)
+    (128, 1, 4, 256, 256, 3, 3, 1, 1),    # split-K path: STN conv on the 1x4 map at the bench batch (16 tiles, 72 K chunks)
+    (40, 2, 8, 128, 256, 3, 3, 1, 1),     # split-K path: ragged last row tile (M = 640), uneven split (36 chunks)
 ]
 
 

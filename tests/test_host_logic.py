@@ -41,7 +41,7 @@ def test_c_abi_exports_every_declared_symbol():
             continue
         if name in ("focr_set_precision", "focr_get_precision", "focr_bn_ws_floats", "focr_bn_bwd_ws_floats",
                     "focr_lstm_ws_bytes", "focr_grad_sumsq_ws_floats", "focr_conv2d_wgrad_ws_floats",
-                    "focr_weight_frag_bytes", "focr_conv3x3_frag_tiles", "focr_psnr_ssim_ws_floats", "focr_get_tuning", "focr_comm_nranks"):
+                    "focr_weight_frag_bytes", "focr_conv3x3_frag_tiles", "focr_psnr_ssim_ws_floats", "focr_get_tuning", "focr_comm_nranks", "focr_conv2d_fwd_ws_floats"):
             assert len(_lib.SIGNATURES[name]) == nargs
             continue
         assert name in _lib.SIGNATURES, "no ctypes signature for " + name

@@ -141,7 +141,7 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(ref_conv_kernel, dim3((ny + 255) / 256), 256, 0, 0, x, w, bias, res, yref, s.N, s.H, s.W, s.Cin, s.Cout, 3, 3, 1);
     CK(hipDeviceSynchronize());
     const int M = s.N * s.H * s.W;
-    auto old_k = [&]() { focr_conv_fwd_bx3(x, w, bias, res, y0, s.N, s.H, s.W, s.Cin, s.H, s.W, s.Cout, 3, 3, 1, 1, M, s.Cout, s.Cout, s.Cin, 1.f, 0, 0); };
+    auto old_k = [&]() { focr_conv_fwd_bx3(x, w, bias, res, y0, s.N, s.H, s.W, s.Cin, s.H, s.W, s.Cout, 3, 3, 1, 1, M, s.Cout, s.Cout, s.Cin, 1.f, 0, nullptr, 0, 0); };
     auto h2 = [&]() { focr_conv3x3_halo(x, wf, bias, res, y1, nullptr, s.N, s.H, s.W, s.Cin, s.Cout, s.Cin, s.Cout, s.Cout, 1.f, 0, 2, 0); };
     auto h2s = [&]() { focr_conv3x3_halo(x, wf, bias, res, y1, stats, s.N, s.H, s.W, s.Cin, s.Cout, s.Cin, s.Cout, s.Cout, 1.f, 0, 2, 0); };
     auto h1 = [&]() { focr_conv3x3_halo(x, wf, bias, res, y2, nullptr, s.N, s.H, s.W, s.Cin, s.Cout, s.Cin, s.Cout, s.Cout, 1.f, 0, 1, 0); };
