@@ -842,6 +842,131 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_bx3_kernel(
                     dqacc[4 * g + 3] * scale);
 }
 
+// dQ with two query tiles per wave (block = 256 queries): the K / V staging of a 64-key tile (global loads, hi/lo split,
+// transposed copy: ~75 VALU instructions per thread) and every K / V fragment read serve 256 queries instead of 128.
+template <bool DROPOUT, bool FAST>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq2_bx3_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+    const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ Dv,
+    float* __restrict__ dQ, const uint32_t* __restrict__ MASK, int Ntok, int ld, int ldo, float scale, float p_drop,
+    int nheads) {
+  __shared__ __attribute__((aligned(16))) __bf16 Kh[64 * RP], Kl[64 * RP], Vh[64 * RP], Vl[64 * RP];
+  __shared__ __attribute__((aligned(16))) __bf16 Kth[32 * TP], Ktl[32 * TP];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  int bh_, qb_;
+  attn_block_decode(blockIdx.x, gridDim.x / (Ntok / 256), Ntok / 256, bh_, qb_);
+  const int H = nheads, h = bh_ % nheads, b = bh_ / nheads;
+  const size_t base = (size_t)b * Ntok * ld + h * 32;
+  const size_t baseo = (size_t)b * Ntok * ldo + h * 32;
+  const size_t sbase = (size_t)(b * H + h) * Ntok;
+  const int q0 = qb_ * 256 + wave * 64 + li;                 // tile t: query q0 + 32 t
+  const float inv_keep = DROPOUT ? 1.f / (1.f - (float)attn_drop_thr16(p_drop) / 65536.f) : 1.f;
+
+  bf16x8 qh[2][2], ql[2][2], gh[2][2], gl[2][2];
+  float lse[2], dd[2];
+  f32x16 dqacc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int q = q0 + 32 * t;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      row_frag(Q + base + (size_t)q * ld + 16 * m + 8 * lh, scale * LOG2E, qh[t][m], ql[t][m]);
+      // dO carries the dropout scale 1/(1-p) (dP' = V dO'^T); D was computed from the unscaled dO by the prep kernel
+      row_frag(dO + baseo + (size_t)q * ldo + 16 * m + 8 * lh, inv_keep, gh[t][m], gl[t][m]);
+    }
+    lse[t] = LSE[sbase + q] * LOG2E;
+    dd[t] = Dv[sbase + q];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqacc[t][r] = 0.f;
+  }
+  const int NG = Ntok / 32;
+  const int qg = __builtin_amdgcn_readfirstlane(qb_ * 8 + wave * 2);
+  const uint64_t* mgrp = reinterpret_cast<const uint64_t*>(MASK) + ((size_t)bh_ * NG + qg) * NG * 16;
+
+  const int rp = tid >> 3, c0 = (tid & 7) * 4;
+  float4 k0, k1, v0, v1;
+  const int ntiles = Ntok / 64;
+  LOAD_KV(0);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    put_rows(Kh, Kl, rp, c0, k0, k1);
+    if (FAST) put_cols_hi(Kth, rp, c0, k0, k1);
+    else put_cols(Kth, Ktl, rp, c0, k0, k1);
+    put_rows(Vh, Vl, rp, c0, v0, v1);
+    __syncthreads();
+    if (kt + 1 < ntiles) LOAD_KV(kt + 1);
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      uint64_t mk[2][16];
+      if (DROPOUT) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const uint64_t* mp = mgrp + ((size_t)t * NG + (kt * 2 + sub)) * 16;      // wave-uniform -> scalar loads
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mk[t][r] = mp[r];
+        }
+        __builtin_amdgcn_sched_barrier(0);       // keep the requests up here (the scheduler sinks them to their uses)
+      }
+      f32x16 s[2], dp[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[t][r] = 0.f; dp[t][r] = 0.f; }
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int off = (sub * 32 + li) * RP + 16 * m + 8 * lh;
+        bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Kh[off]), al = *reinterpret_cast<const bf16x8*>(&Kl[off]);
+        MFMA3(s[0], ah, al, qh[0][m], ql[0][m]);
+        MFMA3(s[1], ah, al, qh[1][m], ql[1][m]);
+        bf16x8 ch = *reinterpret_cast<const bf16x8*>(&Vh[off]), cl = *reinterpret_cast<const bf16x8*>(&Vl[off]);
+        MFMA3(dp[0], ch, cl, gh[0][m], gl[0][m]);
+        MFMA3(dp[1], ch, cl, gh[1][m], gl[1][m]);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(s[t][r] - lse[t]);
+          float dpe = dp[t][r];
+          if (DROPOUT) dpe = keep_lanes(dpe, mk[t][r]);
+          s[t][r] = p * (dpe - dd[t]);
+        }
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int kc = sub * 32 + 16 * m + 4 * lh;
+        bf16x8 ah = cat44(*reinterpret_cast<const bf16x4*>(&Kth[li * TP + kc]),
+                          *reinterpret_cast<const bf16x4*>(&Kth[li * TP + kc + 8]));
+        if (FAST) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            bf16x8 sh;
+            hi_regs(s[t], m, sh);
+            MFMA1(dqacc[t], ah, sh);
+          }
+        } else {
+          bf16x8 al = cat44(*reinterpret_cast<const bf16x4*>(&Ktl[li * TP + kc]),
+                            *reinterpret_cast<const bf16x4*>(&Ktl[li * TP + kc + 8]));
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            bf16x8 sh, sl;
+            split_regs(s[t], m, sh, sl);
+            MFMA3(dqacc[t], ah, al, sh, sl);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    float* row = dQ + base + (size_t)(q0 + 32 * t) * ld;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(row + 8 * g + 4 * lh) =
+          make_float4(dqacc[t][4 * g] * scale, dqacc[t][4 * g + 1] * scale, dqacc[t][4 * g + 2] * scale,
+                      dqacc[t][4 * g + 3] * scale);
+  }
+}
+
 // launchers used by the dispatching C ABI entry points in attention.hip
 // 0: one query tile per wave (128-query blocks); 1: two tiles per wave (256-query blocks, needs Ntok % 256 == 0)
 int focr_attn_fwd_bx3(const float* q, const float* k, const float* v, float* o, float* lse, uint32_t* mask,
@@ -876,21 +1001,22 @@ int focr_attn_fwd_bx3(const float* q, const float* k, const float* v, float* o, 
                        p_drop, seed, H);
   return 0;
 }
-#ifndef FOCR_ATTN_BWD_VARIANT
-#define FOCR_ATTN_BWD_VARIANT 0
-#endif
-int g_attn_bwd_variant = FOCR_ATTN_BWD_VARIANT;
 int focr_attn_bwd_bx3(const float* q, const float* k, const float* v, const float* d_o, const float* lse,
                       const float* dwork, const uint32_t* mask, float* dq, float* dk, float* dv, int B, int H,
                       int Ntok, int ld, int ldo, float scale, float p_drop, hipStream_t stream) {
   dim3 grid(B * H * (Ntok / 128));
   const bool fast = focr_get_precision() >= 2;
+  const bool dq2 = focr_get_tuning(FOCR_TUNE_ATTN_BWD_DQ_VARIANT) == 1 && Ntok % 256 == 0;      // two query tiles per wave in the dQ pass
 #define LAUNCH_BWD(DR, FA)                                                                                        \
   do {                                                                                                            \
     hipLaunchKernelGGL((attn_bwd_dkv_bx3_kernel<DR, FA>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dk, dv, \
                        mask, Ntok, ld, ldo, scale, p_drop, H);                                                    \
-    hipLaunchKernelGGL((attn_bwd_dq_bx3_kernel<DR, FA>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dq, mask, \
-                       Ntok, ld, ldo, scale, p_drop, H);                                                          \
+    if (dq2)                                                                                                      \
+      hipLaunchKernelGGL((attn_bwd_dq2_bx3_kernel<DR, FA>), dim3(B * H * (Ntok / 256)), 256, 0, stream, q, k, v, d_o, \
+                         lse, dwork, dq, mask, Ntok, ld, ldo, scale, p_drop, H);                                  \
+    else                                                                                                          \
+      hipLaunchKernelGGL((attn_bwd_dq_bx3_kernel<DR, FA>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dq, mask, \
+                         Ntok, ld, ldo, scale, p_drop, H);                                                        \
   } while (0)
   if (p_drop > 0.f) {
     if (fast) LAUNCH_BWD(true, true);

@@ -41,7 +41,8 @@ extern "C" int focr_get_precision(void) { return g_precision; }
 //   1 "attn_fwd_variant"     1: 256-query attention forward blocks    0: 128-query blocks    2: scores one key
 //                            group ahead + thresholded rescale (measured: no gain in the step)
 //   2 "lstm_persistent"      1: one launch per BiLSTM layer and direction pair (rnn.hip)  0: one launch per time step
-int g_tuning[FOCR_TUNING_COUNT] = {1, 1, 1};
+//   3 "attn_bwd_dq_variant"  1: dQ pass with 256-query blocks (two tiles per wave)        0: 128-query blocks
+int g_tuning[FOCR_TUNING_COUNT] = {1, 1, 1, 1};
 extern "C" int focr_set_tuning(int key, int value) {
   if (key < 0 || key >= FOCR_TUNING_COUNT) {
     focr_set_error("focr_set_tuning: unknown key %d", key);

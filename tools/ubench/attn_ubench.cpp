@@ -13,9 +13,8 @@
 extern "C" void focr_set_error(const char* fmt, ...) { va_list a; va_start(a, fmt); vfprintf(stderr, fmt, a); va_end(a); fputc('\n', stderr); }
 static int g_prec = 2;
 extern "C" int focr_get_precision(void) { return g_prec; }
-static int g_tune[FOCR_TUNING_COUNT] = {1, 1, 1};
+static int g_tune[FOCR_TUNING_COUNT] = {1, 1, 1, 1};
 extern "C" int focr_get_tuning(int key) { return g_tune[key]; }
-extern int g_attn_bwd_variant;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 __global__ void fill_kernel(float* p, long n, uint32_t seed, float scale) {
@@ -72,10 +71,10 @@ int main(int argc, char** argv) {
     printf("fwd p=%.1f: variantA %7.1f us (%5.0f TF)  variant1 %7.1f us (%5.0f TF)  [mask kernel alone %6.1f us]  max|dO| %.2e of %.2e, max|dLSE| %.2e\n",
            p, t0, fl / t0 / 1e6, t1, fl / t1 / 1e6, tm, e, mx, e2);
     // backward (variants of the backward are compared the same way once they exist)
-    g_attn_bwd_variant = 0;
+    g_tune[FOCR_TUNE_ATTN_BWD_DQ_VARIANT] = 0;
     focr_attention_bwd(q, k, v, o0, dO, lse0, mask, dq0, dk0, dv0, work, B, H, N, D, D, scale, p, 0);
     float b0 = timeit([&]() { focr_attention_bwd(q, k, v, o0, dO, lse0, mask, dq0, dk0, dv0, work, B, H, N, D, D, scale, p, 0); });
-    g_attn_bwd_variant = 1;
+    g_tune[FOCR_TUNE_ATTN_BWD_DQ_VARIANT] = 1;
     focr_attention_bwd(q, k, v, o0, dO, lse0, mask, dq1, dk1, dv1, work, B, H, N, D, D, scale, p, 0);
     float b1 = timeit([&]() { focr_attention_bwd(q, k, v, o0, dO, lse0, mask, dq1, dk1, dv1, work, B, H, N, D, D, scale, p, 0); });
     CK(hipDeviceSynchronize());
