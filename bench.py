@@ -262,7 +262,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i == args.steps - conv_steps:
-            _lib.add_timing(["focr_conv3x3_frag_fwd", "focr_conv2d_fwd", "focr_conv2d_wgrad"])
+            _lib.add_timing(["focr_conv3x3_frag_fwd", "focr_conv2d_fwd", "focr_conv2d_fwd_ws", "focr_conv2d_wgrad"])
         out = step()
     sync()
     dt = time.perf_counter() - t0
@@ -304,7 +304,7 @@ def main():
                    "weights by LDS-DMA; forward + data-gradient launches of every 3x3 conv with C % 64 == 0)",
                    fl, by, ms, n, ex, {"traffic": traffic, "traffic_provenance": prov})
         also = []
-        f2, b2, m2, n2 = _gemm_rows(kt.get("focr_conv2d_fwd", []), "fwd")
+        f2, b2, m2, n2 = _gemm_rows(kt.get("focr_conv2d_fwd", []) + kt.get("focr_conv2d_fwd_ws", []), "fwd")
         if n2:
             also.append(row("conv_fwd_bx3_kernel / linear_stream_bx3_kernel (focr_conv2d_fwd: remaining implicit-GEMM "
                             "convs + streaming linears, forward and data gradient)", f2, b2, m2, n2, 3 if bx3 else 1))
