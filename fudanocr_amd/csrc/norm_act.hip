@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ invstd,
-    float* __restrict__ sum_g, float* __restrict__ sum_gx, long rows, int C, int act) {
+    float* __restrict__ sum_g, float* __restrict__ sum_gx, long rows, int C, int act, int lddz) {
   __shared__ float4 red0[256], red1[256];
   const int C4 = C >> 2;
   const int cols = C4 < 256 ? C4 : 256;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ii[4] = {i4.x, i4.y, i4.z, i4.w};
     for (long r = r0 + rl; r < r1; r += rl_n) {
       float4 xv = *reinterpret_cast<const float4*>(x + r * C + col * 4);
-      float4 dv = *reinterpret_cast<const float4*>(dz + r * C + col * 4);
+      float4 dv = *reinterpret_cast<const float4*>(dz + r * lddz + col * 4);
       const float xx[4] = {xv.x, xv.y, xv.z, xv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ sum_g, const float* __restrict__ sum_gx, float* __restrict__ dx, long total4,
-    long rows, int C, int act) {
+    long rows, int C, int act, int lddz) {
   const float inv_rows = 1.f / (float)rows;
   const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x, step = (long)gridDim.x * blockDim.x;
   // the grid stride is a multiple of C (ew_grid() hands out multiples of 256 threads = 1024 floats): every thread
@@ -280,7 +280,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
       }
     }
     float4 v = reinterpret_cast<const float4*>(x)[i];
-    float4 d = reinterpret_cast<const float4*>(dz)[i];
+    float4 d;
+    if (lddz == C) {
+      d = reinterpret_cast<const float4*>(dz)[i];
+    } else {                                   // dz is a column slice of a wider row-major matrix (row pitch lddz)
+      const long row = (i * 4) / C;
+      d = *reinterpret_cast<const float4*>(dz + row * lddz + (i * 4 - row * C));
+    }
     float vv[4] = {v.x, v.y, v.z, v.w}, dd[4] = {d.x, d.y, d.z, d.w}, oo[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -725,8 +731,10 @@ extern "C" long focr_bn_bwd_ws_floats(long rows, int C) { return (long)bwd_slabs
 
 extern "C" int focr_bn_bwd(const float* dz, const float* x, const float* gamma, const float* beta,
                            const float* mean, const float* invstd, float* dx, float* dgamma,
-                           float* dbeta, float* ws, long rows, int C, int act, int train,
+                           float* dbeta, float* ws, long rows, int C, int act, int train, int lddz,
                            hipStream_t stream) {
+  if (lddz <= 0) lddz = C;
+  FOCR_CHECK_ARG(lddz >= C && lddz % 4 == 0, "dz row pitch must be >= C and a multiple of 4");
   FOCR_CHECK_ARG(dz && x && gamma && beta && mean && invstd && dx, "null pointer");
   FOCR_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0, "need C % 4 == 0");
   long total4 = rows * C / 4;
@@ -736,23 +744,23 @@ extern "C" int focr_bn_bwd(const float* dz, const float* x, const float* gamma, 
     float* pg = ws;                       // [slabs][C]
     float* pgx = ws + (size_t)slabs * C;  // [slabs][C]
     dim3 g(cdiv(C, 1024), slabs);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, g, 256, 0, stream, dz, x, gamma, beta, mean, invstd, pg, pgx, rows, C, act);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, g, 256, 0, stream, dz, x, gamma, beta, mean, invstd, pg, pgx, rows, C, act, lddz);
     hipLaunchKernelGGL(bn_fold2_kernel, dim3(C / 4, 2), 256, 0, stream, (const float*)pg, dbeta, (const float*)pgx,
                        dgamma, slabs, C);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), 256, 0, stream, dz, x, gamma, beta, mean,
-                       invstd, (const float*)dbeta, (const float*)dgamma, dx, total4, rows, C, act);
+                       invstd, (const float*)dbeta, (const float*)dgamma, dx, total4, rows, C, act, lddz);
   } else {
     if (dgamma && dbeta && ws) {        // eval-mode statistics, trainable affine: the same two sums, no mean terms in dx
       const int slabs = bwd_slabs(rows);
       float* pg = ws;
       float* pgx = ws + (size_t)slabs * C;
       dim3 g(cdiv(C, 1024), slabs);
-      hipLaunchKernelGGL(bn_bwd_reduce_kernel, g, 256, 0, stream, dz, x, gamma, beta, mean, invstd, pg, pgx, rows, C, act);
+      hipLaunchKernelGGL(bn_bwd_reduce_kernel, g, 256, 0, stream, dz, x, gamma, beta, mean, invstd, pg, pgx, rows, C, act, lddz);
       hipLaunchKernelGGL(bn_fold2_kernel, dim3(C / 4, 2), 256, 0, stream, (const float*)pg, dbeta, (const float*)pgx,
                          dgamma, slabs, C);
     }
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), 256, 0, stream, dz, x, gamma, beta, mean,
-                       invstd, (const float*)nullptr, (const float*)nullptr, dx, total4, rows, C, act);
+                       invstd, (const float*)nullptr, (const float*)nullptr, dx, total4, rows, C, act, lddz);
   }
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;

@@ -556,6 +556,20 @@ def linear(x, weight, bias=None, residual=None, alpha=1.0, relu=False, dropout=0
 # ----------------------------------------------------------------------------------------
 # batch norm (+activation, +residual)
 # ----------------------------------------------------------------------------------------
+def _row_pitch(t):
+    """row pitch (in elements) of a tensor that is a column slice of a contiguous row-major matrix: last dim dense, all
+    leading dims collapse to ONE uniform row stride, 16-byte aligned; 0 if it is not (or is plainly contiguous)"""
+    if t.dim() < 2 or t.stride(-1) != 1 or t.is_contiguous():
+        return 0
+    pitch = t.stride(-2)
+    if pitch < t.shape[-1] or pitch % 4 or t.data_ptr() % 16:
+        return 0
+    for d in range(t.dim() - 2):
+        if t.stride(d) != t.stride(d + 1) * t.shape[d + 1]:
+            return 0
+    return pitch
+
+
 class _BatchNormAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, rmean, rvar, nbt, residual, training, act, momentum, eps, stats=None):
@@ -591,7 +605,11 @@ class _BatchNormAct(torch.autograd.Function):
     def backward(ctx, dz):
         x, gamma, beta, mean, invstd = ctx.saved_tensors
         rows, c, act, training, has_res = ctx.cfg
-        dz = dz.contiguous()
+        # dz may arrive as the feature half of a [.., feature | PE] gradient (kernels._ConcatPE): the kernels take its
+        # row pitch instead of a gathered copy
+        lddz = _row_pitch(dz) if not has_res else 0
+        if lddz == 0:
+            dz = dz.contiguous()
         dx = torch.empty_like(x)
         dg = db = None
         if training:
@@ -600,7 +618,7 @@ class _BatchNormAct(torch.autograd.Function):
             db = tb if tb is not None else torch.empty(c, device=x.device)
             ws = torch.empty(_lib.load().focr_bn_bwd_ws_floats(rows, c), device=x.device)
             _lib.call("focr_bn_bwd", _p(dz), _p(x), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(dx), _p(dg),
-                      _p(db), _p(ws), rows, c, act, 1, _stream())
+                      _p(db), _p(ws), rows, c, act, 1, lddz, _stream())
             dg = None if tg is not None else dg
             db = None if tb is not None else db
         elif ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:       # eval statistics, trainable affine parameters
@@ -609,12 +627,12 @@ class _BatchNormAct(torch.autograd.Function):
             db = tb if tb is not None else torch.empty(c, device=x.device)
             ws = torch.empty(_lib.load().focr_bn_bwd_ws_floats(rows, c), device=x.device)
             _lib.call("focr_bn_bwd", _p(dz), _p(x), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(dx), _p(dg),
-                      _p(db), _p(ws), rows, c, act, 0, _stream())
+                      _p(db), _p(ws), rows, c, act, 0, lddz, _stream())
             dg = None if tg is not None else dg
             db = None if tb is not None else db
         else:
             _lib.call("focr_bn_bwd", _p(dz), _p(x), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(dx), _NULL,
-                      _NULL, _NULL, rows, c, act, 0, _stream())
+                      _NULL, _NULL, rows, c, act, 0, lddz, _stream())
         return dx, dg, db, None, None, None, (dz if has_res else None), None, None, None, None, None
 
 
@@ -807,10 +825,9 @@ class _ConcatPE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dtok):
         b, t, cf, cp = ctx.cfg
-        dtok = dtok.contiguous()
-        df = torch.empty((b, t, cf), device=dtok.device)
-        _lib.call("focr_slice_cols", _p(dtok), _NULL, _p(df), b * t, cf + cp, 0, cf, _stream())
-        return df, None
+        # the feature half as a VIEW: the consumer (the BatchNorm backward of the block's second convolution) reads it
+        # through its row pitch; any other consumer gathers it with its own .contiguous()
+        return dtok.contiguous()[:, :, :cf], None
 
 
 def concat_pe(feat, pe):

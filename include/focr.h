@@ -170,8 +170,10 @@ int focr_bn_eval_fwd(const float* x, const float* gamma, const float* beta, cons
                      long rows, int C, float eps, int act, focr_stream_t stream);
 int focr_bn_bwd(const float* dz, const float* x, const float* gamma, const float* beta, const float* mean,
                 const float* invstd, float* dx, float* dgamma, float* dbeta, float* ws, long rows, int C,
-                int act, int train, focr_stream_t stream);
-/* train = 0 (statistics were the running ones): dx = gamma * invstd * act'(.) dz; dgamma / dbeta / ws may be null
+                int act, int train, int lddz, focr_stream_t stream);
+/* lddz: row pitch of dz in floats (0 = C): dz may be a column slice of a wider matrix (the gradient of the feature half
+ * of the [feature | positional encoding] token matrix, tbsrn.py:85).
+ * train = 0 (statistics were the running ones): dx = gamma * invstd * act'(.) dz; dgamma / dbeta / ws may be null
  * (frozen layer) or all given (trainable affine parameters under eval statistics). */
 long focr_bn_bwd_ws_floats(long rows, int C); /* workspace size (floats) of focr_bn_bwd */
 
