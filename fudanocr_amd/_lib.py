@@ -17,6 +17,7 @@ SIGNATURES = {
     "focr_conv2d_fwd": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, I, I, P],
     "focr_conv2d_fwd_ws": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, I, I, P, L, P],
     "focr_conv2d_fwd_ws_floats": [I, I, I, I, I, I, I, I, I],
+    "focr_linear_masked_fwd": [P, P, P, P, L, I, I, F, P],
     "focr_conv2d_wgrad": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, L, P],
     "focr_conv2d_wgrad_ws_floats": [I, I, I, I, I, I, I, I, I],
     "focr_weight_flip_transpose": [P, P, I, I, I, I, P],

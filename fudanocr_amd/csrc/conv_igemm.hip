@@ -407,7 +407,7 @@ int focr_conv9x9_cin3_fwd(const float* x, const float* w, const float* bias, con
                           float alpha, int relu, hipStream_t stream);
 int focr_linear_stream_bx3(const float* x, const float* w, const float* bias, const float* residual, float* y, int M,
                            int Cin, int Cout, int ldx, int ldy, int ldr, float alpha, int relu, uint32_t drop_k,
-                           float drop_scale, uint32_t drop_seed, hipStream_t stream);
+                           float drop_scale, uint32_t drop_seed, float mask_scale, hipStream_t stream);
 extern "C" int focr_dropout(const float* x, float* y, long n, float p, uint64_t seed, hipStream_t stream);
 
 static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, const float* residual, float* y, int N,
@@ -429,7 +429,7 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, co
   }
   if (vec && focr_get_precision() != 0 && KH == 1 && KW == 1 && padH == 0 && padW == 0 &&
       focr_linear_stream_bx3(x, w, bias, residual, y, g.M, Cin, Cout, g.ldx, g.ldy, g.ldr, alpha, relu, 0u, 1.f, 0u,
-                             stream)) {
+                             0.f, stream)) {
     FOCR_LAUNCH_CHECK();
     return FOCR_OK;
   }
@@ -490,13 +490,31 @@ extern "C" int focr_linear_relu_dropout_fwd(const float* x, const float* w, cons
   *keep_scale = 65536.f / (float)kq;
   if (focr_get_precision() != 0 && rows < (1l << 31) &&
       focr_linear_stream_bx3(x, w, bias, nullptr, y, (int)rows, Cin, Cout, Cin, Cout, Cout, alpha, 1, kq, *keep_scale,
-                             (uint32_t)(seed ^ (seed >> 32)), stream)) {
+                             (uint32_t)(seed ^ (seed >> 32)), 0.f, stream)) {
     FOCR_LAUNCH_CHECK();
     return FOCR_OK;
   }
   int rc = focr_conv2d_fwd(x, w, bias, nullptr, y, (int)rows, 1, 1, Cin, Cout, 1, 1, 0, 0, alpha, 1, 0, 0, 0, stream);
   if (rc != FOCR_OK) return rc;
   return focr_dropout(y, y, rows * Cout, 1.f - (float)kq / 65536.f, seed, stream);
+}
+
+// g = (h > 0) ? scale * (dy W^T) : 0 -- the data gradient of a Linear whose INPUT h is the output of a relu (or fused
+// relu + dropout: dropped elements are the zeros of h) Linear, with that producer's relu backward fused into the epilogue
+// (one pass instead of dgrad + relu_bwd_scaled: the intermediate dy_h is never written).  w: [Cout][Cin] as for
+// focr_conv2d_fwd (i.e. the TRANSPOSED weight of the layer whose data gradient this is).  FOCR_EUNSUPPORTED when the
+// streaming kernel does not take the shape (the caller then runs the two passes).
+extern "C" int focr_linear_masked_fwd(const float* x, const float* w, const float* mask_src, float* y, long rows,
+                                      int Cin, int Cout, float scale, hipStream_t stream) {
+  FOCR_CHECK_ARG(x && w && mask_src && y && rows > 0 && scale != 0.f, "bad argument");
+  if (focr_get_precision() != 0 && rows < (1l << 31) &&
+      focr_linear_stream_bx3(x, w, nullptr, mask_src, y, (int)rows, Cin, Cout, Cin, Cout, Cout, 1.f, 0, 0u, 1.f, 0u, scale,
+                             stream)) {
+    FOCR_LAUNCH_CHECK();
+    return FOCR_OK;
+  }
+  focr_set_error("focr_linear_masked_fwd: shape not taken by the streaming kernel");
+  return FOCR_EUNSUPPORTED;
 }
 
 // dw must hold Cout*KH*KW*Cin floats, dbias (nullable) Cout floats.  The kernel ACCUMULATES with fp32

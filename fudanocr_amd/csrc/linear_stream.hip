@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256, 2) void linear_stream_bx3_kernel(const float* 
                                                                    const float* __restrict__ R, float* __restrict__ Y,
                                                                    int M, int Cout, int ldx, int ldy, int ldr,
                                                                    float alpha, int relu, uint32_t drop_k,
-                                                                   float drop_scale, uint32_t drop_seed) {
+                                                                   float drop_scale, uint32_t drop_seed,
+                                                                   float mask_scale) {
   constexpr int KP = K + 8;            // bf16 pitch: conflict-free ds_read_b128 fragment reads
   constexpr int Q = K / 4;             // float4 per weight row
   constexpr int KS = K / 16;           // MFMA k-steps
@@ -156,7 +157,9 @@ __global__ __launch_bounds__(256, 2) void linear_stream_bx3_kernel(const float* 
           const int p = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           if (p < M) {
             float v = alpha * acc[u][r] + bv[ng + u];
-            if (HAS_RES) v += rv[u][r];
+            // mask_scale != 0: R is not added but GATES the result (relu / relu-dropout backward fused into the data
+            // gradient of the FOLLOWING linear: g = (h > 0) ? scale * (dy W) : 0, R = h)
+            if (HAS_RES) v = mask_scale != 0.f ? (rv[u][r] > 0.f ? v * mask_scale : 0.f) : v + rv[u][r];
             if (relu) v = fmaxf(v, 0.f);
             if (HAS_DROP) v = ((keep >> (u * 16 + r)) & 1u) ? v * drop_scale : 0.f;
             Y[(size_t)p * ldy + co] = v;
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void linear_stream_bx3_kernel(const float* 
 template <int K, int NT, bool HAS_RES, bool HAS_DROP>
 static int launch_ls_(const float* x, const float* w, const float* bias, const float* r, float* y, int M, int Cout,
                       int ldx, int ldy, int ldr, float alpha, int relu, uint32_t drop_k, float drop_scale,
-                      uint32_t drop_seed, hipStream_t stream) {
+                      uint32_t drop_seed, float mask_scale, hipStream_t stream) {
   const size_t lds = (size_t)2 * 32 * NT * (K + 8) * sizeof(__bf16);
   static bool attr_set = false;
   if (!attr_set) {
@@ -185,21 +188,24 @@ static int launch_ls_(const float* x, const float* w, const float* bias, const f
   if (nb > cdiv(ntiles, 4)) nb = cdiv(ntiles, 4);
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL((linear_stream_bx3_kernel<K, NT, HAS_RES, HAS_DROP>), dim3(nb, ny), 256, lds, stream, x, w, bias,
-                     r, y, M, Cout, ldx, ldy, ldr, alpha, relu, drop_k, drop_scale, drop_seed);
+                     r, y, M, Cout, ldx, ldy, ldr, alpha, relu, drop_k, drop_scale, drop_seed, mask_scale);
   return 1;
 }
 
 template <int K, int NT>
 static int launch_ls(const float* x, const float* w, const float* bias, const float* r, float* y, int M, int Cout,
                      int ldx, int ldy, int ldr, float alpha, int relu, uint32_t drop_k, float drop_scale,
-                     uint32_t drop_seed, hipStream_t stream) {
+                     uint32_t drop_seed, float mask_scale, hipStream_t stream) {
   if (drop_k) {
     if (r) return 0;                                   // dropout + residual: not built
     return launch_ls_<K, NT, false, true>(x, w, bias, r, y, M, Cout, ldx, ldy, ldr, alpha, relu, drop_k, drop_scale,
-                                          drop_seed, stream);
+                                          drop_seed, 0.f, stream);
   }
-  return r ? launch_ls_<K, NT, true, false>(x, w, bias, r, y, M, Cout, ldx, ldy, ldr, alpha, relu, 0u, 1.f, 0u, stream)
-           : launch_ls_<K, NT, false, false>(x, w, bias, r, y, M, Cout, ldx, ldy, ldr, alpha, relu, 0u, 1.f, 0u, stream);
+  if (mask_scale != 0.f && !r) return 0;
+  return r ? launch_ls_<K, NT, true, false>(x, w, bias, r, y, M, Cout, ldx, ldy, ldr, alpha, relu, 0u, 1.f, 0u, mask_scale,
+                                            stream)
+           : launch_ls_<K, NT, false, false>(x, w, bias, r, y, M, Cout, ldx, ldy, ldr, alpha, relu, 0u, 1.f, 0u, 0.f,
+                                             stream);
 }
 
 #ifndef LS_MIN_ROWS
@@ -209,18 +215,18 @@ static int launch_ls(const float* x, const float* w, const float* bias, const fl
 // used by focr_conv2d_fwd (conv_igemm.hip) for 1x1 layers; returns 1 if the layer was handled here
 int focr_linear_stream_bx3(const float* x, const float* w, const float* bias, const float* residual, float* y, int M,
                            int Cin, int Cout, int ldx, int ldy, int ldr, float alpha, int relu, uint32_t drop_k,
-                           float drop_scale, uint32_t drop_seed, hipStream_t stream) {
+                           float drop_scale, uint32_t drop_seed, float mask_scale, hipStream_t stream) {
   if (M < LS_MIN_ROWS || ldx % 4 || Cout % 32) return 0;
   if (Cin == 128) {
     if (Cout % 128 == 0) return launch_ls<128, 4>(x, w, bias, residual, y, M, Cout, ldx, ldy, ldr, alpha, relu, drop_k, drop_scale,
-                                                 drop_seed, stream);
+                                                 drop_seed, mask_scale, stream);
     if (Cout % 64 == 0) return launch_ls<128, 2>(x, w, bias, residual, y, M, Cout, ldx, ldy, ldr, alpha, relu, drop_k, drop_scale,
-                                                 drop_seed, stream);
+                                                 drop_seed, mask_scale, stream);
   } else if (Cin == 64) {
     if (Cout % 128 == 0) return launch_ls<64, 4>(x, w, bias, residual, y, M, Cout, ldx, ldy, ldr, alpha, relu, drop_k, drop_scale,
-                                                 drop_seed, stream);
+                                                 drop_seed, mask_scale, stream);
     if (Cout % 64 == 0) return launch_ls<64, 2>(x, w, bias, residual, y, M, Cout, ldx, ldy, ldr, alpha, relu, drop_k, drop_scale,
-                                                 drop_seed, stream);
+                                                 drop_seed, mask_scale, stream);
   }
   return 0;
 }

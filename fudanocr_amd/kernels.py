@@ -13,6 +13,7 @@ import math
 import threading
 import weakref
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -83,6 +84,7 @@ class StepContext:
 
     def __init__(self, managed_frags=False):
         self.deferred = {}
+        self.premasked = {}              # data_ptr of gradients whose relu backward a consumer's dgrad already applied
         self.flips = None                # FlipTable while an engine step's backward runs
         self.frags = None                # managed FragTable while an engine step runs (None: the default table)
         self.side_enabled = False
@@ -143,6 +145,7 @@ class StepContext:
         return self.deferred.pop(_dkey(t), None)
 
     def check_deferred(self):
+        self.premasked.clear()
         if self.deferred:
             self.deferred.clear()
             raise RuntimeError("fudanocr_amd: a deferred residual gradient was never consumed by its GEMM backward")
@@ -401,13 +404,16 @@ class _Conv2d(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, pad, alpha, relu, drop_p=0.0, take_deferred=False,
-                defer_residual=False, want_stats=False):
+                defer_residual=False, want_stats=False, in_relu_scale=0.0):
         """want_stats (halo-kernel layers only): also returns the per-tile (sum, sum of squares) partials of y
         [tiles, Cout, 2] for a following train-mode BatchNorm (non-differentiable second output)."""
         cout = weight.shape[0]
         ctx.step = step = current_context()
         ctx.take_deferred, ctx.defer_residual = bool(take_deferred), bool(defer_residual)
         ctx.res_key = _dkey(residual) if (residual is not None and defer_residual) else None
+        # x is the output h of a relu / relu-dropout Linear (scale = its 1 / P(keep)): this layer's data gradient can
+        # apply that producer's relu backward in its epilogue (see backward)
+        ctx.in_relu_scale = float(in_relu_scale)
         if weight.dim() == 2:
             kh = kw = 1
             ph = pw = 0
@@ -458,7 +464,9 @@ class _Conv2d(torch.autograd.Function):
         cout = weight.shape[0]
         oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
         dy4 = dy.contiguous().reshape(n, oh, ow, cout)
-        if relu:
+        if relu and step.premasked.pop(dy4.data_ptr(), None) is not None:
+            pass        # the consumer's data-gradient kernel already applied (y > 0) * scale in its epilogue
+        elif relu:
             g = torch.empty_like(dy4)
             if ctx.drop_scale:        # relu + fused dropout: the dropped elements are the zeros of y
                 _lib.call("focr_relu_bwd_scaled", _p(dy4), _p(y), _p(g), dy4.numel(), ctx.drop_scale, _stream())
@@ -516,7 +524,29 @@ class _Conv2d(torch.autograd.Function):
             radd = step.take_deferred(x4) if ctx.take_deferred else None  # parked residual gradient of x: + in the epilogue
             if radd is not None:
                 radd = radd.reshape(-1, cin)
-            if _halo_ok(oh, ow, cout, cin, kh, kw, kh - 1 - ph, kw - 1 - pw):
+            fused_mask = False
+            if (ctx.in_relu_scale != 0.0 and radd is None and kh == 1 and kw == 1 and alpha == 1.0
+                    and weight.dim() == 2 and x4.is_contiguous()):
+                # dx = (x > 0) ? scale * (dy W) : 0 in ONE pass: the relu(-dropout) backward of the layer that produced
+                # x rides in this data gradient's epilogue; that layer's backward finds dx in step.premasked and skips
+                # its own relu pass (no intermediate dy_x is written or re-read)
+                persistent = weight.is_leaf and wk.data_ptr() == weight.data_ptr()
+                wd = step.flips.lookup(wk, cout, kh, kw, cin, not weight.requires_grad) \
+                    if (step.flips is not None and persistent) else None
+                if wd is None:
+                    wd = torch.empty(wk.numel(), device=dy.device, dtype=torch.float32)
+                    _lib.call("focr_weight_flip_transpose", _p(wk), _p(wd), cout, kh, kw, cin, _stream())
+                dx4 = torch.empty_like(x4)
+                rc = _lib.load().focr_linear_masked_fwd(_p(dy4), _p(wd), _p(x4), _p(dx4), dy4.numel() // cout, cout, cin,
+                                                        ctypes.c_float(ctx.in_relu_scale), _stream())
+                if rc == 0:
+                    fused_mask = True
+                    step.premasked[dx4.data_ptr()] = True
+                elif rc != -2:
+                    raise RuntimeError("focr_linear_masked_fwd failed: " + _lib.load().focr_last_error().decode())
+            if fused_mask:
+                pass
+            elif _halo_ok(oh, ow, cout, cin, kh, kw, kh - 1 - ph, kw - 1 - pw):
                 # data gradient on the halo kernel: flipped weights in fragment order; a single bf16 product under
                 # precision mode 3 (csrc/focr_core.hip), split products otherwise
                 wf = _frag_weights(step, weight, wk, cout, kh, kw, cin, True)
@@ -538,7 +568,7 @@ class _Conv2d(torch.autograd.Function):
             dw = None
         if tb is not None:
             db = None
-        return dx, dw, db, dres, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias=None, pad=(0, 0), residual=None, alpha=1.0, relu=False, take_deferred=False):
@@ -549,8 +579,14 @@ def linear(x, weight, bias=None, residual=None, alpha=1.0, relu=False, dropout=0
            defer_residual=False):
     """x [..., In] @ weight[Out, In]^T (+bias) (+residual) (relu) (dropout with probability `dropout`, relu only).
     take_deferred / defer_residual: see the deferred residual gradients note above."""
-    return _Conv2d.apply(x, weight, bias, residual, (0, 0), alpha, relu, float(dropout), take_deferred,
-                         defer_residual)
+    out = _Conv2d.apply(x, weight, bias, residual, (0, 0), alpha, relu, float(dropout), take_deferred,
+                        defer_residual, False, float(getattr(x, "_focr_relu_scale", 0.0)))
+    if relu and residual is None and torch.is_grad_enabled():
+        # tag the output: a Linear that consumes it directly can fuse this layer's relu(-dropout) backward into its
+        # data-gradient epilogue (scale = 1 / P(keep), the float32 value focr_linear_relu_dropout_fwd reports)
+        kq = 65536 - int(float(dropout) * 65536.0 + 0.5) if dropout > 0 else 65536
+        out._focr_relu_scale = float(np.float32(65536.0) / np.float32(kq))
+    return out
 
 
 # ----------------------------------------------------------------------------------------

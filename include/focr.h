@@ -74,6 +74,12 @@ int focr_conv2d_fwd_ws(const float* x, const float* w, const float* bias, const 
 int focr_linear_relu_dropout_fwd(const float* x, const float* w, const float* bias, float* y, long rows, int Cin,
                                  int Cout, float alpha, float p_drop, uint64_t seed, float* keep_scale,
                                  focr_stream_t stream);
+/* g = (mask_src > 0) ? scale * (x W^T) : 0: the data gradient of a Linear whose input h = mask_src came out of a relu
+ * (or fused relu + dropout) Linear, with that producer's relu backward in the epilogue (w: [Cout][Cin], the transposed
+ * weight of the layer whose data gradient this is).  Returns FOCR_EUNSUPPORTED (-2) for shapes the streaming kernel
+ * does not take; the caller then runs focr_conv2d_fwd + focr_relu_bwd_scaled. */
+int focr_linear_masked_fwd(const float* x, const float* w, const float* mask_src, float* y, long rows, int Cin,
+                           int Cout, float scale, focr_stream_t stream);
 /* dw[Cout][KH][KW][Cin], dbias[Cout] (nullable); ldd = row pitch of dy (0: Cout).  Gradient outputs of
  * every *_wgrad/_bwd entry are accumulated with atomics: prezeroed=0 clears them first (overwrite),
  * prezeroed=1 means the caller guarantees zeros (slices of a gradient buffer cleared once per step). */

@@ -917,3 +917,36 @@ def test_attention_premasked_equals_seeded():
         assert o3.shape == (1, 128, d) and torch.isfinite(o3).all()
     kept = (o2 != 0).float().mean().item()
     assert kept > 0.99                                             # outputs are sums over keys: dropout never zeroes them all
+
+
+def test_ffn_relu_backward_fused_into_consumer_dgrad(precision):
+    """w_2(dropout(relu(w_1 x))): the data gradient of w_2 applies the relu-dropout backward of w_1's output in its
+    epilogue (focr_linear_masked_fwd) and w_1's backward skips its own relu pass -- gradients equal the unfused chain
+    (same dropout mask: recovered from the zeros of h), and nothing is left in the context afterwards"""
+    if precision == 0:
+        pytest.skip("streaming kernels are bf16x3 only")
+    k = K()
+    rows, d = 20000, 128
+    x = dev(rnd(rows, d, seed=1)).requires_grad_(True)
+    w1, b1 = dev(rnd(d, d, seed=2, scale=1 / math.sqrt(d))).requires_grad_(True), dev(rnd(d, seed=3)).requires_grad_(True)
+    w2, b2 = dev(rnd(d, d, seed=4, scale=1 / math.sqrt(d))).requires_grad_(True), dev(rnd(d, seed=5)).requires_grad_(True)
+    gy = dev(rnd(rows, d, seed=6))
+    c = k.StepContext()
+    with k.use_context(c):
+        h = k.linear(x, w1, b1, relu=True, dropout=0.1)
+        assert h._focr_relu_scale > 1.0
+        y = k.linear(h, w2, b2)
+        y.backward(gy)
+    assert not c.premasked
+    c.check_deferred()
+    # reference through the same mask
+    hd = h.detach().cpu().double()
+    mask = (hd > 0).double() * h._focr_relu_scale
+    xr, w1r, b1r, w2r, b2r = (t.detach().cpu().double().requires_grad_(True) for t in (x, w1, b1, w2, b2))
+    hr = torch.relu(xr @ w1r.t() + b1r) * mask
+    yr = hr @ w2r.t() + b2r
+    yr.backward(gy.cpu().double())
+    close(x.grad, xr.grad, ptol(precision), what="fused ffn dx")
+    close(w1.grad, w1r.grad, ptol(precision, 5e-5), what="fused ffn dw1")
+    close(b1.grad, b1r.grad, 5e-5, what="fused ffn db1")
+    close(w2.grad, w2r.grad, ptol(precision, 5e-5), what="fused ffn dw2")
