@@ -211,9 +211,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     float4 m4 = *reinterpret_cast<const float4*>(mean + col * 4), i4 = *reinterpret_cast<const float4*>(invstd + col * 4);
     const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
     const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ii[4] = {i4.x, i4.y, i4.z, i4.w};
-    for (long r = r0 + rl; r < r1; r += rl_n) {
-      float4 xv = *reinterpret_cast<const float4*>(x + r * C + col * 4);
-      float4 dv = *reinterpret_cast<const float4*>(dz + r * lddz + col * 4);
+    const float* xp = x + (r0 + rl) * C + col * 4;
+    const float* dp = dz + (r0 + rl) * lddz + col * 4;
+    const long xstep = (long)rl_n * C, dstep = (long)rl_n * lddz;
+    for (long r = r0 + rl; r < r1; r += rl_n, xp += xstep, dp += dstep) {
+      float4 xv = *reinterpret_cast<const float4*>(xp);
+      float4 dv = *reinterpret_cast<const float4*>(dp);
       const float xx[4] = {xv.x, xv.y, xv.z, xv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
