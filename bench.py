@@ -190,6 +190,8 @@ def main():
                          "additionally runs the halo-kernel data-gradient convolutions and the attention-backward "
                          "accumulations as single bf16 products; bf16x3 = mode 2; bf16x3-allsplit = mode 1; fp32 = "
                          "exact fp32 MFMA (mode 0)")
+    ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE",
+                    help="A/B kernel-selection switch (focr_set_tuning, include/focr.h); reported in config.tuning")
     args = ap.parse_args()
     cfg = args.config
     if args.arch == "tsrn" and cfg == "c3":
@@ -220,6 +222,9 @@ def main():
     _lib.load()
     mode = {"bf16x3-dgrad16": 3, "bf16x3": 2, "bf16x3-allsplit": 1, "fp32": 0}[args.precision]
     _lib.set_precision(mode)
+    for kv in args.tuning:
+        k_, v_ = kv.split("=")
+        _lib.call("focr_set_tuning", int(k_), int(v_))
     side = os.environ.get("FOCR_WGRAD_SIDE", "1") != "0"
     if cfg == "c5":
         from fudanocr_amd.sld import util as sld_util

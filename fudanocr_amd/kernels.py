@@ -31,7 +31,14 @@ def _po(t, off):
     return ctypes.c_void_p(t.data_ptr() + 4 * off)
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """the current HIP stream of the current device as a C pointer.  (torch.cuda.current_stream() builds a Stream object
+    through three Python layers: ~9 us, 270 times per step; the raw getter is one C call.)"""
+    if _RAW_STREAM is not None:
+        return ctypes.c_void_p(_RAW_STREAM(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
