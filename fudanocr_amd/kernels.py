@@ -583,14 +583,19 @@ def conv2d(x, weight, bias=None, pad=(0, 0), residual=None, alpha=1.0, relu=Fals
 
 
 def linear(x, weight, bias=None, residual=None, alpha=1.0, relu=False, dropout=0.0, take_deferred=False,
-           defer_residual=False):
+           defer_residual=False, fuse_input_relu=False):
     """x [..., In] @ weight[Out, In]^T (+bias) (+residual) (relu) (dropout with probability `dropout`, relu only).
-    take_deferred / defer_residual: see the deferred residual gradients note above."""
+    take_deferred / defer_residual: see the deferred residual gradients note above.
+    fuse_input_relu: x is the output of a relu / relu-dropout `linear` AND THIS CALL IS ITS ONLY CONSUMER (the model
+    code knows the wiring, as with the deferred residuals): the data gradient of this layer applies that producer's
+    relu backward in its epilogue and the producer's backward skips its own pass.  With a second consumer autograd
+    would sum a masked and an unmasked gradient and the producer would scale twice -- hence opt-in, never inferred."""
+    scale = float(getattr(x, "_focr_relu_scale", 0.0)) if fuse_input_relu else 0.0
     out = _Conv2d.apply(x, weight, bias, residual, (0, 0), alpha, relu, float(dropout), take_deferred,
-                        defer_residual, False, float(getattr(x, "_focr_relu_scale", 0.0)))
+                        defer_residual, False, scale)
     if relu and residual is None and torch.is_grad_enabled():
-        # tag the output: a Linear that consumes it directly can fuse this layer's relu(-dropout) backward into its
-        # data-gradient epilogue (scale = 1 / P(keep), the float32 value focr_linear_relu_dropout_fwd reports)
+        # the output carries its 1 / P(keep) (the float32 value focr_linear_relu_dropout_fwd reports) for a consumer
+        # that opts in with fuse_input_relu
         kq = 65536 - int(float(dropout) * 65536.0 + 0.5) if dropout > 0 else 65536
         out._focr_relu_scale = float(np.float32(65536.0) / np.float32(kq))
     return out

@@ -28,9 +28,10 @@ class Conv2d(nn.Conv2d):
 
 
 class Linear(nn.Linear):
-    def forward(self, x, residual=None, relu=False, alpha=1.0, dropout=0.0, take_deferred=False, defer_residual=False):
+    def forward(self, x, residual=None, relu=False, alpha=1.0, dropout=0.0, take_deferred=False, defer_residual=False,
+                fuse_input_relu=False):
         return K.linear(x, self.weight, self.bias, residual=residual, relu=relu, alpha=alpha, dropout=dropout,
-                        take_deferred=take_deferred, defer_residual=defer_residual)
+                        take_deferred=take_deferred, defer_residual=defer_residual, fuse_input_relu=fuse_input_relu)
 
 
 class _BNMixin:

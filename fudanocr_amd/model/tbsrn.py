@@ -87,7 +87,8 @@ class PositionwiseFeedForward(nn.Module):
     def forward(self, x, take_deferred=False):
         # Dropout(relu(w_1 x)) in one kernel: the dropout is part of the GEMM epilogue (and of its relu backward)
         p = self.dropout.p if self.dropout.training else 0.0
-        return self.w_2(self.w_1(x, relu=True, dropout=p, take_deferred=take_deferred))
+        # h has exactly one consumer (w_2): its relu-dropout backward rides in w_2's data-gradient epilogue
+        return self.w_2(self.w_1(x, relu=True, dropout=p, take_deferred=take_deferred), fuse_input_relu=True)
 
 
 class FeatureEnhancer(nn.Module):

@@ -935,7 +935,7 @@ def test_ffn_relu_backward_fused_into_consumer_dgrad(precision):
     with k.use_context(c):
         h = k.linear(x, w1, b1, relu=True, dropout=0.1)
         assert h._focr_relu_scale > 1.0
-        y = k.linear(h, w2, b2)
+        y = k.linear(h, w2, b2, fuse_input_relu=True)
         y.backward(gy)
     assert not c.premasked
     c.check_deferred()
@@ -950,3 +950,11 @@ def test_ffn_relu_backward_fused_into_consumer_dgrad(precision):
     close(w1.grad, w1r.grad, ptol(precision, 5e-5), what="fused ffn dw1")
     close(b1.grad, b1r.grad, 5e-5, what="fused ffn db1")
     close(w2.grad, w2r.grad, ptol(precision, 5e-5), what="fused ffn dw2")
+    # without the opt-in nothing is fused (a tensor with two consumers must not be): same gradients through two passes
+    x2 = x.detach().clone().requires_grad_(True)
+    h2 = k.linear(x2, w1.detach(), b1.detach(), relu=True)
+    (k.linear(h2, w2.detach(), None) + k.linear(h2, w2.detach(), None)).backward(gy)
+    xr2 = x.detach().cpu().double().requires_grad_(True)
+    hr2 = torch.relu(xr2 @ w1r.detach().t() + b1r.detach())
+    (2 * (hr2 @ w2r.detach().t())).backward(gy.cpu().double())
+    close(x2.grad, xr2.grad, ptol(precision), what="two-consumer relu linear dx")
