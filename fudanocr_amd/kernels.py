@@ -9,6 +9,7 @@ kernel wants, with the reference's state_dict shapes unchanged.
 """
 import contextlib
 import ctypes
+import os
 import math
 import threading
 import weakref
@@ -1145,6 +1146,20 @@ def bicubic_gray(x, ow=100):
 # ----------------------------------------------------------------------------------------
 # bidirectional LSTM (recurrent part; the input projection is a `linear`)
 # ----------------------------------------------------------------------------------------
+def _lstm_check(ws, batch):
+    """FOCR_LSTM_CHECK=1 (debugging / tests; synchronises): the persistent scan's blocks meet at step counters with a
+    BOUNDED spin; if the partners of a block were never scheduled (more persistent kernels resident than the GPU has
+    CUs, e.g. several processes sharing one device) the scan writes an error word instead of hanging -- read it."""
+    if os.environ.get("FOCR_LSTM_CHECK", "0") != "1":
+        return
+    ngroups = (batch + 31) // 32 * 2
+    if _lib.load().focr_get_tuning(2) != 1 or _lib.get_precision() == 0 or 8 * ngroups > 256:
+        return                                           # per-step launches: the flag words are not used
+    flags = ws[-1024:].view(torch.int32)                 # rnn.hip LP_FLAG_BYTES at the end of the workspace
+    if int(flags[ngroups].item()) != 0:
+        raise RuntimeError("persistent LSTM scan: a step-counter wait timed out (partner blocks not resident)")
+
+
 class _LSTMRecur(torch.autograd.Function):
     """gx: [rows, 2*4H] with row(t,b) = t*st_t + b*st_b;  returns hseq [T,B,2H].
     Gradients: gx always; W_hh / b_hh when they require one (trainable recognizer):
@@ -1161,6 +1176,7 @@ class _LSTMRecur(torch.autograd.Function):
         ws = torch.empty(_lib.load().focr_lstm_ws_bytes(t_len, batch, hid, 0), device=gx.device, dtype=torch.uint8)
         _lib.call("focr_lstm_bidir_fwd", _p(gx), _p(whh), _p(bhh), _p(hseq), _p(gates), _p(cseq), _p(ws), t_len,
                   batch, hid, st_t, st_b, _stream())
+        _lstm_check(ws, batch)
         ctx.cfg = (t_len, batch, hid, st_t, st_b, tuple(gx.shape))
         ctx.save_for_backward(whh, gates, cseq, hseq if (whh.requires_grad or bhh.requires_grad) else None)
         return hseq
@@ -1175,6 +1191,7 @@ class _LSTMRecur(torch.autograd.Function):
         ws = torch.empty(_lib.load().focr_lstm_ws_bytes(t_len, batch, hid, 1), device=dh.device, dtype=torch.uint8)
         _lib.call("focr_lstm_bidir_bwd", _p(dh), _p(whh), _p(gates), _p(cseq), _p(dgx), _p(carry), _p(ws), t_len,
                   batch, hid, st_t, st_b, _stream())
+        _lstm_check(ws, batch)
         dwhh = dbhh = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             rows = t_len * batch

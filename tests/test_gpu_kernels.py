@@ -613,11 +613,12 @@ def test_lstm(b, precision):
 
 
 @pytest.mark.parametrize("b", [128, 70])
-def test_lstm_persistent_scan_equals_per_step_launches(b):
+def test_lstm_persistent_scan_equals_per_step_launches(b, monkeypatch):
     """rnn.hip persistent kernels (one launch walks all T steps; the 8 blocks that share a sequence block meet at a
     global counter every step) against the per-step launches of the same arithmetic: forward h and the data gradient
     agree to rounding (the K reduction is folded 2-way instead of 4-way), run twice = bit-identical (deterministic)"""
     from fudanocr_amd import _lib
+    monkeypatch.setenv("FOCR_LSTM_CHECK", "1")           # read the scan's time-out word after every launch
     k = K()
     t, hid = 26, 256
     gx0 = dev(rnd(t * b, 8 * hid, seed=1, scale=0.5))
