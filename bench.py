@@ -225,6 +225,10 @@ def main():
     for kv in args.tuning:
         k_, v_ = kv.split("=")
         _lib.call("focr_set_tuning", int(k_), int(v_))
+    if backend != "nccl" and world > 2:
+        # several ranks on ONE device (functional check only): the persistent LSTM scan needs all of its 64 blocks
+        # resident per process, which more than two processes on a 256-CU device cannot guarantee -> per-step launches
+        _lib.call("focr_set_tuning", 2, 0)
     side = os.environ.get("FOCR_WGRAD_SIDE", "1") != "0"
     if cfg == "c5":
         from fudanocr_amd.sld import util as sld_util
