@@ -282,3 +282,16 @@ def test_integration_recipe_module_level(tmp_path, golden_dir):
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def test_row_pitch_helper():
+    """kernels._row_pitch: which gradient views the BatchNorm backward may read in place through a row pitch"""
+    from fudanocr_amd import kernels as K
+    t = torch.zeros(4, 1024, 128)
+    assert K._row_pitch(t) == 0                                   # plainly contiguous: no pitch needed
+    assert K._row_pitch(t[:, :, :64]) == 128                      # feature half of [feature | PE] tokens
+    assert K._row_pitch(t[:, :, 64:]) == 128                      # offset 256 B: still 16-byte aligned
+    assert K._row_pitch(t[:, :, 2:66]) == 0                       # 8-byte offset: float4 loads would be misaligned
+    assert K._row_pitch(t[:, ::2, :64]) == 0                      # rows do not collapse to one stride
+    assert K._row_pitch(t.transpose(1, 2)) == 0                   # last dim not dense
+    assert K._row_pitch(torch.zeros(8, 130)[:, :64]) == 0         # pitch not a multiple of 4 floats
