@@ -292,6 +292,7 @@ def test_row_pitch_helper():
     assert K._row_pitch(t[:, :, :64]) == 128                      # feature half of [feature | PE] tokens
     assert K._row_pitch(t[:, :, 64:]) == 128                      # offset 256 B: still 16-byte aligned
     assert K._row_pitch(t[:, :, 2:66]) == 0                       # 8-byte offset: float4 loads would be misaligned
-    assert K._row_pitch(t[:, ::2, :64]) == 0                      # rows do not collapse to one stride
+    assert K._row_pitch(t[:, ::2, :64]) == 256                    # every other row: still ONE uniform row stride
+    assert K._row_pitch(t[:, :500, :64]) == 0                     # batch stride != rows x pitch: does not collapse
     assert K._row_pitch(t.transpose(1, 2)) == 0                   # last dim not dense
     assert K._row_pitch(torch.zeros(8, 130)[:, :64]) == 0         # pitch not a multiple of 4 floats
