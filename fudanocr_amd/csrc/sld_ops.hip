@@ -226,8 +226,12 @@ extern "C" int focr_adadelta(float* p, const float* g, float* sq, float* acc, lo
 
 // ------------------------------------------------------------------------------------------------- attention
 // q [B, Lq, H*Dk] (row pitch ldq), k / v [B, Lk, H*Dk] (pitch ldk); head h = columns h*Dk .. h*Dk + Dk - 1.
-// One workgroup (256 threads) per (b, h).  P (softmax, before dropout) and Pd (after dropout: what multiplies V and
-// what the reference returns as the attention map) are written [B, H, Lq, Lk] for the backward.
+// The problems are tiny (B*H = 128 .. 512 heads, Lq <= ~40 queries, Lk <= 256 keys): what matters is to spread them
+// over the chip.  One workgroup (256 threads) per (b, h, QUERY ROW): 4 .. 20 thousand blocks instead of B*H blocks that
+// walk their rows one after the other (round 2, first version: 546 us forward / 1243 us backward at B = 32, 9 % and 12 % of
+// the SLD step for 0.1 % of its flops).
+// P (softmax, before dropout) and Pd (after dropout: what multiplies V and what the reference returns as the attention
+// map) are written [B, H, Lq, Lk] for the backward.
 // causal: key j visible to query i iff j <= i (subsequent_mask, transformer.py:203-207).
 #define SA_LKMAX 256
 template <int DK>
@@ -240,119 +244,122 @@ __global__ __launch_bounds__(256) void small_attn_fwd_kernel(const float* __rest
   __shared__ float qs[DK];
   __shared__ float ps[SA_LKMAX];
   __shared__ float red[4];
-  const int b = blockIdx.x / H, h = blockIdx.x % H, tid = threadIdx.x;
+  const int b = blockIdx.x / H, h = blockIdx.x % H, i = blockIdx.y, tid = threadIdx.x;
   const float* qb = Q + (size_t)b * Lq * ldq + h * DK;
   const float* kb = K + (size_t)b * Lk * ldk + h * DK;
   const float* vb = V + (size_t)b * Lk * ldk + h * DK;
   float* ob = O + (size_t)b * Lq * ldo + h * DK;
   const size_t pbase = ((size_t)b * H + h) * Lq * Lk;
-  for (int i = 0; i < Lq; ++i) {
-    __syncthreads();
-    for (int d = tid; d < DK; d += 256) qs[d] = qb[(size_t)i * ldq + d];
-    __syncthreads();
-    // scores: thread = key
-    float s = -1e30f;
-    if (tid < Lk && (!causal || tid <= i)) {
-      const float4* kr = reinterpret_cast<const float4*>(kb + (size_t)tid * ldk);
-      float acc = 0.f;
+  for (int d = tid; d < DK; d += 256) qs[d] = qb[(size_t)i * ldq + d];
+  __syncthreads();
+  // scores: thread = key
+  float s = -1e30f;
+  if (tid < Lk && (!causal || tid <= i)) {
+    const float4* kr = reinterpret_cast<const float4*>(kb + (size_t)tid * ldk);
+    float acc = 0.f;
 #pragma unroll 8
-      for (int d4 = 0; d4 < DK / 4; ++d4) {
-        const float4 kv = kr[d4];
-        acc += qs[4 * d4] * kv.x + qs[4 * d4 + 1] * kv.y + qs[4 * d4 + 2] * kv.z + qs[4 * d4 + 3] * kv.w;
-      }
-      s = acc * scale;
+    for (int d4 = 0; d4 < DK / 4; ++d4) {
+      const float4 kv = kr[d4];
+      acc += qs[4 * d4] * kv.x + qs[4 * d4 + 1] * kv.y + qs[4 * d4 + 2] * kv.z + qs[4 * d4 + 3] * kv.w;
     }
-    float mx = wave_max(s);
-    __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    const float e = s > -1e29f ? expf(s - mx) : 0.f;
-    const float sum = block_sum256(e, red);
-    const float p = e / sum;
-    float pd = p;
-    if (drop_thr) {
-      const uint32_t r = rng_hash(seed, (pbase + (size_t)i * Lk + tid)) >> 16;
-      pd = r < drop_thr ? 0.f : p * keep_scale;
-    }
-    if (tid < Lk) {
-      P[pbase + (size_t)i * Lk + tid] = p;
-      Pd[pbase + (size_t)i * Lk + tid] = pd;
-      ps[tid] = pd;
-    }
-    __syncthreads();
-    // output: thread = head dim
-    for (int d = tid; d < DK; d += 256) {
-      float acc = 0.f;
-      const int kend = causal ? i + 1 : Lk;
-      for (int j = 0; j < kend; ++j) acc += ps[j] * vb[(size_t)j * ldk + d];
-      ob[(size_t)i * ldo + d] = acc;
-    }
+    s = acc * scale;
+  }
+  float mx = wave_max(s);
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float e = s > -1e29f ? expf(s - mx) : 0.f;
+  const float sum = block_sum256(e, red);
+  const float p = e / sum;
+  float pd = p;
+  if (drop_thr) {
+    const uint32_t r = rng_hash(seed, (pbase + (size_t)i * Lk + tid)) >> 16;
+    pd = r < drop_thr ? 0.f : p * keep_scale;
+  }
+  if (tid < Lk) {
+    P[pbase + (size_t)i * Lk + tid] = p;
+    Pd[pbase + (size_t)i * Lk + tid] = pd;
+    ps[tid] = pd;
+  }
+  __syncthreads();
+  // output: thread = head dim
+  for (int d = tid; d < DK; d += 256) {
+    float acc = 0.f;
+    const int kend = causal ? i + 1 : Lk;
+    for (int j = 0; j < kend; ++j) acc += ps[j] * vb[(size_t)j * ldk + d];
+    ob[(size_t)i * ldo + d] = acc;
   }
 }
 
-// backward: dQ, dK, dV (overwritten).  dS[i][j] = P (dropmask/keep * dPd - sum_j Pd dPd) with dPd = dO . V.
+// backward, pass 1: block (b, h, query row i) -> dS[i][:] = P (dropmask/keep * dPd - sum_j Pd dPd) with dPd = dO . V
+// (+ the gradient arriving through the returned attention map), written to the workspace for pass 2, and dQ[i][:].
 template <int DK>
-__global__ __launch_bounds__(256) void small_attn_bwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
-                                                             const float* __restrict__ V, const float* __restrict__ dO,
-                                                             const float* __restrict__ P, const float* __restrict__ Pd,
-                                                             const float* __restrict__ dMap,   // nullable: d loss / d Pd
-                                                             float* __restrict__ dQ, float* __restrict__ dK,
-                                                             float* __restrict__ dV, float* __restrict__ dS, int H,
-                                                             int Lq, int Lk, int ldq, int ldk, int ldo, float scale,
-                                                             int causal) {
+__global__ __launch_bounds__(256) void small_attn_bwd_q_kernel(
+    const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ dO, const float* __restrict__ P,
+    const float* __restrict__ Pd, const float* __restrict__ dMap /* nullable: d loss / d Pd */, float* __restrict__ dQ,
+    float* __restrict__ dS, int H, int Lq, int Lk, int ldq, int ldk, int ldo, float scale, int causal) {
   __shared__ float gs[DK];
+  __shared__ float dss[SA_LKMAX];
   __shared__ float red[4];
-  const int b = blockIdx.x / H, h = blockIdx.x % H, tid = threadIdx.x;
-  const float* qb = Q + (size_t)b * Lq * ldq + h * DK;
+  const int b = blockIdx.x / H, h = blockIdx.x % H, i = blockIdx.y, tid = threadIdx.x;
   const float* kb = K + (size_t)b * Lk * ldk + h * DK;
   const float* vb = V + (size_t)b * Lk * ldk + h * DK;
   const float* gb = dO + (size_t)b * Lq * ldo + h * DK;
   const size_t pbase = ((size_t)b * H + h) * Lq * Lk;
-  float* ds = dS + pbase;                                  // workspace [B, H, Lq, Lk]
-  // phase A: dS rows
-  for (int i = 0; i < Lq; ++i) {
-    __syncthreads();
-    for (int d = tid; d < DK; d += 256) gs[d] = gb[(size_t)i * ldo + d];
-    __syncthreads();
-    float dpd = 0.f, p = 0.f, pd = 0.f;
-    const bool vis = tid < Lk && (!causal || tid <= i);
-    if (vis) {
-      const float4* vr = reinterpret_cast<const float4*>(vb + (size_t)tid * ldk);
-      float acc = 0.f;
+  for (int d = tid; d < DK; d += 256) gs[d] = gb[(size_t)i * ldo + d];
+  __syncthreads();
+  float dpd = 0.f, p = 0.f, pd = 0.f;
+  const bool vis = tid < Lk && (!causal || tid <= i);
+  if (vis) {
+    const float4* vr = reinterpret_cast<const float4*>(vb + (size_t)tid * ldk);
+    float acc = 0.f;
 #pragma unroll 8
-      for (int d4 = 0; d4 < DK / 4; ++d4) {
-        const float4 vv = vr[d4];
-        acc += gs[4 * d4] * vv.x + gs[4 * d4 + 1] * vv.y + gs[4 * d4 + 2] * vv.z + gs[4 * d4 + 3] * vv.w;
-      }
-      dpd = acc;
-      if (dMap) dpd += dMap[pbase + (size_t)i * Lk + tid];      // the attention map is an output too (text-focus L1 term)
-      p = P[pbase + (size_t)i * Lk + tid];
-      pd = Pd[pbase + (size_t)i * Lk + tid];
+    for (int d4 = 0; d4 < DK / 4; ++d4) {
+      const float4 vv = vr[d4];
+      acc += gs[4 * d4] * vv.x + gs[4 * d4 + 1] * vv.y + gs[4 * d4 + 2] * vv.z + gs[4 * d4 + 3] * vv.w;
     }
-    const float D = block_sum256(pd * dpd, red);
-    // dP = dPd * (Pd / P)  (Pd = P * mask / keep; P > 0 for every visible key)
-    const float dp = (vis && p > 0.f) ? dpd * (pd / p) : 0.f;
-    if (tid < Lk) ds[(size_t)i * Lk + tid] = vis ? p * (dp - D) : 0.f;
+    dpd = acc;
+    if (dMap) dpd += dMap[pbase + (size_t)i * Lk + tid];      // the attention map is an output too (text-focus L1 term)
+    p = P[pbase + (size_t)i * Lk + tid];
+    pd = Pd[pbase + (size_t)i * Lk + tid];
+  }
+  const float D = block_sum256(pd * dpd, red);
+  // dP = dPd * (Pd / P)  (Pd = P * mask / keep; P > 0 for every visible key)
+  const float dp = (vis && p > 0.f) ? dpd * (pd / p) : 0.f;
+  const float dsv = vis ? p * (dp - D) : 0.f;
+  if (tid < Lk) {
+    dS[pbase + (size_t)i * Lk + tid] = dsv;
+    dss[tid] = dsv;
   }
   __syncthreads();
-  // phase B: thread = head dim
-  for (int d = tid; d < DK; d += 256) {
-    for (int i = 0; i < Lq; ++i) {
-      float acc = 0.f;
-      const int kend = causal ? i + 1 : Lk;
-      for (int j = 0; j < kend; ++j) acc += ds[(size_t)i * Lk + j] * kb[(size_t)j * ldk + d];
-      dQ[(size_t)b * Lq * ldq + h * DK + (size_t)i * ldq + d] = acc * scale;
+  for (int d = tid; d < DK; d += 256) {                      // dQ row: thread = head dim
+    float acc = 0.f;
+    const int kend = causal ? i + 1 : Lk;
+    for (int j = 0; j < kend; ++j) acc += dss[j] * kb[(size_t)j * ldk + d];
+    dQ[(size_t)b * Lq * ldq + h * DK + (size_t)i * ldq + d] = acc * scale;
+  }
+}
+// backward, pass 2: block (b, h, SA_JT keys) -> dK[j][:], dV[j][:] (sums over the query rows in index order)
+#define SA_JT 8
+template <int DK>
+__global__ __launch_bounds__(256) void small_attn_bwd_kv_kernel(
+    const float* __restrict__ Q, const float* __restrict__ dO, const float* __restrict__ Pd, const float* __restrict__ dS,
+    float* __restrict__ dK, float* __restrict__ dV, int H, int Lq, int Lk, int ldq, int ldk, int ldo, float scale,
+    int causal) {
+  const int b = blockIdx.x / H, h = blockIdx.x % H, j0 = blockIdx.y * SA_JT, tid = threadIdx.x;
+  const float* qb = Q + (size_t)b * Lq * ldq + h * DK;
+  const float* gb = dO + (size_t)b * Lq * ldo + h * DK;
+  const size_t pbase = ((size_t)b * H + h) * Lq * Lk;
+  for (int idx = tid; idx < SA_JT * DK; idx += 256) {
+    const int j = j0 + idx / DK, d = idx % DK;
+    if (j >= Lk) continue;
+    float ak = 0.f, av = 0.f;
+    for (int i = causal ? j : 0; i < Lq; ++i) {
+      ak += dS[pbase + (size_t)i * Lk + j] * qb[(size_t)i * ldq + d];
+      av += Pd[pbase + (size_t)i * Lk + j] * gb[(size_t)i * ldo + d];
     }
-    for (int j = 0; j < Lk; ++j) {
-      float ak = 0.f, av = 0.f;
-      for (int i = causal ? j : 0; i < Lq; ++i) {
-        ak += ds[(size_t)i * Lk + j] * qb[(size_t)i * ldq + d];
-        av += Pd[pbase + (size_t)i * Lk + j] * gb[(size_t)i * ldo + d];
-      }
-      dK[(size_t)b * Lk * ldk + h * DK + (size_t)j * ldk + d] = ak * scale;
-      dV[(size_t)b * Lk * ldk + h * DK + (size_t)j * ldk + d] = av;
-    }
+    dK[(size_t)b * Lk * ldk + h * DK + (size_t)j * ldk + d] = ak * scale;
+    dV[(size_t)b * Lk * ldk + h * DK + (size_t)j * ldk + d] = av;
   }
 }
 
@@ -362,16 +369,16 @@ extern "C" int focr_small_attention_fwd(const float* q, const float* k, const fl
   FOCR_CHECK_ARG(q && k && v && o && p && pd, "null pointer");
   FOCR_CHECK_ARG((Dk == 256 || Dk == 64) && Lk > 0 && Lk <= SA_LKMAX && Lq > 0 && ldk % 4 == 0,
                  "need Dk in {64, 256}, Lk <= 256");
-  FOCR_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "bad dropout probability");
+  FOCR_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f && Lq <= 65535, "bad dropout probability / too many query rows");
   const uint32_t thr = (uint32_t)(p_drop * 65536.f + 0.5f);
   FOCR_CHECK_ARG(thr < 65536u, "dropout probability rounds to 1");
   const float ks = thr ? 65536.f / (65536.f - (float)thr) : 1.f;
   if (Dk == 64)
-    hipLaunchKernelGGL((small_attn_fwd_kernel<64>), dim3(B * H), 256, 0, stream, q, k, v, o, p, pd, H, Lq, Lk, ldq, ldk,
-                       ldo, scale, causal, thr, ks, seed);
+    hipLaunchKernelGGL((small_attn_fwd_kernel<64>), dim3(B * H, Lq), 256, 0, stream, q, k, v, o, p, pd, H, Lq, Lk, ldq,
+                       ldk, ldo, scale, causal, thr, ks, seed);
   else
-    hipLaunchKernelGGL((small_attn_fwd_kernel<256>), dim3(B * H), 256, 0, stream, q, k, v, o, p, pd, H, Lq, Lk, ldq, ldk,
-                       ldo, scale, causal, thr, ks, seed);
+    hipLaunchKernelGGL((small_attn_fwd_kernel<256>), dim3(B * H, Lq), 256, 0, stream, q, k, v, o, p, pd, H, Lq, Lk, ldq,
+                       ldk, ldo, scale, causal, thr, ks, seed);
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }
@@ -383,12 +390,19 @@ extern "C" int focr_small_attention_bwd(const float* q, const float* k, const fl
   FOCR_CHECK_ARG(q && k && v && d_o && p && pd && dq && dk && dv && ws, "null pointer");
   FOCR_CHECK_ARG((Dk == 256 || Dk == 64) && Lk > 0 && Lk <= SA_LKMAX && Lq > 0 && ldk % 4 == 0,
                  "need Dk in {64, 256}, Lk <= 256");
-  if (Dk == 64)
-    hipLaunchKernelGGL((small_attn_bwd_kernel<64>), dim3(B * H), 256, 0, stream, q, k, v, d_o, p, pd, dmap, dq, dk, dv,
-                       ws, H, Lq, Lk, ldq, ldk, ldo, scale, causal);
-  else
-    hipLaunchKernelGGL((small_attn_bwd_kernel<256>), dim3(B * H), 256, 0, stream, q, k, v, d_o, p, pd, dmap, dq, dk, dv,
-                       ws, H, Lq, Lk, ldq, ldk, ldo, scale, causal);
+  FOCR_CHECK_ARG(Lq <= 65535, "too many query rows for the launch grid");
+  const dim3 gq(B * H, Lq), gkv(B * H, (Lk + SA_JT - 1) / SA_JT);
+  if (Dk == 64) {
+    hipLaunchKernelGGL((small_attn_bwd_q_kernel<64>), gq, 256, 0, stream, k, v, d_o, p, pd, dmap, dq, ws, H, Lq, Lk, ldq,
+                       ldk, ldo, scale, causal);
+    hipLaunchKernelGGL((small_attn_bwd_kv_kernel<64>), gkv, 256, 0, stream, q, d_o, pd, (const float*)ws, dk, dv, H, Lq, Lk,
+                       ldq, ldk, ldo, scale, causal);
+  } else {
+    hipLaunchKernelGGL((small_attn_bwd_q_kernel<256>), gq, 256, 0, stream, k, v, d_o, p, pd, dmap, dq, ws, H, Lq, Lk, ldq,
+                       ldk, ldo, scale, causal);
+    hipLaunchKernelGGL((small_attn_bwd_kv_kernel<256>), gkv, 256, 0, stream, q, d_o, pd, (const float*)ws, dk, dv, H, Lq, Lk,
+                       ldq, ldk, ldo, scale, causal);
+  }
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }
