@@ -48,6 +48,12 @@ SIGNATURES = {
     "focr_concat_pe": [P, P, P, L, I, I, I, P],
     "focr_slice_cols": [P, P, P, L, I, I, I, P],
     "focr_dropout": [P, P, L, F, U, P],
+    "focr_fe_chain_supported": [L, I],
+    "focr_fe_post_fwd": [P] * 21 + [L, F, F, U, P, P],
+    "focr_fe_post_bwd": [P] * 7 + [F] + [P] * 9 + [L, F, P],
+    "focr_fe_qkv_dgrad": [P, P, P, P, L, P],
+    "focr_fe_wgrads_ws_floats": [L],
+    "focr_fe_wgrads": [P] * 31 + [L, L, P],
     "focr_mse_fwd": [P, P, P, L, P],
     "focr_mse_bwd": [P, P, P, P, L, P],
     "focr_axpy": [P, P, P, L, F, P],
@@ -129,6 +135,7 @@ def load():
     lib.focr_conv2d_fwd_ws_floats.restype = ctypes.c_long
     lib.focr_weight_frag_bytes.restype = ctypes.c_long
     lib.focr_psnr_ssim_ws_floats.restype = ctypes.c_long
+    lib.focr_fe_wgrads_ws_floats.restype = ctypes.c_long
     _lib = lib
     if os.environ.get("FOCR_PRECISION"):          # 0 fp32 | 1 bf16x3 | 2 (default) + bf16 attention-gradient sums | 3 + bf16 dgrad
         rc = lib.focr_set_precision(int(os.environ["FOCR_PRECISION"]))

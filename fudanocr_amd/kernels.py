@@ -963,6 +963,128 @@ def attention(q, k, v, heads=4, p_drop=0.0):
     return _Attention.apply(q, k, v, heads, p_drop, seed)
 
 
+# ----------------------------------------------------------------------------------------
+# The whole FeatureEnhancer as ONE autograd node (reference tbsrn.py:76-92).  Forward: concat-PE, packed QKV projection,
+# attention, then the two fused row chains of csrc/fe_chain.hip; backward: the two data-gradient chains, the attention
+# backward, the QKV data gradient restricted to the feature columns, and every parameter gradient of the block in one
+# library call on the weight-gradient side stream.  5 + 5 library calls instead of ~10 + ~25 autograd nodes, and the
+# intermediates between the row-local layers never touch HBM.
+# ----------------------------------------------------------------------------------------
+def fe_chain_supported(feat):
+    return bool(feat.is_cuda and feat.dtype == torch.float32 and feat.dim() == 3 and feat.shape[-1] == 64
+                and _lib.load().focr_fe_chain_supported(feat.shape[0] * feat.shape[1], 128))
+
+
+class _FeatureEnhancerFused(torch.autograd.Function):
+    N_PARAMS = 14          # wqkv bqkv wo bo a1 b1 w1 bb1 w2 bb2 a3 b3 wl bl
+
+    @staticmethod
+    def forward(ctx, feat, xres, pe, heads, p_attn, p_ffn, eps, defer_residual, *params):
+        wqkv, bqkv, wo, bo, a1, b1, w1, bb1, w2, bb2, a3, b3, wl, bl = params
+        ctx.step = step = current_context()
+        b, t, cf = feat.shape
+        rows, d = b * t, 128
+        _chk(feat, xres, pe, *params)
+        dev = feat.device
+        tok = torch.empty((b, t, d), device=dev)
+        _lib.call("focr_concat_pe", _p(feat), _p(pe), _p(tok), rows, cf, pe.shape[-1], t, _stream())
+        qkv = torch.empty((b, t, 3 * d), device=dev)
+        _lib.call("focr_conv2d_fwd", _p(tok), _p(wqkv), _p(bqkv), _NULL, _p(qkv), rows, 1, 1, d, 3 * d, 1, 1, 0, 0,
+                  1.0, 0, 0, 0, 0, _stream())
+        o = torch.empty((b, t, d), device=dev)
+        lse = torch.empty((b, heads, t), device=dev)
+        mask, ready = step.next_mask(b, heads, t, p_attn, dev) if p_attn > 0 else (None, False)
+        scale = 1.0 / math.sqrt(d // heads)
+        if ready:
+            _lib.call("focr_attention_fwd_premasked", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _p(o), _p(lse),
+                      _p(mask), b, heads, t, 3 * d, d, scale, float(p_attn), _stream())
+        else:
+            _lib.call("focr_attention_fwd", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _p(o), _p(lse), _p(mask), b,
+                      heads, t, 3 * d, d, scale, float(p_attn), _new_seed() if p_attn > 0 else 0, _stream())
+        xhat1, xhat2, h = torch.empty_like(tok), torch.empty_like(tok), torch.empty_like(tok)
+        rinv1, rinv2 = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+        out = torch.empty((b, t, cf), device=dev)
+        ks = ctypes.c_float(1.0)
+        _lib.call("focr_fe_post_fwd", _p(o), _p(tok), _p(xres), _p(wo), _p(bo), _p(a1), _p(b1), _p(w1), _p(bb1),
+                  _p(w2), _p(bb2), _p(a3), _p(b3), _p(wl), _p(bl), _p(xhat1), _p(rinv1), _p(h), _p(xhat2), _p(rinv2),
+                  _p(out), rows, float(eps), float(p_ffn), _new_seed() if p_ffn > 0 else 0, ctypes.byref(ks), _stream())
+        ctx.cfg = (b, t, heads, scale, float(p_attn), float(eps), float(ks.value))
+        ctx.defer_residual = bool(defer_residual) and xres is not None
+        ctx.res_key = _dkey(xres) if ctx.defer_residual else None
+        ctx.targets = tuple(_target(p_) for p_ in params)
+        ctx.save_for_backward(tok, qkv, o, lse, mask, xhat1, rinv1, h, xhat2, rinv2, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        tok, qkv, o, lse, mask, xhat1, rinv1, h, xhat2, rinv2 = ctx.saved_tensors[:10]
+        params = ctx.saved_tensors[10:]
+        wqkv, bqkv, wo, bo, a1, b1, w1, bb1, w2, bb2, a3, b3, wl, bl = params
+        b, t, heads, scale, p_attn, eps, keep_scale = ctx.cfg
+        step = ctx.step
+        rows, d = b * t, 128
+        dev = dy.device
+        d_out = dy.contiguous()
+        d_s2, d_hpre, d_s1, d_ctx = (torch.empty_like(tok) for _ in range(4))
+        _lib.call("focr_fe_post_bwd", _p(d_out), _p(wl), _p(xhat2), _p(rinv2), _p(a3), _p(w2), _p(h), keep_scale,
+                  _p(w1), _p(xhat1), _p(rinv1), _p(a1), _p(wo), _p(d_s2), _p(d_hpre), _p(d_s1), _p(d_ctx), rows, eps,
+                  _stream())
+        dqkv = torch.empty_like(qkv)
+        work = torch.empty((b, heads, t), device=dev)
+        _lib.call("focr_attention_bwd", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _p(o), _p(d_ctx), _p(lse), _p(mask),
+                  _po(dqkv, 0), _po(dqkv, d), _po(dqkv, 2 * d), _p(work), b, heads, t, 3 * d, d, scale, p_attn,
+                  _stream())
+        d_feat = None
+        if ctx.needs_input_grad[0]:
+            d_feat = torch.empty((b, t, 64), device=dev)
+            _lib.call("focr_fe_qkv_dgrad", _p(dqkv), _p(wqkv), _p(d_s1), _p(d_feat), rows, _stream())
+        # residual gradient of the block input: parked for the data-gradient kernel of its other consumer (the block's
+        # first convolution), or handed to autograd
+        dres = None
+        if ctx.needs_input_grad[1]:
+            if ctx.defer_residual:
+                if ctx.res_key in step.deferred:
+                    raise RuntimeError("two deferred gradients for the same tensor")
+                step.deferred[ctx.res_key] = d_out
+            else:
+                dres = d_out
+        # parameter gradients: one library call, on the side stream when every target is a flat-buffer slice
+        grads = [None] * _FeatureEnhancerFused.N_PARAMS
+        if any(ctx.needs_input_grad[8:]):
+            tg = list(ctx.targets)
+            flat = all(x is not None for x in tg)
+            if not flat:
+                tg = [torch.empty_like(p_, memory_format=torch.contiguous_format) for p_ in params]
+                grads = list(tg)
+            side = step.side_stream() if flat else None
+            nws = _lib.load().focr_fe_wgrads_ws_floats(rows)
+            if side is not None:
+                if dres is not None:
+                    dres = dres.clone()      # autograd may accumulate into it in place while the side stream reads d_out
+                ev = torch.cuda.Event()
+                ev.record()
+                side.wait_event(ev)
+                for x in (d_out, xhat2, d_s2, h, d_hpre, xhat1, d_s1, o, dqkv, tok):
+                    x.record_stream(side)
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                ws = torch.empty(nws, device=dev)
+                # order of the targets: wqkv bqkv wo bo a1 b1 w1 bb1 w2 bb2 a3 b3 wl bl
+                g = dict(zip(("wqkv", "bqkv", "wo", "bo", "a1", "b1", "w1", "bb1", "w2", "bb2", "a3", "b3", "wl", "bl"),
+                             tg))
+                _lib.call("focr_fe_wgrads", _p(d_out), _p(xhat2), _p(d_s2), _p(h), _p(d_hpre), _p(xhat1), _p(d_s1),
+                          _p(o), _p(dqkv), _p(tok), _p(wl), _p(w1), _p(a1), _p(b1), _p(a3), _p(b3), _p(g["wl"]),
+                          _p(g["bl"]), _p(g["a3"]), _p(g["b3"]), _p(g["w2"]), _p(g["bb2"]), _p(g["w1"]), _p(g["bb1"]),
+                          _p(g["a1"]), _p(g["b1"]), _p(g["wo"]), _p(g["bo"]), _p(g["wqkv"]), _p(g["bqkv"]), _p(ws),
+                          nws, rows, _stream())
+        return (d_feat, dres, None, None, None, None, None, None) + tuple(grads)
+
+
+def feature_enhancer_fused(feat, xres, pe, params, heads=4, p_attn=0.0, p_ffn=0.0, eps=1e-6, defer_residual=False):
+    """params: (wqkv [384,128], bqkv, wo, bo, a1, b1, w1, bb1, w2, bb2, a3, b3, wl [64,128], bl) -- tbsrn.py:76-92"""
+    return _FeatureEnhancerFused.apply(feat, xres, pe, int(heads), float(p_attn), float(p_ffn), float(eps),
+                                       bool(defer_residual), *params)
+
+
 class _Dropout(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p, seed):

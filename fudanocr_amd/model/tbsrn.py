@@ -7,6 +7,7 @@ dead timing lines), including the parameters that never receive a gradient (`con
 load.  I/O is NCHW at the module boundary, channel-last inside.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -15,6 +16,9 @@ from .. import kernels as K
 from ._layers import BatchNorm2d, Conv2d, Linear, PReLU
 from .stn_head import STNHead
 from .tps_spatial_transformer import TPSSpatialTransformer
+
+# FOCR_FE_FUSED=0: the FeatureEnhancer as separate per-layer kernels (A/B measurements; precision mode 0 always does)
+_FE_FUSED = os.environ.get("FOCR_FE_FUSED", "1") != "0"
 
 
 def positionalencoding2d(d_model, height, width):
@@ -113,6 +117,22 @@ class FeatureEnhancer(nn.Module):
         # gradient (defer) and the GEMM's data-gradient kernel adds it in its epilogue (take_deferred) -- see
         # kernels.py "Deferred residual gradients"; three 67 MB gradient-add passes per block disappear.
         g = torch.is_grad_enabled() and conv_feature.requires_grad
+        if _FE_FUSED and K.fe_chain_supported(conv_feature):
+            # one autograd node for the whole block: the row-local layers run as fused chains (csrc/fe_chain.hip)
+            mh, ln1, ln3, pff = self.multihead, self.mul_layernorm1, self.mul_layernorm3, self.pff
+            assert ln1.eps == ln3.eps and mh.h == 4
+            if mh._packed_qkv is not None and mh._packed_qkv[0].data_ptr() == mh.linears[0].weight.data_ptr():
+                wqkv, bqkv = mh._packed_qkv       # views of the engine's flat buffers
+            else:
+                wqkv = torch.cat([mh.linears[0].weight, mh.linears[1].weight, mh.linears[2].weight], 0)
+                bqkv = torch.cat([mh.linears[0].bias, mh.linears[1].bias, mh.linears[2].bias], 0)
+            params = (wqkv, bqkv, mh.linears[3].weight, mh.linears[3].bias, ln1.a_2, ln1.b_2, pff.w_1.weight,
+                      pff.w_1.bias, pff.w_2.weight, pff.w_2.bias, ln3.a_2, ln3.b_2, self.linear.weight, self.linear.bias)
+            return K.feature_enhancer_fused(
+                conv_feature, residual, self._pe_table(conv_feature.device), params, heads=mh.h,
+                p_attn=mh.dropout.p if mh.dropout.training else 0.0,
+                p_ffn=pff.dropout.p if pff.dropout.training else 0.0, eps=ln1.eps,
+                defer_residual=g and residual is not None and defer_block_input)
         tok = K.concat_pe(conv_feature, self._pe_table(conv_feature.device))
         att, _ = self.multihead(tok, tok, tok, mask=None, take_deferred=g)
         r = self.mul_layernorm1(att, residual=tok, defer=g)

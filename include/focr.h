@@ -210,6 +210,38 @@ int focr_concat_pe(const float* feat, const float* pe, float* tok, long rows, in
                    focr_stream_t stream);
 int focr_slice_cols(const float* x, const float* add, float* out, long rows, int ld, int c0, int w,
                     focr_stream_t stream);
+/* ---- fused row-local chains of the FeatureEnhancer (model/tbsrn.py:76-92: everything between the attention output
+ * and the block's 128 -> 64 projection is independent per token row; csrc/fe_chain.hip).  rows = B * H * W tokens
+ * (multiple of 32), d_model 128, precision mode != 0.  Kept for the backward: the NORMALISED rows xhat1 / xhat2 and
+ * 1 / (std + eps) of the two LayerNorms (tbsrn.py:23-36) and h = Dropout(relu(w_1 .)).
+ *   focr_fe_post_fwd : [ctx -> O-proj (+ tok) -> LN1 -> w_1 -> relu -> dropout] [-> w_2 (+ LN1 out) -> LN3 -> linear
+ *                      128 -> 64 (+ xin)], two launches; *keep_scale (host) receives 1 / P(keep) of the FFN dropout.
+ *   focr_fe_post_bwd : the two data-gradient chains (d_out -> d_s2, d_hpre; -> d_s1 = gradient of LN1's input sum = the
+ *                      O-proj output gradient = the token's residual gradient, d_ctx = attention output gradient).
+ *   focr_fe_qkv_dgrad: d_feat[rows,64] = dqkv[rows,384] Wqkv[:, 0:64] + d_s1[:, 0:64] (the positional-encoding half of
+ *                      the token, tbsrn.py:83-86, has no gradient consumer).
+ *   focr_fe_wgrads   : every parameter gradient of these layers in one call (targets are overwritten); the LayerNorm
+ *                      a_2 / b_2 gradients and the weight gradients of the linears fed by a LayerNorm come out of one
+ *                      weight-gradient GEMM on xhat.  ws: focr_fe_wgrads_ws_floats(rows) floats. */
+int focr_fe_chain_supported(long rows, int d_model);
+int focr_fe_post_fwd(const float* ctx, const float* tok, const float* xin, const float* wo, const float* bo,
+                     const float* a1, const float* b1, const float* w1, const float* bb1, const float* w2,
+                     const float* bb2, const float* a3, const float* b3, const float* wl, const float* bl,
+                     float* xhat1, float* rinv1, float* h, float* xhat2, float* rinv2, float* out, long rows,
+                     float eps, float p_drop, uint64_t seed, float* keep_scale, focr_stream_t stream);
+int focr_fe_post_bwd(const float* d_out, const float* wl, const float* xhat2, const float* rinv2, const float* a3,
+                     const float* w2, const float* h, float keep_scale, const float* w1, const float* xhat1,
+                     const float* rinv1, const float* a1, const float* wo, float* d_s2, float* d_hpre, float* d_s1,
+                     float* d_ctx, long rows, float eps, focr_stream_t stream);
+int focr_fe_qkv_dgrad(const float* dqkv, const float* wqkv, const float* d_s1, float* d_feat, long rows,
+                      focr_stream_t stream);
+long focr_fe_wgrads_ws_floats(long rows);
+int focr_fe_wgrads(const float* d_out, const float* xhat2, const float* d_s2, const float* h, const float* d_hpre,
+                   const float* xhat1, const float* d_s1, const float* ctx, const float* dqkv, const float* tok,
+                   const float* wl, const float* w1, const float* a1, const float* b1, const float* a3,
+                   const float* b3, float* g_wl, float* g_bl, float* g_a3, float* g_b3, float* g_w2, float* g_bb2,
+                   float* g_w1, float* g_bb1, float* g_a1, float* g_b1, float* g_wo, float* g_bo, float* g_wqkv,
+                   float* g_bqkv, float* ws, long ws_floats, long rows, focr_stream_t stream);
 /* nn.Dropout tbsrn.py:160,163 : y = keep ? x/(1-p) : 0 ; the same call is its backward */
 int focr_dropout(const float* x, float* y, long n, float p, uint64_t seed, focr_stream_t stream);
 /* nn.MSELoss loss/text_focus_loss.py:44,86 ; upstream = device scalar */

@@ -1,0 +1,161 @@
+// Standalone correctness check + micro-benchmark of the fused FeatureEnhancer row chains (csrc/fe_chain.hip); no torch.
+//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/fe_ubench.cpp -o build/fe_ubench
+//   run:   build/fe_ubench [batch=128]
+// Every kernel is compared with a one-thread-per-row fp64 evaluation of the same chain (reference tbsrn.py:76-92).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include <cmath>
+#include <algorithm>
+#include "../../fudanocr_amd/csrc/fe_chain.hip"
+
+extern "C" void focr_set_error(const char* fmt, ...) { va_list a; va_start(a, fmt); vfprintf(stderr, fmt, a); va_end(a); fputc('\n', stderr); }
+extern "C" int focr_get_precision(void) { return 2; }
+extern "C" int focr_get_tuning(int) { return 1; }
+// the weight-gradient composite is exercised by the pytest suite (needs the whole library)
+extern "C" int focr_conv2d_wgrad(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int,
+                                 int, int, float*, long, hipStream_t) { return -2; }
+extern "C" long focr_conv2d_wgrad_ws_floats(int, int, int, int, int, int, int, int, int) { return 0; }
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+__global__ void fill_kernel(float* p, long n, uint32_t seed, float scale, float offset) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { uint32_t h = hash32((uint32_t)i * 2654435761u + seed); p[i] = offset + scale * ((h >> 8) * (1.f / 8388608.f) - 1.f); }
+}
+static float* dalloc(long n, uint32_t seed, float scale, float offset = 0.f) {
+  float* p; CK(hipMalloc(&p, n * sizeof(float)));
+  hipLaunchKernelGGL(fill_kernel, dim3((n + 255) / 256), 256, 0, 0, p, n, seed, scale, offset);
+  return p;
+}
+static std::vector<float> d2h(const float* p, long n) { std::vector<float> v(n); CK(hipMemcpy(v.data(), p, n * sizeof(float), hipMemcpyDeviceToHost)); return v; }
+static void cmp(const char* name, const float* got, const float* ref, long n, double tol) {
+  std::vector<float> a = d2h(got, n), b = d2h(ref, n);
+  double mx = 0, md = 0; long bad = 0;
+  for (long i = 0; i < n; ++i) { mx = std::max(mx, (double)fabsf(b[i])); double d = fabs((double)a[i] - b[i]); if (!(d <= md)) md = d; if (!(a[i] == a[i])) ++bad; }
+  printf("  %-10s max|ref| %.4g  max diff %.3g  rel %.3g  nan %ld  %s\n", name, mx, md, md / (mx + 1e-30), bad,
+         (md <= tol * (1 + mx) && !bad) ? "ok" : "FAIL");
+}
+template <class F> static float timeit(F fn, int iters = 10) {
+  const int REP = 5;
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  for (int i = 0; i < 3; ++i) fn();
+  std::vector<float> ts;
+  for (int i = 0; i < iters; ++i) { CK(hipEventRecord(a, 0)); for (int r = 0; r < REP; ++r) fn(); CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b)); float ms; CK(hipEventElapsedTime(&ms, a, b)); ts.push_back(ms * 1e3f / REP); }
+  std::sort(ts.begin(), ts.end());
+  return ts[ts.size() / 2];
+}
+
+struct P {   // parameters (device)
+  float *wo, *bo, *a1, *b1, *w1, *bb1, *w2, *bb2, *a3, *b3, *wl, *bl, *wqkv;
+};
+#define D 128
+__device__ void ref_ln(const double* s, double eps, double* xh, double* rinv) {
+  double m = 0; for (int c = 0; c < D; ++c) m += s[c]; m /= D;
+  double q = 0; for (int c = 0; c < D; ++c) q += (s[c] - m) * (s[c] - m);
+  double sd = sqrt(q / (D - 1)); *rinv = 1.0 / (sd + eps);
+  for (int c = 0; c < D; ++c) xh[c] = (s[c] - m) * *rinv;
+}
+__device__ void ref_ln_bwd(double* d, const float* xh, const float* a, double rinv, double eps) {
+  double sg = 0, sgx = 0;
+  for (int c = 0; c < D; ++c) { d[c] *= a[c]; sg += d[c]; sgx += d[c] * xh[c]; }
+  double sd = 1.0 / rinv - eps, k = sgx / ((D - 1) * sd), mg = sg / D;
+  for (int c = 0; c < D; ++c) d[c] = rinv * (d[c] - mg) - k * xh[c];
+}
+__global__ void ref_fwd(P p, const float* ctx, const float* tok, const float* xin, float* xhat1, float* rinv1, float* h,
+                        float* xhat2, float* rinv2, float* out, long M, double eps) {
+  long m = (long)blockIdx.x * blockDim.x + threadIdx.x; if (m >= M) return;
+  double s[D], xh[D], r1[D], hh[D], ri;
+  for (int o = 0; o < D; ++o) { double a = p.bo[o]; for (int k = 0; k < D; ++k) a += (double)ctx[m * D + k] * p.wo[o * D + k]; s[o] = a + tok[m * D + o]; }
+  ref_ln(s, eps, xh, &ri); rinv1[m] = (float)ri;
+  for (int c = 0; c < D; ++c) { xhat1[m * D + c] = (float)xh[c]; r1[c] = p.a1[c] * xh[c] + p.b1[c]; }
+  for (int o = 0; o < D; ++o) { double a = p.bb1[o]; for (int k = 0; k < D; ++k) a += r1[k] * p.w1[o * D + k]; hh[o] = a > 0 ? a : 0; h[m * D + o] = (float)hh[o]; }
+  for (int o = 0; o < D; ++o) { double a = p.bb2[o]; for (int k = 0; k < D; ++k) a += hh[k] * p.w2[o * D + k]; s[o] = a + r1[o]; }
+  ref_ln(s, eps, xh, &ri); rinv2[m] = (float)ri;
+  for (int c = 0; c < D; ++c) { xhat2[m * D + c] = (float)xh[c]; r1[c] = p.a3[c] * xh[c] + p.b3[c]; }
+  for (int o = 0; o < 64; ++o) { double a = p.bl[o]; for (int k = 0; k < D; ++k) a += r1[k] * p.wl[o * D + k]; out[m * 64 + o] = (float)(a + (xin ? xin[m * 64 + o] : 0.f)); }
+}
+__global__ void ref_bwd(P p, const float* dout, const float* xhat2, const float* rinv2, const float* h, float scale,
+                        const float* xhat1, const float* rinv1, const float* dqkv, float* ds2, float* dhpre, float* ds1,
+                        float* dctx, float* dfeat, long M, double eps) {
+  long m = (long)blockIdx.x * blockDim.x + threadIdx.x; if (m >= M) return;
+  double d[D], e[D];
+  for (int c = 0; c < D; ++c) { double a = 0; for (int o = 0; o < 64; ++o) a += (double)dout[m * 64 + o] * p.wl[o * D + c]; d[c] = a; }
+  ref_ln_bwd(d, xhat2 + m * D, p.a3, rinv2[m], eps);
+  for (int c = 0; c < D; ++c) ds2[m * D + c] = (float)d[c];
+  for (int k = 0; k < D; ++k) { double a = 0; for (int o = 0; o < D; ++o) a += d[o] * p.w2[o * D + k]; e[k] = h[m * D + k] > 0.f ? a * scale : 0.0; dhpre[m * D + k] = (float)e[k]; }
+  for (int k = 0; k < D; ++k) { double a = d[k]; for (int o = 0; o < D; ++o) a += e[o] * p.w1[o * D + k]; d[k] = a; }
+  ref_ln_bwd(d, xhat1 + m * D, p.a1, rinv1[m], eps);
+  for (int c = 0; c < D; ++c) ds1[m * D + c] = (float)d[c];
+  for (int k = 0; k < D; ++k) { double a = 0; for (int o = 0; o < D; ++o) a += d[o] * p.wo[o * D + k]; dctx[m * D + k] = (float)a; }
+  for (int c = 0; c < 64; ++c) { double a = d[c]; for (int n = 0; n < 384; ++n) a += (double)dqkv[m * 384 + n] * p.wqkv[n * D + c]; dfeat[m * 64 + c] = (float)a; }
+}
+
+int main(int argc, char** argv) {
+  const int B = argc > 1 ? atoi(argv[1]) : 128;
+  const long M = (long)B * 1024;
+  printf("fe_ubench: B=%d rows=%ld\n", B, M);
+  P p;
+  const float ws = 0.088f;   // ~ xavier for 128 x 128
+  p.wo = dalloc(D * D, 1, ws); p.w1 = dalloc(D * D, 2, ws); p.w2 = dalloc(D * D, 3, ws); p.wl = dalloc(64 * D, 4, ws);
+  p.wqkv = dalloc(384 * D, 5, ws);
+  p.bo = dalloc(D, 6, 0.1f); p.bb1 = dalloc(D, 7, 0.1f); p.bb2 = dalloc(D, 8, 0.1f); p.bl = dalloc(64, 9, 0.1f);
+  p.a1 = dalloc(D, 10, 0.3f, 1.f); p.b1 = dalloc(D, 11, 0.1f); p.a3 = dalloc(D, 12, 0.3f, 1.f); p.b3 = dalloc(D, 13, 0.1f);
+  float* ctx = dalloc(M * D, 20, 1.f); float* tok = dalloc(M * D, 21, 1.f); float* xin = dalloc(M * 64, 22, 1.f);
+  float* dout = dalloc(M * 64, 23, 1.f); float* dqkv = dalloc(M * 384, 24, 0.5f);
+  auto buf = [&](long n) { float* q; CK(hipMalloc(&q, n * sizeof(float))); CK(hipMemset(q, 0xff, n * sizeof(float))); return q; };
+  float *xhat1 = buf(M * D), *rinv1 = buf(M), *h = buf(M * D), *xhat2 = buf(M * D), *rinv2 = buf(M), *out = buf(M * 64);
+  float *rxhat1 = buf(M * D), *rrinv1 = buf(M), *rh = buf(M * D), *rxhat2 = buf(M * D), *rrinv2 = buf(M), *rout = buf(M * 64);
+  float *ds2 = buf(M * D), *dhpre = buf(M * D), *ds1 = buf(M * D), *dctx = buf(M * D), *dfeat = buf(M * 64);
+  float *rds2 = buf(M * D), *rdhpre = buf(M * D), *rds1 = buf(M * D), *rdctx = buf(M * D), *rdfeat = buf(M * 64);
+  const float eps = 1e-6f;
+  float ks = 0.f;
+  // ---- forward, no dropout
+  int rc = focr_fe_post_fwd(ctx, tok, xin, p.wo, p.bo, p.a1, p.b1, p.w1, p.bb1, p.w2, p.bb2, p.a3, p.b3, p.wl, p.bl, xhat1,
+                            rinv1, h, xhat2, rinv2, out, M, eps, 0.f, 1234, &ks, 0);
+  if (rc) { printf("focr_fe_post_fwd failed %d\n", rc); return 1; }
+  hipLaunchKernelGGL(ref_fwd, dim3((M + 63) / 64), 64, 0, 0, p, ctx, tok, xin, rxhat1, rrinv1, rh, rxhat2, rrinv2, rout, M, (double)eps);
+  CK(hipDeviceSynchronize());
+  printf("forward (p = 0):\n");
+  cmp("xhat1", xhat1, rxhat1, M * D, 2e-5); cmp("rinv1", rinv1, rrinv1, M, 2e-5); cmp("h", h, rh, M * D, 2e-5);
+  cmp("xhat2", xhat2, rxhat2, M * D, 2e-5); cmp("rinv2", rinv2, rrinv2, M, 2e-5); cmp("out", out, rout, M * 64, 2e-5);
+  // ---- backward (on the reference forward's saved rows, so that the comparison is exact in its inputs)
+  rc = focr_fe_post_bwd(dout, p.wl, rxhat2, rrinv2, p.a3, p.w2, rh, 1.25f, p.w1, rxhat1, rrinv1, p.a1, p.wo, ds2, dhpre, ds1,
+                        dctx, M, eps, 0);
+  if (rc) { printf("focr_fe_post_bwd failed %d\n", rc); return 1; }
+  rc = focr_fe_qkv_dgrad(dqkv, p.wqkv, ds1, dfeat, M, 0);
+  if (rc) { printf("focr_fe_qkv_dgrad failed %d\n", rc); return 1; }
+  hipLaunchKernelGGL(ref_bwd, dim3((M + 63) / 64), 64, 0, 0, p, dout, rxhat2, rrinv2, rh, 1.25f, rxhat1, rrinv1, dqkv, rds2,
+                     rdhpre, rds1, rdctx, rdfeat, M, (double)eps);
+  CK(hipDeviceSynchronize());
+  printf("backward:\n");
+  cmp("d_s2", ds2, rds2, M * D, 2e-5); cmp("d_hpre", dhpre, rdhpre, M * D, 2e-5); cmp("d_s1", ds1, rds1, M * D, 2e-5);
+  cmp("d_ctx", dctx, rdctx, M * D, 2e-5); cmp("d_feat", dfeat, rdfeat, M * 64, 4e-5);
+  // ---- dropout statistics: kept elements equal scale * reference, dropped fraction of the positive ones ~ p
+  rc = focr_fe_post_fwd(ctx, tok, xin, p.wo, p.bo, p.a1, p.b1, p.w1, p.bb1, p.w2, p.bb2, p.a3, p.b3, p.wl, p.bl, xhat1,
+                        rinv1, h, xhat2, rinv2, out, M, eps, 0.1f, 99, &ks, 0);
+  CK(hipDeviceSynchronize());
+  {
+    std::vector<float> a = d2h(h, M * D), b = d2h(rh, M * D);
+    long pos = 0, dropped = 0, wrong = 0;
+    for (long i = 0; i < M * D; ++i) if (b[i] > 1e-4f) { ++pos; if (a[i] == 0.f) ++dropped; else if (fabsf(a[i] - ks * b[i]) > 1e-4f * (1 + fabsf(b[i]))) ++wrong; }
+    printf("dropout p=0.1: keep_scale %.6f  dropped %.5f of %ld positive  wrong %ld  %s\n", ks, (double)dropped / pos, pos, wrong,
+           (fabs((double)dropped / pos - 0.1) < 2e-3 && !wrong) ? "ok" : "FAIL");
+  }
+  // ---- timing
+  const double T = (double)M * D * 4;   // bytes of one [rows, 128] fp32 matrix
+  float t;
+  t = timeit([&] { hipLaunchKernelGGL(fe_fwd_a_kernel, dim3(fc_blocks(M / 32)), FC_THREADS, FC_LDS_FWD_A, 0, ctx, tok, p.wo, p.bo, p.a1, p.b1, p.w1, p.bb1, xhat1, rinv1, h, (int)(M / 32), eps, 58982u, ks, 7u); });
+  printf("fe_fwd_a   %7.1f us  %.2f TB/s (4 row matrices)\n", t, 4 * T / t * 1e-6);
+  t = timeit([&] { hipLaunchKernelGGL(fe_fwd_b_kernel, dim3(fc_blocks(M / 32)), FC_THREADS, FC_LDS_FWD_B, 0, (const float*)h, (const float*)xhat1, p.a1, p.b1, p.w2, p.bb2, p.a3, p.b3, p.wl, p.bl, xin, xhat2, rinv2, out, (int)(M / 32), eps); });
+  printf("fe_fwd_b   %7.1f us  %.2f TB/s (4 row matrices)\n", t, 4 * T / t * 1e-6);
+  t = timeit([&] { hipLaunchKernelGGL(fe_bwd_a_kernel, dim3(fc_blocks(M / 32)), FC_THREADS, FC_LDS_BWD_A, 0, dout, p.wl, rxhat2, rrinv2, p.a3, p.w2, rh, ds2, dhpre, (int)(M / 32), eps, 1.25f); });
+  printf("fe_bwd_a   %7.1f us  %.2f TB/s (4.5 row matrices)\n", t, 4.5 * T / t * 1e-6);
+  t = timeit([&] { hipLaunchKernelGGL(fe_bwd_b_kernel, dim3(fc_blocks(M / 32)), FC_THREADS, FC_LDS_BWD_B, 0, (const float*)dhpre, (const float*)ds2, p.w1, rxhat1, rrinv1, p.a1, p.wo, ds1, dctx, (int)(M / 32), eps); });
+  printf("fe_bwd_b   %7.1f us  %.2f TB/s (5 row matrices)\n", t, 5 * T / t * 1e-6);
+  t = timeit([&] { hipLaunchKernelGGL(fe_bwd_qkv_kernel, dim3(fc_blocks(M / 32)), FC_THREADS, FC_LDS_BWD_QKV, 0, dqkv, p.wqkv, (const float*)ds1, dfeat, (int)(M / 32), D); });
+  printf("fe_bwd_qkv %7.1f us  %.2f TB/s (4 row matrices)\n", t, 4 * T / t * 1e-6);
+  return 0;
+}
