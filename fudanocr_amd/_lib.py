@@ -100,6 +100,8 @@ SIGNATURES = {
     "focr_comm_init": [I, I, P],
     "focr_allreduce_async": [P, L, I, P],
     "focr_comm_nranks": [],
+    "focr_comm_async_error": [],
+    "focr_comm_wait": [P, I],
     "focr_comm_destroy": [],
     "focr_get_tuning": [I],
     "focr_get_precision": [],

@@ -7,6 +7,8 @@
 // RCCL is bound at run time (dlopen of librccl.so.1): a process that already holds RCCL (PyTorch loads its own copy)
 // gets THAT instance back, and the library has no link-time dependency on it -- single-GPU users never load it.
 #include <dlfcn.h>
+#include <chrono>
+#include <thread>
 #include <rccl/rccl.h>
 #include "focr_common.h"
 
@@ -17,6 +19,8 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 } g_rccl;
 ncclComm_t g_comm = nullptr;
@@ -35,6 +39,8 @@ int load_rccl() {
   g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(h, "ncclAllReduce"));
   g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
   g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+  g_rccl.CommGetAsyncError = reinterpret_cast<decltype(g_rccl.CommGetAsyncError)>(dlsym(h, "ncclCommGetAsyncError"));
+  g_rccl.CommAbort = reinterpret_cast<decltype(g_rccl.CommAbort)>(dlsym(h, "ncclCommAbort"));
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
     focr_set_error("focr_comm: librccl.so lacks an expected symbol");
     dlclose(h);
@@ -46,7 +52,17 @@ int load_rccl() {
 int check(ncclResult_t r, const char* what) {
   if (r == ncclSuccess) return FOCR_OK;
   focr_set_error("focr_comm: %s failed: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "rccl error");
-  return FOCR_EHIP;
+  return FOCR_ENCCL;
+}
+// asynchronous errors of the communicator (a peer died, a link went down: RCCL reports them out of band, the collective
+// itself just never completes)
+int async_error() {
+  if (!g_comm || !g_rccl.CommGetAsyncError) return FOCR_OK;
+  ncclResult_t st = ncclSuccess;
+  ncclResult_t r = g_rccl.CommGetAsyncError(g_comm, &st);
+  if (r != ncclSuccess) return check(r, "ncclCommGetAsyncError");
+  if (st != ncclSuccess && st != ncclInProgress) return check(st, "communicator (asynchronous error)");
+  return FOCR_OK;
 }
 }  // namespace
 
@@ -81,7 +97,39 @@ extern "C" int focr_allreduce_async(void* buf, size_t n, int dtype, hipStream_t 
     focr_set_error("focr_allreduce_async: no communicator (focr_comm_init first)");
     return FOCR_EINVAL;
   }
+  int rc = async_error();             // an earlier collective failed asynchronously: do not queue behind it
+  if (rc != FOCR_OK) return rc;
   return check(g_rccl.AllReduce(buf, buf, n, ncclFloat32, ncclSum, g_comm, stream), "ncclAllReduce");
+}
+// Non-blocking health check of the communicator (FOCR_OK / FOCR_ENCCL + message).
+extern "C" int focr_comm_async_error(void) { return async_error(); }
+// Host-side watchdog: wait until everything queued on `stream` (the collectives' stream) has completed, polling the
+// communicator for asynchronous errors; after `timeout_ms` without completion (or on an error) the communicator is
+// ABORTED (ncclCommAbort: the stuck kernels are torn down, the process can exit or rebuild the group) and FOCR_ENCCL is
+// returned.  This call synchronises the host with `stream`: the training step calls it only when FOCR_COMM_TIMEOUT_MS
+// is set; tools/dp_selfcheck.py always does.
+extern "C" int focr_comm_wait(hipStream_t stream, int timeout_ms) {
+  if (!g_comm) return FOCR_OK;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    hipError_t q = hipStreamQuery(stream);
+    if (q == hipSuccess) return async_error();
+    if (q != hipErrorNotReady) {
+      focr_set_error("focr_comm_wait: stream error: %s", hipGetErrorString(q));
+      return FOCR_EHIP;
+    }
+    int rc = async_error();
+    const long ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+    if (rc == FOCR_OK && (timeout_ms <= 0 || ms < timeout_ms)) {
+      std::this_thread::sleep_for(std::chrono::microseconds(200));
+      continue;
+    }
+    if (rc == FOCR_OK) focr_set_error("focr_comm_wait: collective did not complete within %d ms (peer lost?)", timeout_ms);
+    if (g_rccl.CommAbort) (void)g_rccl.CommAbort(g_comm);
+    g_comm = nullptr;
+    g_nranks = 0;
+    return FOCR_ENCCL;
+  }
 }
 extern "C" int focr_comm_nranks(void) { return g_comm ? g_nranks : 0; }
 extern "C" int focr_comm_destroy(void) {

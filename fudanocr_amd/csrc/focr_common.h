@@ -9,6 +9,7 @@
 #define FOCR_EINVAL (-1)
 #define FOCR_EUNSUPPORTED (-2)
 #define FOCR_EHIP (-3)
+#define FOCR_ENCCL (-4)
 
 extern "C" void focr_set_error(const char* fmt, ...);
 extern "C" int focr_get_precision(void);

@@ -827,7 +827,10 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_bx3_kernel(
 #define LSTM_SPIN_LIMIT (1 << 22)
 #endif
 
-__device__ __forceinline__ void lp_wait(unsigned* flag, unsigned target, unsigned* err) {
+// `bad` (LDS, zeroed by the kernel): set when the wait timed out, i.e. a partner block was never scheduled.  The kernels
+// then write NaN into every later output of this block, so a scan that could not synchronise can never pass for a
+// result (the error word `err` additionally tells the host why; kernels._lstm_check reads it under FOCR_LSTM_CHECK=1).
+__device__ __forceinline__ void lp_wait(unsigned* flag, unsigned target, unsigned* err, unsigned* bad) {
 #ifdef LSTM_ABL_NOSYNC
   __syncthreads();
   return;
@@ -837,6 +840,7 @@ __device__ __forceinline__ void lp_wait(unsigned* flag, unsigned target, unsigne
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
       if (++spins > LSTM_SPIN_LIMIT) {
         __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *bad = 1u;
         break;
       }
     }
@@ -869,6 +873,8 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
   const long nw = (long)2 * 4 * H * H;
   unsigned* flag = flags + group;
   unsigned* err = flags + ngroups;
+  __shared__ unsigned lp_bad;
+  if (threadIdx.x == 0) lp_bad = 0u;
   for (int i = tid; i < 128 * 32; i += 512) {                   // 16-byte pieces of the 128 rows x 256 k slice
     const int row = i >> 5, ch = i & 31, gg = row >> 5, u = row & 31;
     const __bf16* src = whh2 + ((size_t)dir * 4 * H + gg * H + j0 + u) * H + 8 * ch;
@@ -897,7 +903,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     if (step > 0) {
-      lp_wait(flag, 8u * (unsigned)step, err);
+      lp_wait(flag, 8u * (unsigned)step, err, &lp_bad);
       const __bf16* arow = hseq2 + ((size_t)tp * B + br) * 2 * H + dir * H + 128 * kq + 8 * lh;
       const __bf16* brow = Wh + (g * 32 + li) * LP_WP + 128 * kq + 8 * lh;
       rbf16x8 ah[8], al[8];
@@ -940,6 +946,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
       o_og[e] = sigmoidf_(part[3][ebl][eu] + gxv[e][3] + bias.w);
       o_c[e] = o_fg[e] * cprev[e] + o_ig[e] * o_gg[e];
       o_h[e] = o_og[e] * tanhf(o_c[e]);
+      if (lp_bad) o_h[e] = __int_as_float(0x7fc00000);     // a wait timed out: poison, never a silently stale scan
       cprev[e] = o_c[e];
       if (eb < B) {
         const size_t ho = ((size_t)t * B + eb) * 2 * H + dir * H + j0 + eu;
@@ -981,6 +988,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_bx3_kernel(
   const long nwt = (long)2 * H * 4 * H;
   unsigned* flag = flags + group;
   unsigned* err = flags + ngroups;
+  __shared__ unsigned lp_bad;
+  if (threadIdx.x == 0) lp_bad = 0u;
   for (int i = tid; i < 32 * 128; i += 512) {                   // 16-byte pieces of 32 rows x 1024 n
     const int row = i >> 7, ch = i & 127;
     const __bf16* src = whhT2 + ((size_t)dir * H + j0 + row) * 4 * H + 8 * ch;
@@ -1010,7 +1019,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_bx3_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     if (step > 0) {
-      lp_wait(flag, 8u * (unsigned)step, err);
+      lp_wait(flag, 8u * (unsigned)step, err, &lp_bad);
       // wave w contracts n in [128 w, 128 w + 128) of the 4H gate-gradient row
       const __bf16* arow = dgx2 + ((size_t)tn * st_t + (size_t)br * st_b) * 8 * H + dir * 4 * H + 128 * wave + 8 * lh;
       const __bf16* brow = Wh + li * LP_WTP + 128 * wave + 8 * lh;
@@ -1055,6 +1064,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_bx3_kernel(
       d4[e][1] = dc * cp[e] * fg[e] * (1.f - fg[e]);
       d4[e][2] = dc * ig[e] * (1.f - gg[e] * gg[e]);
       d4[e][3] = dh * tc * og[e] * (1.f - og[e]);
+      if (lp_bad) d4[e][0] = d4[e][1] = d4[e][2] = d4[e][3] = __int_as_float(0x7fc00000);
       if (eb < B) {
         const size_t ob = ((size_t)t * st_t + (size_t)eb * st_b) * 8 * H + dir * 4 * H + j0 + eu;
 #pragma unroll
@@ -1081,9 +1091,29 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_bx3_kernel(
 #define LP_FWD_LDS (2 * 128 * LP_WP * 2 + 4 * 32 * 33 * 4)       // 152064 B
 #define LP_BWD_LDS (2 * 32 * LP_WTP * 2 + 4 * 32 * 33 * 4)       // 148992 B
 #define LP_FLAG_BYTES 1024                                      // step counters of the groups + error word
+// The persistent scan synchronises its 8 * ngroups blocks through global step counters under an ordinary launch: it is
+// only correct when ALL of them are resident at once.  Ask the runtime how many blocks of each kernel fit on this device
+// (CU count under the current partition mode / CU mask x blocks per CU at ~150 KB LDS) and fall back to the per-step
+// launches when the grid does not fit; a query that fails also means "not usable".
+static int lp_resident_blocks(const void* kern, size_t lds) {
+  int dev = 0, per_cu = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 512, lds) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  return per_cu * cus;
+}
 static bool lp_usable(int B, int H) {
-  return H == 256 && 8 * cdiv(B, 32) * 2 <= 256 && focr_get_tuning(FOCR_TUNE_LSTM_PERSISTENT) != 0 &&
-         cdiv(B, 32) * 2 + 1 <= LP_FLAG_BYTES / 4;
+  if (!(H == 256 && 8 * cdiv(B, 32) * 2 <= 256 && focr_get_tuning(FOCR_TUNE_LSTM_PERSISTENT) != 0 &&
+        cdiv(B, 32) * 2 + 1 <= LP_FLAG_BYTES / 4))
+    return false;
+  static int resident = -1;                 // min over the two kernels, queried once per process (one device per process)
+  if (resident < 0) {
+    const int f = lp_resident_blocks((const void*)lstm_fwd_persist_bx3_kernel, LP_FWD_LDS);
+    const int b = lp_resident_blocks((const void*)lstm_bwd_persist_bx3_kernel, LP_BWD_LDS);
+    resident = f < b ? f : b;
+  }
+  return 8 * cdiv(B, 32) * 2 <= resident;
 }
 
 // ws (forward): bf16 elements: 2*2*4H*H (whh hi/lo) + 2*T*B*2H (h hi/lo)          -> bytes = 2 * that

@@ -102,6 +102,9 @@ class ShardLoader:
         self._stage = [(torch.empty((batch_size,) + hs, dtype=torch.uint8).pin_memory(),
                         torch.empty((batch_size,) + ls, dtype=torch.uint8).pin_memory())
                        for _ in range(self.prefetch + 1)]
+        self._slot_event = [None] * len(self._stage)          # last H2D copy out of each pinned slot
+        from concurrent.futures import ThreadPoolExecutor
+        self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="focr-shard-gather")
 
     def _indices(self):
         n = int(self.offsets[-1])
@@ -114,44 +117,67 @@ class ShardLoader:
         n = int(self.offsets[-1]) // self.world
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
-    def _issue(self, slot, ids):
-        """host gather into the pinned slot + asynchronous upload; returns (hr_dev_u8, lr_dev_u8, labels, event)"""
+    def _gather(self, slot, ids):
+        """worker thread: host gather of one batch into pinned slot `slot`.  The slot's previous upload is waited for
+        ON THE HOST first (`Event.synchronize`): a device-side `wait_event` orders streams, not the host's memcpy into
+        the pinned buffer, and the training step never synchronises the host."""
+        ev = self._slot_event[slot]
+        if ev is not None:
+            ev.synchronize()
+            self._slot_event[slot] = None
         hr_p, lr_p = self._stage[slot]
-        nb = len(ids)
         hr_np, lr_np = hr_p.numpy(), lr_p.numpy()
-        labels = []
-        for j, g in enumerate(ids):
-            s = int(np.searchsorted(self.offsets, g, side="right") - 1)
-            d, k = self.sets[s], int(g - self.offsets[s])
-            hr_np[j], lr_np[j] = d.hr[k], d.lr[k]
-            labels.append(d.labels[k])
+        ids = np.asarray(ids, dtype=np.int64)
+        shard = np.searchsorted(self.offsets, ids, side="right") - 1
+        labels = [None] * len(ids)
+        for s in np.unique(shard):
+            pos = np.nonzero(shard == s)[0]
+            d, k = self.sets[int(s)], ids[pos] - int(self.offsets[int(s)])
+            order = np.argsort(k, kind="stable")                 # ascending reads of the memory-mapped arrays
+            hr_np[pos[order]] = d.hr[k[order]]
+            lr_np[pos[order]] = d.lr[k[order]]
+            for j, kk in zip(pos, k):
+                labels[int(j)] = d.labels[int(kk)]
+        return tuple(labels)
+
+    def _upload(self, slot, nb):
+        """launch thread: asynchronous H2D of a gathered slot on the copy stream -> (hr_dev_u8, lr_dev_u8, event)"""
+        hr_p, lr_p = self._stage[slot]
         with torch.cuda.stream(self.copy_stream):
             hr_d = hr_p[:nb].to(self.device, non_blocking=True)
             lr_d = lr_p[:nb].to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
-        return hr_d, lr_d, tuple(labels), ev
+        self._slot_event[slot] = ev
+        return hr_d, lr_d, ev
 
     def __iter__(self):
         idx = self._indices()
         self.epoch += 1
         nb = len(self)
         batches = [idx[i * self.batch_size:(i + 1) * self.batch_size] for i in range(nb)]
-        inflight = []
-        nxt = 0
-        while nxt < min(self.prefetch, nb):
-            inflight.append(self._issue(nxt % len(self._stage), batches[nxt]))
-            nxt += 1
+        ns = len(self._stage)
+        # pipeline: gather(i + prefetch) runs in the worker thread while batch i trains; upload(i + 1) is issued as soon
+        # as batch i was handed to the device transform, so it overlaps step i
+        gathers = {i: self._pool.submit(self._gather, i % ns, batches[i]) for i in range(min(self.prefetch, nb))}
+        nxt_gather = len(gathers)
+        uploads = {}
+
+        def ensure_upload(i):
+            if i < nb and i not in uploads:
+                labels = gathers.pop(i).result()
+                uploads[i] = self._upload(i % ns, len(batches[i])) + (labels,)
+        ensure_upload(0)
         for i in range(nb):
-            hr_d, lr_d, labels, ev = inflight.pop(0)
+            hr_d, lr_d, ev, labels = uploads.pop(i)
             torch.cuda.current_stream().wait_event(ev)
             hr = u8_to_input(hr_d, self.mask)
             lr = u8_to_input(lr_d, self.mask)
             hr_d.record_stream(torch.cuda.current_stream())
             lr_d.record_stream(torch.cuda.current_stream())
-            if nxt < nb:
-                # the slot being refilled was uploaded `prefetch + 1` batches ago: its copy has completed (its event was
-                # waited for when that batch was consumed)
-                inflight.append(self._issue(nxt % len(self._stage), batches[nxt]))
-                nxt += 1
+            if nxt_gather < nb:
+                # its pinned slot was last uploaded `prefetch + 1` batches ago; _gather waits for that upload on the host
+                gathers[nxt_gather] = self._pool.submit(self._gather, nxt_gather % ns, batches[nxt_gather])
+                nxt_gather += 1
+            ensure_upload(i + 1)
             yield hr, lr, labels

@@ -308,6 +308,12 @@ class TrainStep:
         for w in self._works:
             w.wait()
         if self.native_comm:
+            from . import _lib
+            tmo = os.environ.get("FOCR_COMM_TIMEOUT_MS")
+            if tmo:     # watchdog (host sync): a lost peer becomes an error instead of a hang at the next step
+                _lib.call("focr_comm_wait", ctypes.c_void_p(self.comm_stream.cuda_stream), int(tmo))
+            else:
+                _lib.call("focr_comm_async_error")
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self._works, self._sent = [], []
 

@@ -25,6 +25,9 @@ class TextSR(base.TextBase):
         best_history_acc, best_model_acc, best_acc, converge_list = {}, {}, 0, []
         t_start, n_img = time.time(), 0
         for epoch in range(cfg.epochs):
+            sampler = getattr(train_loader, "sampler", None)
+            if hasattr(sampler, "set_epoch"):
+                sampler.set_epoch(epoch)      # DistributedSampler: a new permutation per epoch (ShardLoader advances itself)
             for j, data in enumerate(train_loader):
                 iters = len(train_loader) * epoch + j
                 images_hr, images_lr, label_strs = data

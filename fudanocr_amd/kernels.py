@@ -287,7 +287,7 @@ def bump_weight_epoch():
 
 
 class _FragEntry:
-    __slots__ = ("ref", "buf", "geom", "ptr", "version", "epoch", "managed")
+    __slots__ = ("ref", "buf", "geom", "ptr", "version", "epoch", "managed", "trainable")
 
 
 class FragTable:
@@ -318,15 +318,21 @@ class FragTable:
         if e is not None:
             if e.managed:
                 return e.buf                                    # refreshed at the start of this step
-            if e.version == weight._version and (not weight.requires_grad or e.epoch == WEIGHT_EPOCH):
+            # Trainable weights are also checked against the engine's epoch (raw-pointer Adam updates are invisible to
+            # ._version).  A weight that was trainable when its fragments were made and is frozen now (or the reverse)
+            # is re-prepared once: a model trained by an engine and THEN frozen in-process (demo(), the reference's
+            # eval) must not keep pre-training fragments.  Weights frozen all along are never touched by an engine.
+            if (e.version == weight._version and e.trainable == weight.requires_grad
+                    and (not weight.requires_grad or e.epoch == WEIGHT_EPOCH)):
                 return e.buf
-            e.version, e.epoch = weight._version, WEIGHT_EPOCH
+            e.version, e.epoch, e.trainable = weight._version, WEIGHT_EPOCH, weight.requires_grad
             self._prep(e, wk, flip)
             return e.buf
         e = _FragEntry()
         rows, k = (cin, kh * kw * cout) if flip else (cout, kh * kw * cin)
         e.buf = torch.empty(_lib.load().focr_weight_frag_bytes(rows, k), device=wk.device, dtype=torch.uint8)
         e.geom, e.ptr, e.version, e.epoch = geom, wk.data_ptr(), weight._version, WEIGHT_EPOCH
+        e.trainable = weight.requires_grad
         e.ref = weakref.ref(weight, lambda _r, key=key: self.entries.pop(key, None)) if cacheable else (lambda: None)
         e.managed = bool(self.managed and cacheable and weight.requires_grad)
         self._prep(e, wk, flip)

@@ -198,6 +198,9 @@ def test_c_abi_rccl_communicator_single_rank():
         for _ in range(3):
             _lib.call("focr_allreduce_async", ctypes.c_void_p(x.data_ptr()), x.numel(), 0,
                       ctypes.c_void_p(side.cuda_stream))
+        _lib.call("focr_comm_async_error")                   # healthy communicator: no asynchronous error
+        _lib.call("focr_comm_wait", ctypes.c_void_p(side.cuda_stream), 20000)   # watchdog: drains well inside the limit
+        assert lib.focr_comm_nranks() == 1                   # ... and did not abort the communicator
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         assert torch.equal(x, ref)
