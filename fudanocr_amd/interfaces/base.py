@@ -148,6 +148,11 @@ class TextBase(object):
         para_num = sum(p.numel() for p in model.parameters())
         self.logging.info("Total Parameters {}".format(para_num))
         rec, _ = self.CRNN_init() if getattr(a, "ctc", True) else (None, None)
+        if getattr(a, "stroke_focus", False):
+            # text-gestalt's criterion (text-gestalt/interfaces/base.py:162): MSE + stroke_lambda * L1 on the attention
+            # maps of the stroke-level recognizer.  `--text_focus` switches its focus term on, as in the reference.
+            from ..loss.stroke_focus_loss import StrokeFocusLoss
+            return {"model": model, "crit": StrokeFocusLoss(a, device=self.device), "recognizer": rec}
         if getattr(a, "text_focus", False):
             # the reference's criterion for tbsrn / tsrn (interfaces/base.py:143-150): MSE + text-focus terms.  The
             # CRNN stays the eval-time recognizer only, exactly as in the reference.

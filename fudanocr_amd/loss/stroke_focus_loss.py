@@ -1,0 +1,106 @@
+"""StrokeFocusLoss of text-gestalt (reference text-gestalt/loss/stroke_focus_loss.py:20-118) on the HIP path:
+
+    loss = mse(sr, hr) + stroke_lambda * L1(attention_map(hr), attention_map(sr))
+
+Labels are decomposed into stroke sequences (`english_decomposition.txt`: one "<character> <digits>" line per
+character, strokes 1-9; `0` closes the word) and fed with teacher forcing to the frozen, eval-mode stroke-level
+recognizer (loss/transformer_english_decomposition.py) on the luma of HR (no gradient) and of SR (data gradient back
+into the SR network).  Returns the reference's 4-tuple (loss, mse_loss, attention_loss, recognition_loss = -1), with
+`-1` sentinels for both terms when `args.text_focus` is off.
+
+Neither ./dataset/mydata/english_decomposition.txt nor pretrain_transformer_stroke_decomposition.pth ships with the
+reference.  When the files are absent the decomposition is a seeded stand-in table (`standin_decomposition`: same
+format, every alphanumeric character -> 1-4 strokes) and the recognizer gets the name-keyed deterministic weights: the
+maths, shapes and cost of the step are the reference's, only the learned content is missing -- and that is logged."""
+import logging
+import os
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import kernels as K
+from ..sld import ops
+from ..utils.weight_fill import fill_module_
+from .text_focus_loss import to_gray_tensor
+from .transformer_english_decomposition import Transformer
+
+
+def standin_decomposition(seed=2021):
+    """character -> stroke digits (1-9), for 0-9a-zA-Z: the FORMAT of english_decomposition.txt with seeded content"""
+    chars = "0123456789abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ"
+    rs = np.random.RandomState(seed)
+    return {c: "".join(str(int(d)) for d in rs.randint(1, 10, size=int(rs.randint(1, 5)))) for c in chars}
+
+
+def load_decomposition(path="./dataset/mydata/english_decomposition.txt"):
+    if not os.path.isfile(path):
+        logging.getLogger(__name__).warning("english_decomposition.txt not found (%s): seeded stand-in stroke table", path)
+        return standin_decomposition()
+    dic = {}
+    for line in open(path, "r").readlines():
+        character, sequence = line.strip().split()
+        dic[character] = sequence
+    return dic
+
+
+class StrokeFocusLoss(nn.Module):
+    correct_flag = False               # reference :99: the "select correct" branch is switched off
+
+    def __init__(self, args, transformer=None, decomposition=None, device="cuda"):
+        super().__init__()
+        self.args = args
+        self.english_stroke_alphabet = "0123456789"
+        self.english_stroke_dict = {c: i for i, c in enumerate(self.english_stroke_alphabet)}
+        self.dic = dict(decomposition) if decomposition is not None else load_decomposition()
+        self.device = torch.device(device)
+        self._transformer = [transformer]                 # not registered: stays out of state_dict / parameters()
+        if getattr(args, "text_focus", False) and transformer is None:
+            self.build_up_transformer()
+
+    @property
+    def transformer(self):
+        return self._transformer[0]
+
+    def build_up_transformer(self, path="./dataset/mydata/pretrain_transformer_stroke_decomposition.pth"):
+        t = Transformer()
+        if os.path.isfile(path):
+            sd = torch.load(path, map_location="cpu")
+            t.load_state_dict({k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()})
+        else:
+            logging.getLogger(__name__).warning("pretrain_transformer_stroke_decomposition.pth not found (%s): "
+                                                "name-keyed weights", path)
+            fill_module_(t)
+        t = t.to(self.device).eval()
+        for p in t.parameters():
+            p.requires_grad = False
+        self._transformer[0] = t
+
+    def label_stroke_encoder(self, label):
+        """reference :49-80: characters without a decomposition are skipped, `0` closes the word; teacher-forcing input
+        shifted right by one, flat targets; CUDA tensors"""
+        label = ["".join(self.dic[c] for c in one if c in self.dic) + "0" for one in label]
+        length = [len(i) for i in label]
+        input_tensor = np.zeros((len(label), max(length)), dtype=np.int64)
+        for i, s in enumerate(label):
+            for j in range(length[i] - 1):
+                input_tensor[i][j + 1] = self.english_stroke_dict[s[j]]
+        text_gt = torch.tensor([self.english_stroke_dict[c] for s in label for c in s], dtype=torch.long)
+        length_tensor = torch.tensor(length, dtype=torch.long).to(self.device)
+        length_tensor._focr_host = length
+        return length_tensor, torch.from_numpy(input_tensor).to(self.device), text_gt.to(self.device)
+
+    def forward(self, sr_img, hr_img, label, encoded=None):
+        mse_loss = K.mse_loss(sr_img, hr_img)
+        if not getattr(self.args, "text_focus", False):
+            return mse_loss, mse_loss, -1, -1
+        length_tensor, input_tensor, _ = self.label_stroke_encoder(label)
+        tr = self.transformer
+        with torch.no_grad():
+            _, word_attention_map_gt, _ = tr(to_gray_tensor(hr_img), length_tensor, input_tensor, test=False,
+                                             want_correct=self.correct_flag)
+        _, word_attention_map_pred, _ = tr(to_gray_tensor(sr_img), length_tensor, input_tensor, test=False,
+                                           want_correct=self.correct_flag)
+        attention_loss = ops.l1_loss(word_attention_map_gt, word_attention_map_pred)
+        loss = mse_loss + attention_loss * float(getattr(self.args, "stroke_lambda", 50))
+        return loss, mse_loss, attention_loss, -1

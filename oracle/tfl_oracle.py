@@ -121,3 +121,65 @@ def text_focus_loss(P, sr, hr, labels_filtered, table):
     att = F.l1_loss(map_gt, map_pred)
     rec = weight_cross_entropy(pred, text_gt, table)
     return mse + att * 10 + rec * 0.0005, mse, att, rec, pred, map_pred, conv
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# text-gestalt: the stroke-focus loss (text-gestalt/loss/stroke_focus_loss.py:20-118) and its stroke-level recognizer
+# (text-gestalt/loss/transformer_english_decomposition.py:8,336-398).  Same network; 10 stroke classes, the embedding /
+# generator registered as *_with_upperword, a correct_list from the training branch, loss = mse + stroke_lambda * L1.
+# Pinned by tests/test_text_focus.py against fixture sfl_step.npz (tools/make_golden_sfl.py).
+# ---------------------------------------------------------------------------------------------------------------------
+STROKES = "0123456789"                                      # transformer_english_decomposition.py:8
+
+
+def stroke_schema():
+    """the STT schema with 10 classes and the two renamed modules, in the reference's registration order"""
+    out = OrderedDict()
+    for k, v in schema(n_class=len(STROKES)).items():
+        k = k.replace("embedding_word.", "embedding_word_with_upperword.").replace(
+            "generator_word.", "generator_word_with_upperword.")
+        out[k] = v
+    return out
+
+
+def make_stroke_params():
+    return OrderedDict((k, v.clone()) for k, v in stroke_schema().items())
+
+
+def label_stroke_encoder(labels, dic):
+    """stroke_focus_loss.py:49-80: characters without a decomposition are skipped, '0' closes the word"""
+    a2n = {c: i for i, c in enumerate(STROKES)}
+    seqs = ["".join(dic[c] for c in s if c in dic) + "0" for s in labels]
+    length = torch.tensor([len(s) for s in seqs], dtype=torch.long)
+    text_input = torch.zeros(len(seqs), int(length.max()), dtype=torch.long)
+    for i, s in enumerate(seqs):
+        for j in range(len(s) - 1):
+            text_input[i, j + 1] = a2n[s[j]]
+    text_gt = torch.tensor([a2n[c] for s in seqs for c in s], dtype=torch.long)
+    return length, text_input, text_gt
+
+
+def stroke_recognizer(P, image, text_length, text_input):
+    """transformer_english_decomposition.py:361-396 (test=False branch): 4-channel input -> luma, then the shared
+    network; correct_list[i] = greedy classes of positions 0 .. L-2 reproduce the teacher-forcing input 1 .. L-1"""
+    if image.shape[1] == 4:
+        image = to_gray(image)
+    Q = OrderedDict((k.replace("_with_upperword", ""), v) for k, v in P.items())
+    pred, amap, conv = recognizer(Q, image, text_length, text_input)
+    correct, start = [], 0
+    for i, n in enumerate(text_length):
+        n = int(n)
+        correct.append(bool((pred[start:start + n].max(1)[1][:-1] == text_input[i][1:n]).all()))
+        start += n
+    return pred, amap, correct
+
+
+def stroke_focus_loss(P, sr, hr, labels, dic, stroke_lambda=50.0):
+    """stroke_focus_loss.py:83-112 (text_focus on; correct_flag is False there, so every sample takes part)"""
+    mse = F.mse_loss(sr, hr)
+    length, text_input, _ = label_stroke_encoder(labels, dic)
+    with torch.no_grad():
+        _, map_gt, correct_hr = stroke_recognizer(P, to_gray(hr), length, text_input)
+    pred, map_pred, correct_sr = stroke_recognizer(P, to_gray(sr), length, text_input)
+    att = F.l1_loss(map_gt, map_pred)
+    return mse + att * stroke_lambda, mse, att, -1, pred, map_pred, correct_hr, correct_sr

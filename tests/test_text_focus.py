@@ -169,3 +169,105 @@ def test_harness_trains_with_text_focus(tmp_path, monkeypatch):
     cfg.TRAIN.iters_per_epoch, cfg.TRAIN.displayInterval, cfg.TRAIN.saveInterval = 2, 1, 100
     res = M.main(cfg, M.parse(["--arch", "tbsrn", "--STN", "--exp_name", "tf", "--batch_size", "4", "--text_focus"]))
     assert res["images_per_sec"] > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# text-gestalt half of row N1: StrokeFocusLoss + the stroke-level recognizer (fixture tools/make_golden_sfl.py)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_stroke_oracle_matches_reference_fixture(golden_dir):
+    from oracle import tfl_oracle as O
+    g = np.load(os.path.join(golden_dir, "sfl_step.npz"))
+    sc = json.load(open(os.path.join(golden_dir, "sfl_schema.json")))
+    P = O.make_stroke_params()
+    assert [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in P.items()] == sc["schema"]
+    assert "embedding_word_with_upperword.lut.weight" in P and P["generator_word_with_upperword.proj.weight"].shape[0] == 10
+    fill_dict_(P)
+    _, hr, _ = make_batch(4, 1234)
+    labels, dic = sc["labels"], sc["decomposition"]
+    assert "#" in labels[1] and "#" not in dic            # a character without a decomposition is skipped
+    length, text_input, text_gt = O.label_stroke_encoder(labels, dic)
+    assert length.tolist() == sc["length"] and text_input.tolist() == sc["text_input"] and text_gt.tolist() == sc["text_gt"]
+    sr = make_sr(hr).requires_grad_(True)
+    loss, mse, att, rec, pred, amap, c_hr, c_sr = O.stroke_focus_loss(P, sr, hr, labels, dic, sc["stroke_lambda"])
+    assert rec == -1 and g["losses"][3] == -1
+    for got, want in zip((loss, mse, att), g["losses"]):
+        assert abs(got.item() - want) <= 1e-4 * abs(want) + 1e-12, (got.item(), want)
+    assert c_hr == sc["correct_hr"] and c_sr == sc["correct_sr"]
+    assert _rel(pred.detach(), g["pred"]) < 1e-4
+    assert _rel(amap.detach()[:, ::4, :, ::8], g["map_sub"]) < 1e-4
+    d_map, = torch.autograd.grad((amap * map_probe(amap.shape)).sum(), sr, retain_graph=True)
+    assert _rel(d_map[:, :, ::2, ::4], g["dsr_map_sub"]) < 1e-4
+    loss.backward()
+    assert _rel(sr.grad[:, :, ::2, ::4], g["dsr_sub"]) < 1e-4
+    with torch.no_grad():
+        rgbm = torch.cat([sr.detach(), torch.ones_like(sr[:, :1])], 1)
+        pred4, _, _ = O.stroke_recognizer(P, rgbm, length, text_input)
+        assert _rel(pred4, g["pred4"]) < 1e-4
+        _, _, c_mixed = O.stroke_recognizer(P, O.to_gray(sr.detach()), length, torch.tensor(sc["text_input_mixed"]))
+    assert c_mixed == sc["correct_mixed"] and any(c_mixed) and not all(c_mixed)
+
+
+def test_stroke_standin_table_and_encoder_host_logic():
+    """the stand-in decomposition has the file's format (digits 1-9 per character) and is the table the fixture used"""
+    from fudanocr_amd.loss.stroke_focus_loss import standin_decomposition
+    sc = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "sfl_schema.json")))
+    dic = standin_decomposition()
+    assert dic == sc["decomposition"]
+    assert all(1 <= len(v) <= 4 and set(v) <= set("123456789") for v in dic.values()) and len(dic) == 62
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [2, 3], ids=["bf16x3", "dgrad16"])
+def test_stroke_focus_loss_golden(golden_dir, mode):
+    """HIP StrokeFocusLoss (text-gestalt): stroke encoding, 10-class recognizer with the reference's key names, correct_list,
+    loss = mse + stroke_lambda * L1(attention maps), d loss / d SR -- against the reference-generated fixture"""
+    import types
+    from fudanocr_amd import _lib
+    from fudanocr_amd.loss.stroke_focus_loss import StrokeFocusLoss
+    from fudanocr_amd.loss.text_focus_loss import to_gray_tensor
+    from fudanocr_amd.loss.transformer_english_decomposition import Transformer
+    from fudanocr_amd.utils.weight_fill import fill_module_
+    g = np.load(os.path.join(golden_dir, "sfl_step.npz"))
+    sc = json.load(open(os.path.join(golden_dir, "sfl_schema.json")))
+    old = _lib.get_precision()
+    _lib.set_precision(mode)
+    try:
+        tr = fill_module_(Transformer())
+        assert [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in tr.state_dict().items()] == sc["schema"]
+        tr = tr.cuda().eval()
+        for p in tr.parameters():
+            p.requires_grad = False
+        args = types.SimpleNamespace(text_focus=True, stroke_lambda=sc["stroke_lambda"])
+        crit = StrokeFocusLoss(args, transformer=tr, decomposition=sc["decomposition"])
+        _, hr, _ = make_batch(4, 1234)
+        labels = sc["labels"]
+        length, text_input, text_gt = crit.label_stroke_encoder(labels)
+        assert length.tolist() == sc["length"] and text_input.tolist() == sc["text_input"] and text_gt.tolist() == sc["text_gt"]
+        sr = make_sr(hr).cuda().requires_grad_(True)
+        loss, mse, att, rec = crit(sr, hr.cuda(), labels)
+        assert rec == -1
+        for got, want, tol in zip((loss, mse, att), g["losses"], (1e-3, 1e-3, 2e-2)):
+            assert abs(got.item() - want) <= tol * abs(want), (got.item(), want)
+        with torch.no_grad():
+            gray = to_gray_tensor(sr.detach())
+            pred, amap, c_sr = tr(gray, length, text_input)
+            _, _, c_hr = tr(to_gray_tensor(hr.cuda()), length, text_input)
+            pred4, _, _ = tr(torch.cat([sr.detach(), torch.ones_like(sr[:, :1])], 1), length, text_input)
+            _, _, c_mixed = tr(gray, length, torch.tensor(sc["text_input_mixed"]).cuda())
+            assert tr(gray, length, text_input, want_correct=False)[2] is None
+        assert c_sr == sc["correct_sr"] and c_hr == sc["correct_hr"] and c_mixed == sc["correct_mixed"]
+        assert _rel(pred.cpu(), g["pred"]) < 1e-3 and _rel(pred4.cpu(), g["pred4"]) < 1e-3
+        assert _rel(amap.cpu()[:, ::4, :, ::8], g["map_sub"]) < 1e-3
+        sr2 = sr.detach().clone().requires_grad_(True)
+        _, amap2, _ = tr(to_gray_tensor(sr2), length, text_input, want_correct=False)
+        d_map, = torch.autograd.grad((amap2 * map_probe(amap2.shape).cuda()).sum(), sr2)
+        assert _rel_q(d_map.cpu()[:, :, ::2, ::4], g["dsr_map_sub"]) < (2e-2 if mode == 3 else 5e-3)
+        assert _rel(d_map.cpu()[:, :, ::2, ::4], g["dsr_map_sub"]) < 0.15
+        loss.backward()
+        # total gradient = MSE part (exact) + 50 * L1 part (sign of ~1e-8 map differences: loose, see the text-focus test)
+        assert _rel(sr.grad.cpu()[:, :, ::2, ::4], g["dsr_sub"]) < 2e-2
+        off = StrokeFocusLoss(types.SimpleNamespace(text_focus=False), decomposition=sc["decomposition"])(
+            sr.detach(), hr.cuda(), labels)
+        assert off[2] == -1 and off[3] == -1 and abs(off[0].item() - g["losses"][1]) < 1e-3 * g["losses"][1]
+    finally:
+        _lib.set_precision(old)
