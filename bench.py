@@ -190,6 +190,9 @@ def main():
                          "additionally runs the halo-kernel data-gradient convolutions and the attention-backward "
                          "accumulations as single bf16 products; bf16x3 = mode 2; bf16x3-allsplit = mode 1; fp32 = "
                          "exact fp32 MFMA (mode 0)")
+    ap.add_argument("--all-configs", action="store_true",
+                    help="single GPU only: also run c1, c2 and c5 (one subprocess each, 40 timed steps, no CPU baseline) and "
+                         "print their JSON lines BEFORE this configuration's line (which stays the last line)")
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE",
                     help="A/B kernel-selection switch (focr_set_tuning, include/focr.h); reported in config.tuning")
     args = ap.parse_args()
@@ -271,7 +274,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i == args.steps - conv_steps:
-            _lib.add_timing(["focr_conv3x3_frag_fwd", "focr_conv2d_fwd", "focr_conv2d_fwd_ws", "focr_conv2d_wgrad"])
+            _lib.add_timing(["focr_conv3x3_frag_fwd", "focr_conv2d_fwd", "focr_conv2d_fwd_ws", "focr_conv2d_wgrad",
+                             "focr_fe_post_fwd", "focr_fe_post_bwd", "focr_fe_qkv_dgrad"])
         out = step()
     sync()
     dt = time.perf_counter() - t0
@@ -281,6 +285,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     loss = out["loss"].item()
+    mode1_ms = None
+    if world == 1 and cfg == "c3" and mode == 3 and args.steps >= 20:
+        # the same step with split products at EVERY site (mode 1 = fp32-equivalent everywhere), reported beside the
+        # default mode's number in config.mode1_ms_per_step
+        _lib.set_precision(1)
+        for _ in range(5):
+            step()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            step()
+        sync()
+        mode1_ms = (time.perf_counter() - t1) / 20 * 1e3
+        _lib.set_precision(mode)
+    if rank == 0 and world == 1 and args.all_configs:
+        import subprocess
+        for other in ("c1", "c2", "c5"):
+            if other == cfg:
+                continue
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", other, "--steps", "40", "--warmup",
+                                "20", "--no-cpu-baseline", "--precision", args.precision], capture_output=True, text=True)
+            lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            print(lines[-1] if lines else json.dumps({"config": {"name": other}, "error": p.stderr[-400:]}), flush=True)
     if rank == 0:
         value = batch * world * args.steps / dt
         bx3 = mode != 0
@@ -336,6 +363,19 @@ def main():
                     sum(bwd), len(bwd), 3 if bx3 else 1)
             r["launches_per_step"] = len(bwd) // args.steps
             also.append(r)
+        # fused FeatureEnhancer row chains (csrc/fe_chain.hip): HBM-bound; algorithmic bytes = the [rows, 128] fp32
+        # matrices each call reads + writes once (forward pair 8, backward pair 9.5, QKV data gradient 4)
+        for name, nmat, nlaunch in (("focr_fe_post_fwd", 8.0, 2), ("focr_fe_post_bwd", 9.5, 2), ("focr_fe_qkv_dgrad", 4.0, 1)):
+            ev = kt.get(name, [])
+            if ev:
+                rows_ = batch * 1024
+                byt = nmat * rows_ * 512.0
+                ms_ = sum(t for t, _ in ev)
+                gbs = byt * len(ev) / (ms_ * 1e-3) / 1e9
+                also.append({"kernel": name + " (fused FeatureEnhancer row chain, %d launches per call)" % nlaunch,
+                             "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": round(gbs / PEAK_HBM_GBS, 4), "calls_per_step": len(ev) // max(1, conv_steps),
+                             "avg_call_ms": round(ms_ / len(ev), 4), "algorithmic_bytes_per_call": byt})
         roof["also"] = also
         roof["step_algorithmic_tflops"] = round(value * FLOP_PER_IMG[cfg] / world / 1e12, 2)
         roof["step_frac_of_bf16_peak"] = round(value * FLOP_PER_IMG[cfg] / world / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)
@@ -365,7 +405,9 @@ def main():
             "config": {"workload": workload, "name": cfg, "per_gpu_batch": batch, "global_batch": batch * world,
                        "parallelism": "dp%d" % world, "arch": arch if cfg != "c5" else "sld-transformer",
                        "collective_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
-                       "arithmetic": arith},
+                       "arithmetic": arith,
+                       # mode 1 = split products at every site of forward AND backward (fp32-equivalent everywhere)
+                       "mode1_ms_per_step": None if mode1_ms is None else round(mode1_ms, 3)},
             # the bounding roofline of this path is the dense-contraction (MFMA) one; `achieved` is the
             # ALGORITHMIC flop rate of the dominant kernel's launches, `executed_frac` counts the MFMA flops actually
             # issued (3 per algorithmic flop for split products).  hbm_view: the same launches against HBM.

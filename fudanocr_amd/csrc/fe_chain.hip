@@ -512,33 +512,35 @@ __global__ __launch_bounds__(FC_THREADS, 1) void fe_bwd_qkv_kernel(const float* 
 //     dW[o][k] = sum_m dy[m][o] r[m][k]                 = a[k] G[o][k] + b[k] dc[o]
 //     da[k]    = sum_m (dy W)[m][k] xhat[m][k]          = sum_o W[o][k] G[o][k]   (+ extra[k]:       other consumers of r)
 //     db[k]    = sum_m (dy W)[m][k]                     = sum_o W[o][k] dc[o]     (+ extra[128 + k])
-// G | dc: the output of the ordinary weight-gradient kernel run with xhat as its X operand.  One block, 1024 threads.
+// G | dc: the output of the ordinary weight-gradient kernel run with xhat as its X operand.
 // =====================================================================================================================
 __global__ __launch_bounds__(1024) void fe_ln_lin_finish_kernel(const float* __restrict__ G, const float* __restrict__ W,
                                                                const float* __restrict__ a, const float* __restrict__ b,
                                                                const float* __restrict__ extra, float* __restrict__ dW,
                                                                float* __restrict__ dc, float* __restrict__ da,
                                                                float* __restrict__ db, int N) {
-  __shared__ float red[2][8][FC_D];
-  const int k = threadIdx.x & 127, og = threadIdx.x >> 7;
+  // grid: 4 blocks, each 32 columns k x 32 groups of rows o (fixed-order fold of the groups through LDS)
+  __shared__ float red[2][32][33];
+  const int kl = threadIdx.x & 31, og = threadIdx.x >> 5;
+  const int k = blockIdx.x * 32 + kl;
   const float* Gc = G + (size_t)N * FC_D;
   const float ak = a[k], bk = b[k];
   float sa = 0.f, sb = 0.f;
-  for (int o = og; o < N; o += 8) {
+  for (int o = og; o < N; o += 32) {
     const float g = G[(size_t)o * FC_D + k], w = W[(size_t)o * FC_D + k], c = Gc[o];
     dW[(size_t)o * FC_D + k] = ak * g + bk * c;
     sa += w * g;
     sb += w * c;
   }
-  red[0][og][k] = sa;
-  red[1][og][k] = sb;
+  red[0][og][kl] = sa;
+  red[1][og][kl] = sb;
   __syncthreads();
   if (og == 0) {
     float ta = extra ? extra[k] : 0.f, tb = extra ? extra[FC_D + k] : 0.f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      ta += red[0][q][k];
-      tb += red[1][q][k];
+    for (int q = 0; q < 32; ++q) {
+      ta += red[0][q][kl];
+      tb += red[1][q][kl];
     }
     da[k] = ta;
     db[k] = tb;
@@ -574,9 +576,22 @@ __global__ __launch_bounds__(256) void fe_colsum2_kernel(const float* __restrict
 }
 __global__ __launch_bounds__(256) void fe_colsum2_fold_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                               int nblocks) {
+  // grid: 8 blocks x 32 outputs; 8 thread groups each sum a contiguous range of the partials, folded in group order
+  __shared__ float red[8][33];
+  const int il = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + il;
+  const int per = (nblocks + 7) / 8, b0 = g * per, b1 = min(nblocks, b0 + per);
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * 256 + threadIdx.x];
-  out[threadIdx.x] = s;
+#pragma unroll 8
+  for (int b = b0; b < b1; ++b) s += part[(size_t)b * 256 + i];
+  red[g][il] = s;
+  __syncthreads();
+  if (g == 0) {
+    float t = red[0][il];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) t += red[q][il];
+    out[i] = t;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -732,13 +747,13 @@ extern "C" int focr_fe_wgrads(const float* d_out, const float* xhat2, const floa
   if ((rc = focr_conv2d_wgrad(xhat1, d_hpre, G, G + FC_D * FC_D, M, 1, 1, FC_D, FC_D, 1, 1, 0, 0, 0, 0, 0, ws, wsg, stream)))
     return rc;
   hipLaunchKernelGGL(fe_colsum2_kernel, dim3(FC_CS_BLOCKS), 256, 0, stream, d_s2, xhat1, part, rows);
-  hipLaunchKernelGGL(fe_colsum2_fold_kernel, dim3(1), 256, 0, stream, (const float*)part, extra, FC_CS_BLOCKS);
-  hipLaunchKernelGGL(fe_ln_lin_finish_kernel, dim3(1), 1024, 0, stream, (const float*)G, w1, a1, b1, (const float*)extra,
+  hipLaunchKernelGGL(fe_colsum2_fold_kernel, dim3(8), 256, 0, stream, (const float*)part, extra, FC_CS_BLOCKS);
+  hipLaunchKernelGGL(fe_ln_lin_finish_kernel, dim3(4), 1024, 0, stream, (const float*)G, w1, a1, b1, (const float*)extra,
                      g_w1, g_bb1, g_a1, g_b1, FC_D);
   // LN3 -> linear 128 -> 64: G = d_out^T xhat2
   if ((rc = focr_conv2d_wgrad(xhat2, d_out, G, G + 64 * FC_D, M, 1, 1, FC_D, 64, 1, 1, 0, 0, 0, 0, 0, ws, wsg, stream)))
     return rc;
-  hipLaunchKernelGGL(fe_ln_lin_finish_kernel, dim3(1), 1024, 0, stream, (const float*)G, wl, a3, b3, (const float*)nullptr,
+  hipLaunchKernelGGL(fe_ln_lin_finish_kernel, dim3(4), 1024, 0, stream, (const float*)G, wl, a3, b3, (const float*)nullptr,
                      g_wl, g_bl, g_a3, g_b3, 64);
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;

@@ -214,16 +214,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* xp = x + (r0 + rl) * C + col * 4;
     const float* dp = dz + (r0 + rl) * lddz + col * 4;
     const long xstep = (long)rl_n * C, dstep = (long)rl_n * lddz;
-    for (long r = r0 + rl; r < r1; r += rl_n, xp += xstep, dp += dstep) {
-      float4 xv = *reinterpret_cast<const float4*>(xp);
-      float4 dv = *reinterpret_cast<const float4*>(dp);
-      const float xx[4] = {xv.x, xv.y, xv.z, xv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
+    // four rows per iteration: the eight loads are issued together (the kernel was latency-bound with one row pair in
+    // flight per thread: 3.4 TB/s); rows past the slab end are clamped to the last row and weighted 0
+    for (long r = r0 + rl; r < r1; r += 4 * rl_n, xp += 4 * xstep, dp += 4 * dstep) {
+      float4 xv[4], dv[4];
+      float wt[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float xh = (xx[e] - mm[e]) * ii[e];
-        float g = dd[e] * act_grad(gg[e] * xh + bb[e], act);
-        s0[e] += g;
-        s1[e] += g * xh;
+      for (int u = 0; u < 4; ++u) {
+        const bool ok = r + (long)u * rl_n < r1;
+        wt[u] = ok ? 1.f : 0.f;
+        xv[u] = *reinterpret_cast<const float4*>(ok ? xp + u * xstep : xp);
+        dv[u] = *reinterpret_cast<const float4*>(ok ? dp + u * dstep : dp);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float xx[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w}, dd[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float xh = (xx[e] - mm[e]) * ii[e];
+          float g = wt[u] * dd[e] * act_grad(gg[e] * xh + bb[e], act);
+          s0[e] += g;
+          s1[e] += g * xh;
+        }
       }
     }
   }
@@ -726,7 +738,7 @@ extern "C" int focr_bn_eval_fwd(const float* x, const float* gamma, const float*
 // train == 0: eval-mode backward (mean = running_mean, no batch-statistics terms, no dgamma/dbeta, ws unused).
 static inline int bwd_slabs(long rows) {
   long s = (rows + 63) / 64;
-  if (s > 2048) s = 2048;
+  if (s > 512) s = 512;       // 2 blocks per CU: 2048 slabs made the fold (bn_fold2_kernel) as long as the reduction
   if (s < 1) s = 1;
   return (int)s;
 }

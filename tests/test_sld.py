@@ -184,3 +184,21 @@ def test_sld_step_golden(golden_dir, mode):
         assert abs(out2["loss"].item() - traj["loss"][1]) < 5e-2 * traj["loss"][1]
     finally:
         _lib.set_precision(old)
+
+
+@pytest.mark.gpu
+def test_sld_full_size_properties():
+    """BASELINE configs[4] at its per-GPU size (batch 32): size-independent checks of the SLD train step -- finite,
+    decreasing cross-entropy over a few Adadelta steps on a fixed batch, and a deterministic forward (two freshly built
+    engines agree bit for bit on the first loss with dropout off)."""
+    from fudanocr_amd.sld import util
+    from fudanocr_amd.sld.engine import SLDTrainStep
+    image, labels = make_sld_batch(32, 7)
+    length, text_input, text_gt, _ = util.converter("stroke", labels, device="cuda", strokes=True)
+    image = image.cuda()
+    step = SLDTrainStep(_build_gpu(), dropout=True)
+    losses = [step(image, length, text_input, text_gt)["loss"].item() for _ in range(5)]
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0], losses
+    first = [SLDTrainStep(_build_gpu(), dropout=False)(image, length, text_input, text_gt)["loss"].item() for _ in range(2)]
+    assert first[0] == first[1], first

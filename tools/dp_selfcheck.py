@@ -10,8 +10,13 @@ optimisation steps of the configuration and checks
   * the gradient buckets behind the stage boundaries were launched DURING backward (overlap path taken),
   * the all-reduced flat gradient equals the sum of the ranks' local gradients (one extra all_gather of a checksum
     vector per rank: sum / abs-sum / 3 probes -- no 12.8 MB gathers),
+  * (c3) SURVEY 8(e)'s stronger identity: the reduced gradient equals the gradient ONE rank computes for the concatenated
+    global batch with per-shard BatchNorm statistics, i.e. the sum over shards of the single-shard gradients, each
+    recomputed locally from the shard's seed (max abs difference relative to the gradient's max, dropout off),
   * parameters are bit-identical across ranks after the steps,
-and prints per-rank ms/step; rank 0 prints one JSON line with the verdict.  Exit code != 0 on any failure."""
+and prints per-rank ms/step plus the shard loader's images/s on a synthetic uint8 shard (pinned staging + async H2D +
+device transform, no training step attached); rank 0 prints one JSON line with the verdict.  Exit code != 0 on any
+failure."""
 import argparse
 import json
 import os
@@ -25,11 +30,37 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def loader_throughput(dev, rank, world, n=4096, batch=128, epochs=3):
+    """images/s of dataset/shards.py ShardLoader alone (gather thread -> pinned slot -> async H2D -> device ToTensor) on a
+    synthetic TextZoom-shaped uint8 shard in a temporary directory; the first epoch warms the page cache"""
+    import json as _json
+    import tempfile
+    import numpy as np
+    from fudanocr_amd.dataset.shards import ShardDataset, ShardLoader
+    with tempfile.TemporaryDirectory() as d:
+        rs = np.random.RandomState(7)
+        rs.randint(0, 256, (n, 32, 128, 3), dtype=np.uint8).tofile(os.path.join(d, "hr.u8"))
+        rs.randint(0, 256, (n, 16, 64, 3), dtype=np.uint8).tofile(os.path.join(d, "lr.u8"))
+        open(os.path.join(d, "labels.txt"), "w").write("\n".join("w%d" % i for i in range(n)) + "\n")
+        _json.dump({"n": n, "hr": [32, 128, 3], "lr": [16, 64, 3], "format": 1}, open(os.path.join(d, "meta.json"), "w"))
+        ld = ShardLoader(ShardDataset(d), batch, dev, rank=rank, world=world)
+        for _ in ld:
+            pass
+        torch.cuda.synchronize()
+        t0, seen = time.perf_counter(), 0
+        for _ in range(epochs):
+            for hr, lr, _ in ld:
+                seen += hr.shape[0]
+        torch.cuda.synchronize()
+        return seen / (time.perf_counter() - t0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="c3", choices=["c3", "c5"])
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--no-loader", action="store_true", help="skip the shard-loader throughput measurement")
     a = ap.parse_args()
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -70,6 +101,20 @@ def main():
         enc = crit.encode(labels, dev)
         run = lambda: eng(lr, hr, encoded=enc)                        # noqa: E731
         sent = None
+    # ---- reference for the stronger identity (c3): every rank recomputes the single-shard gradient of EVERY shard with
+    # the shared initial weights (world-1 code path of the same engine, optimiser stubbed out) and sums them
+    expected = None
+    if a.config == "c3" and world > 1:
+        keep_world, keep_step = eng.world, eng.opt.step
+        grads = []
+        eng.world = 1
+        eng.opt.step = lambda *_a, **_k: grads.append(eng.flat.flat_grad.detach().clone())
+        for r in range(world):
+            lr_r, hr_r, labels_r = make_batch(a.batch or 16, 1234 + r)
+            eng(lr_r.to(dev), hr_r.to(dev), encoded=crit.encode(labels_r, dev))
+        eng.world, eng.opt.step = keep_world, keep_step
+        expected = torch.stack(grads).sum(0)
+        eng.ctx._mask_cursor = 0
     # ---- step 1 with a gradient audit: snapshot the LOCAL gradient through a hook on the optimiser
     audit = {}
     orig_step = eng.opt.step
@@ -113,6 +158,11 @@ def main():
         for i in (0, 2, 3):
             if abs(mine[i] - probe[i]) > 1e-4 * (abs(probe[i]) + probe[1] * 1e-6):
                 fails.append("reduced gradient checksum %d: %.6e vs sum of locals %.6e" % (i, mine[i], probe[i]))
+        if expected is not None:
+            err = (red - expected).abs().max().item() / (expected.abs().max().item() + 1e-30)
+            if not err <= 1e-4:          # fp32 atomics order in the backward reductions: ~1e-6; a wrong shard / scale: O(1)
+                fails.append("reduced gradient != sum of single-shard gradients (per-shard BN): rel err %.3e" % err)
+            audit["identity_err"] = err
         if a.config == "c3" and len(eng._sent) == 0 and len(local_parts) < 2:
             fails.append("no gradient bucket was launched during backward")
     eng.opt.step = orig_step
@@ -137,8 +187,13 @@ def main():
         dist.all_gather_object(devs, (rank, local, torch.cuda.get_device_name(local)))
         if backend == "nccl" and len({d[1] for d in devs}) != world:
             fails.append("ranks share devices: %s" % devs)
-    print("rank %d dev %d: ms/step %s loss %.5f%s" % (rank, local, ["%.2f" % t for t in times], out["loss"].item(),
-                                                      " FAIL " + "; ".join(fails) if fails else ""), flush=True)
+    loader_ips = None
+    if not a.no_loader:
+        loader_ips = loader_throughput(dev, rank, world)
+    print("rank %d dev %d: ms/step %s loss %.5f identity_err %s loader %s img/s%s" % (
+        rank, local, ["%.2f" % t for t in times], out["loss"].item(),
+        "%.2e" % audit["identity_err"] if "identity_err" in audit else "n/a",
+        "%.0f" % loader_ips if loader_ips else "n/a", " FAIL " + "; ".join(fails) if fails else ""), flush=True)
     allf = [None] * world
     if world > 1:
         dist.all_gather_object(allf, fails)
@@ -146,7 +201,8 @@ def main():
         allf = [fails]
     if rank == 0:
         print(json.dumps({"dp_selfcheck": "ok" if not any(allf) else "FAILED", "world": world, "config": a.config,
-                          "backend": backend, "ms_per_step_rank0": times, "failures": allf}))
+                          "backend": backend, "ms_per_step_rank0": times, "failures": allf,
+                          "identity_err_rank0": audit.get("identity_err"), "loader_img_per_s_rank0": loader_ips}))
     if world > 1:
         dist.destroy_process_group()
     sys.exit(1 if any(allf) else 0)
