@@ -50,7 +50,8 @@ SIGNATURES = {
     "focr_dropout": [P, P, L, F, U, P],
     "focr_fe_chain_supported": [L, I],
     "focr_fe_post_fwd": [P] * 21 + [L, F, F, U, P, P],
-    "focr_fe_post_bwd": [P] * 7 + [F] + [P] * 9 + [L, F, P],
+    "focr_fe_post_bwd": [P] * 7 + [F] + [P] * 9 + [L, F, P, P, I, P],
+    "focr_fe_qkv_fwd": [P, P, P, P, P, P, L, I, P],
     "focr_fe_qkv_dgrad": [P, P, P, P, L, P],
     "focr_fe_wgrads_ws_floats": [L],
     "focr_fe_wgrads": [P] * 31 + [L, L, P],

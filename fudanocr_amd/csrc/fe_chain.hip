@@ -432,7 +432,8 @@ __global__ __launch_bounds__(FC_THREADS, 1) void fe_bwd_a_kernel(
 __global__ __launch_bounds__(FC_THREADS, 1) void fe_bwd_b_kernel(
     const float* __restrict__ dhpre, const float* __restrict__ ds2, const float* __restrict__ W1,
     const float* __restrict__ xhat1, const float* __restrict__ rinv1, const float* __restrict__ a1,
-    const float* __restrict__ Wo, float* __restrict__ ds1, float* __restrict__ dctx, int ntiles, float eps) {
+    const float* __restrict__ Wo, float* __restrict__ ds1, float* __restrict__ dctx, int ntiles, float eps,
+    const float* __restrict__ octx, float* __restrict__ Dw, int ntok) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fc_smem[];
   __bf16* W1th = reinterpret_cast<__bf16*>(fc_smem);
   __bf16* W1tl = W1th + WSZ128;
@@ -464,6 +465,75 @@ __global__ __launch_bounds__(FC_THREADS, 1) void fe_bwd_b_kernel(
       for (int r = 0; r < 16; ++r) d[j][r] = 0.f;
     fc_gemm<4, 8, KP128>(Woth + z, Wotl + z, 0, li, lh, xh, xl, d);
     fc_store_row<4>(dctx + row * FC_D, lh, d);
+    if (Dw) {
+      // D[b][head][token] = sum over the head's 32 columns of dO * O (the attention backward's row term): accumulator
+      // tile j IS head j, so this is an in-lane sum + one exchange -- the separate prep pass over dO and O is gone
+      fc_load_row<4>(octx + row * FC_D, lh, xn);
+      const size_t bi = row / (size_t)ntok, n = row - bi * (size_t)ntok;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float sdot = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sdot += d[j][r] * xn[j][r];
+        sdot = fc_rowsum(sdot);
+        if (lh == 0) Dw[(bi * 4 + j) * (size_t)ntok + n] = sdot;
+      }
+    }
+  }
+}
+
+// =====================================================================================================================
+// forward QKV: tok = [feat | pe[row % ntok]] -> [tok] (column group 0 only) ; qkv[:, 128 y .. 128 y + 127] = tok Wqkv_y^T + b
+// (grid.y = 3 column groups of the packed projection; the concat pass and its 67 MB round trip are gone: the token is
+// assembled in registers from the 64 feature columns and the positional-encoding table, tbsrn.py:83-86)
+// =====================================================================================================================
+__global__ __launch_bounds__(256, 2) void fe_qkv_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ pe,
+                                                           const float* __restrict__ Wqkv,
+                                                           const float* __restrict__ bqkv, float* __restrict__ tok,
+                                                           float* __restrict__ qkv, int ntiles, int ntok) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fc_smem[];
+  __bf16* Wh = reinterpret_cast<__bf16*>(fc_smem);
+  __bf16* Wl = Wh + WSZ128;
+  float* vb = reinterpret_cast<float*>(Wl + WSZ128);
+  const int y = blockIdx.y;
+  {  // stage with 256 threads (fc_stage_* assume FC_THREADS)
+    constexpr int KP = KP128, Q = FC_D / 4;
+    const float* Wg = Wqkv + (size_t)y * FC_D * FC_D;
+    for (int i = threadIdx.x; i < FC_D * Q; i += 256) {
+      const int n = i / Q, c = 4 * (i - n * Q);
+      const float4 v = *reinterpret_cast<const float4*>(Wg + (size_t)n * FC_D + c);
+      const float a[4] = {v.x, v.y, v.z, v.w};
+      fc_bf16x4 h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const __bf16 t = (__bf16)a[e];
+        h[e] = t;
+        l[e] = (__bf16)(a[e] - (float)t);
+      }
+      const int kk = fc_perm(c);
+      *reinterpret_cast<fc_bf16x4*>(&Wh[n * KP + kk]) = h;
+      *reinterpret_cast<fc_bf16x4*>(&Wl[n * KP + kk]) = l;
+    }
+    for (int i = threadIdx.x; i < FC_D; i += 256) vb[i] = bqkv ? bqkv[y * FC_D + i] : 0.f;
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  for (int t = blockIdx.x * 4 + wave; t < ntiles; t += gridDim.x * 4) {
+    const size_t row = (size_t)t * 32 + li;
+    f32x16 v[4];
+    {
+      f32x16 a[2], b[2];
+      fc_load_row<2>(feat + row * 64, lh, a);
+      fc_load_row<2>(pe + (row % (size_t)ntok) * 64, lh, b);
+      v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+    }
+    if (y == 0) fc_store_row<4>(tok + row * FC_D, lh, v);
+    fc_bf16x8 xh[8], xl[8];
+    fc_frags<4>(v, xh, xl);
+    const int z = fc_opaque_zero();
+    fc_load_vec<4>(vb + z, lh, v);
+    fc_gemm<4, 8, KP128>(Wh + z, Wl + z, 0, li, lh, xh, xl, v);
+    fc_store_row<4>(qkv + row * 384 + 128 * y, lh, v);
   }
 }
 
@@ -608,6 +678,7 @@ constexpr size_t FC_LDS_FWD_B = (size_t)(2 * WSZ128 + 2 * 64 * KP128) * 2 + (5 *
 constexpr size_t FC_LDS_BWD_A = (size_t)(2 * FC_D * KP64 + 2 * WSZ128) * 2 + FC_D * 4;
 constexpr size_t FC_LDS_BWD_B = (size_t)4 * WSZ128 * 2 + FC_D * 4;
 constexpr size_t FC_LDS_BWD_QKV = (size_t)2 * 64 * KP384 * 2;
+constexpr size_t FC_LDS_QKV_FWD = (size_t)2 * WSZ128 * 2 + FC_D * 4;
 
 int fc_blocks(int ntiles) {
   int nb = (ntiles + 7) / 8;
@@ -663,11 +734,13 @@ extern "C" int focr_fe_post_fwd(const float* ctx, const float* tok, const float*
 extern "C" int focr_fe_post_bwd(const float* d_out, const float* wl, const float* xhat2, const float* rinv2,
                                 const float* a3, const float* w2, const float* h, float keep_scale, const float* w1,
                                 const float* xhat1, const float* rinv1, const float* a1, const float* wo, float* d_s2,
-                                float* d_hpre, float* d_s1, float* d_ctx, long rows, float eps, hipStream_t stream) {
+                                float* d_hpre, float* d_s1, float* d_ctx, long rows, float eps, const float* ctx,
+                                float* dwork, int ntok, hipStream_t stream) {
   FOCR_CHECK_ARG(d_out && wl && xhat2 && rinv2 && a3 && w2 && h && w1 && xhat1 && rinv1 && a1 && wo && d_s2 && d_hpre &&
                      d_s1 && d_ctx,
                  "null pointer");
   FOCR_CHECK_ARG(focr_fe_chain_supported(rows, FC_D), "rows must be a positive multiple of 32 (precision mode != 0)");
+  FOCR_CHECK_ARG(!dwork || (ctx && ntok > 0 && rows % ntok == 0), "dwork needs ctx and the tokens per image");
   static bool attr = false;
   if (!attr) {
     if (!fc_set_lds(fe_bwd_a_kernel, FC_LDS_BWD_A) || !fc_set_lds(fe_bwd_b_kernel, FC_LDS_BWD_B)) {
@@ -680,7 +753,29 @@ extern "C" int focr_fe_post_bwd(const float* d_out, const float* wl, const float
   hipLaunchKernelGGL(fe_bwd_a_kernel, dim3(nb), FC_THREADS, FC_LDS_BWD_A, stream, d_out, wl, xhat2, rinv2, a3, w2, h,
                      d_s2, d_hpre, ntiles, eps, keep_scale);
   hipLaunchKernelGGL(fe_bwd_b_kernel, dim3(nb), FC_THREADS, FC_LDS_BWD_B, stream, (const float*)d_hpre,
-                     (const float*)d_s2, w1, xhat1, rinv1, a1, wo, d_s1, d_ctx, ntiles, eps);
+                     (const float*)d_s2, w1, xhat1, rinv1, a1, wo, d_s1, d_ctx, ntiles, eps, ctx, dwork, ntok);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+
+// tok [rows,128] = [feat | pe[row % ntok]], qkv [rows,384] = tok Wqkv^T + bqkv (packed q | k | v projection)
+extern "C" int focr_fe_qkv_fwd(const float* feat, const float* pe, const float* wqkv, const float* bqkv, float* tok,
+                               float* qkv, long rows, int ntok, hipStream_t stream) {
+  FOCR_CHECK_ARG(feat && pe && wqkv && tok && qkv && ntok > 0, "bad argument");
+  FOCR_CHECK_ARG(focr_fe_chain_supported(rows, FC_D), "rows must be a positive multiple of 32 (precision mode != 0)");
+  static bool attr = false;
+  if (!attr) {
+    if (!fc_set_lds(fe_qkv_fwd_kernel, FC_LDS_QKV_FWD)) {
+      focr_set_error("focr_fe_qkv_fwd: cannot reserve %zu bytes of LDS", FC_LDS_QKV_FWD);
+      return FOCR_EHIP;
+    }
+    attr = true;
+  }
+  const int ntiles = (int)(rows / 32);
+  int nb = (ntiles + 3) / 4;
+  if (nb > 171) nb = 171;                   // x 3 column groups = 513 blocks: one round at two blocks per CU
+  hipLaunchKernelGGL(fe_qkv_fwd_kernel, dim3(nb, 3), 256, FC_LDS_QKV_FWD, stream, feat, pe, wqkv, bqkv, tok, qkv, ntiles,
+                     ntok);
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }

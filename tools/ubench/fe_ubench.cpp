@@ -93,6 +93,20 @@ __global__ void ref_bwd(P p, const float* dout, const float* xhat2, const float*
   for (int c = 0; c < 64; ++c) { double a = d[c]; for (int n = 0; n < 384; ++n) a += (double)dqkv[m * 384 + n] * p.wqkv[n * D + c]; dfeat[m * 64 + c] = (float)a; }
 }
 
+__global__ void ref_qkv(P p, const float* feat, const float* pe, const float* bqkv, float* tok, float* qkv, long M, int ntok) {
+  long m = (long)blockIdx.x * blockDim.x + threadIdx.x; if (m >= M) return;
+  double t[D];
+  for (int c = 0; c < 64; ++c) { t[c] = feat[m * 64 + c]; t[64 + c] = pe[(m % ntok) * 64 + c]; }
+  for (int c = 0; c < D; ++c) tok[m * D + c] = (float)t[c];
+  for (int n = 0; n < 384; ++n) { double a = bqkv[n]; for (int k = 0; k < D; ++k) a += t[k] * p.wqkv[n * D + k]; qkv[m * 384 + n] = (float)a; }
+}
+__global__ void ref_dwork(const float* dctx, const float* ctx, float* Dw, long M, int ntok) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i >= M * 4) return;
+  long m = i / 4; int h = (int)(i % 4);
+  double a = 0; for (int c = 0; c < 32; ++c) a += (double)dctx[m * D + 32 * h + c] * ctx[m * D + 32 * h + c];
+  Dw[((m / ntok) * 4 + h) * ntok + m % ntok] = (float)a;
+}
+
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 128;
   const long M = (long)B * 1024;
@@ -122,8 +136,9 @@ int main(int argc, char** argv) {
   cmp("xhat1", xhat1, rxhat1, M * D, 2e-5); cmp("rinv1", rinv1, rrinv1, M, 2e-5); cmp("h", h, rh, M * D, 2e-5);
   cmp("xhat2", xhat2, rxhat2, M * D, 2e-5); cmp("rinv2", rinv2, rrinv2, M, 2e-5); cmp("out", out, rout, M * 64, 2e-5);
   // ---- backward (on the reference forward's saved rows, so that the comparison is exact in its inputs)
+  float *dwk = buf(M * 4), *rdwk = buf(M * 4);
   rc = focr_fe_post_bwd(dout, p.wl, rxhat2, rrinv2, p.a3, p.w2, rh, 1.25f, p.w1, rxhat1, rrinv1, p.a1, p.wo, ds2, dhpre, ds1,
-                        dctx, M, eps, 0);
+                        dctx, M, eps, ctx, dwk, 1024, 0);
   if (rc) { printf("focr_fe_post_bwd failed %d\n", rc); return 1; }
   rc = focr_fe_qkv_dgrad(dqkv, p.wqkv, ds1, dfeat, M, 0);
   if (rc) { printf("focr_fe_qkv_dgrad failed %d\n", rc); return 1; }
@@ -133,6 +148,21 @@ int main(int argc, char** argv) {
   printf("backward:\n");
   cmp("d_s2", ds2, rds2, M * D, 2e-5); cmp("d_hpre", dhpre, rdhpre, M * D, 2e-5); cmp("d_s1", ds1, rds1, M * D, 2e-5);
   cmp("d_ctx", dctx, rdctx, M * D, 2e-5); cmp("d_feat", dfeat, rdfeat, M * 64, 4e-5);
+  hipLaunchKernelGGL(ref_dwork, dim3((M * 4 + 255) / 256), 256, 0, 0, rdctx, ctx, rdwk, M, 1024);
+  cmp("D", dwk, rdwk, M * 4, 4e-5);
+  // ---- fused concat-PE + packed QKV projection
+  {
+    float* feat = dalloc(M * 64, 30, 1.f); float* pe = dalloc(1024 * 64, 31, 1.f); float* bqkv = dalloc(384, 32, 0.1f);
+    float *tk = buf(M * D), *qk = buf(M * 384), *rtk = buf(M * D), *rqk = buf(M * 384);
+    rc = focr_fe_qkv_fwd(feat, pe, p.wqkv, bqkv, tk, qk, M, 1024, 0);
+    if (rc) { printf("focr_fe_qkv_fwd failed %d\n", rc); return 1; }
+    hipLaunchKernelGGL(ref_qkv, dim3((M + 63) / 64), 64, 0, 0, p, feat, pe, bqkv, rtk, rqk, M, 1024);
+    CK(hipDeviceSynchronize());
+    printf("qkv forward:\n");
+    cmp("tok", tk, rtk, M * D, 0.0); cmp("qkv", qk, rqk, M * 384, 2e-5);
+    float tq = timeit([&] { focr_fe_qkv_fwd(feat, pe, p.wqkv, bqkv, tk, qk, M, 1024, 0); });
+    printf("fe_qkv_fwd %7.1f us  %.2f TB/s (5.5 row matrices)\n", tq, 5.5 * (double)M * D * 4 / tq * 1e-6);
+  }
   // ---- dropout statistics: kept elements equal scale * reference, dropped fraction of the positive ones ~ p
   rc = focr_fe_post_fwd(ctx, tok, xin, p.wo, p.bo, p.a1, p.b1, p.w1, p.bb1, p.w2, p.bb2, p.a3, p.b3, p.wl, p.bl, xhat1,
                         rinv1, h, xhat2, rinv2, out, M, eps, 0.1f, 99, &ks, 0);
@@ -153,8 +183,8 @@ int main(int argc, char** argv) {
   printf("fe_fwd_b   %7.1f us  %.2f TB/s (4 row matrices)\n", t, 4 * T / t * 1e-6);
   t = timeit([&] { hipLaunchKernelGGL(fe_bwd_a_kernel, dim3(fc_blocks(M / 32)), FC_THREADS, FC_LDS_BWD_A, 0, dout, p.wl, rxhat2, rrinv2, p.a3, p.w2, rh, ds2, dhpre, (int)(M / 32), eps, 1.25f); });
   printf("fe_bwd_a   %7.1f us  %.2f TB/s (4.5 row matrices)\n", t, 4.5 * T / t * 1e-6);
-  t = timeit([&] { hipLaunchKernelGGL(fe_bwd_b_kernel, dim3(fc_blocks(M / 32)), FC_THREADS, FC_LDS_BWD_B, 0, (const float*)dhpre, (const float*)ds2, p.w1, rxhat1, rrinv1, p.a1, p.wo, ds1, dctx, (int)(M / 32), eps); });
-  printf("fe_bwd_b   %7.1f us  %.2f TB/s (5 row matrices)\n", t, 5 * T / t * 1e-6);
+  t = timeit([&] { hipLaunchKernelGGL(fe_bwd_b_kernel, dim3(fc_blocks(M / 32)), FC_THREADS, FC_LDS_BWD_B, 0, (const float*)dhpre, (const float*)ds2, p.w1, rxhat1, rrinv1, p.a1, p.wo, ds1, dctx, (int)(M / 32), eps, (const float*)ctx, dwk, 1024); });
+  printf("fe_bwd_b   %7.1f us  %.2f TB/s (6 row matrices, incl. D)\n", t, 6 * T / t * 1e-6);
   t = timeit([&] { hipLaunchKernelGGL(fe_bwd_qkv_kernel, dim3(fc_blocks(M / 32)), FC_THREADS, FC_LDS_BWD_QKV, 0, dqkv, p.wqkv, (const float*)ds1, dfeat, (int)(M / 32), D); });
   printf("fe_bwd_qkv %7.1f us  %.2f TB/s (4 row matrices)\n", t, 4 * T / t * 1e-6);
   return 0;
