@@ -16,5 +16,5 @@ F=$(find gpurun_out/p_${TAG}_FETCH_SIZE -name "*.db" | head -1); W=$(find gpurun
 python tools/pmc_traffic.py $F $W 128 "$TAG: rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- $B" gpurun_out/${TAG}_pmc_traffic.json
 python tools/rocpd_pmc.py $F gpurun_out/${TAG}_pmc_FETCH_SIZE.csv; python tools/rocpd_pmc.py $W gpurun_out/${TAG}_pmc_WRITE_SIZE.csv
 M=$(find gpurun_out/p_${TAG}_mfma -name "*.db" | head -1); python tools/rocpd_pmc.py $M gpurun_out/${TAG}_pmc_mfma.csv
-rm -rf gpurun_out/p_${TAG}_kt gpurun_out/p_${TAG}_FETCH_SIZE gpurun_out/p_${TAG}_WRITE_SIZE gpurun_out/p_${TAG}_mfma
+python tools/rocpd_bygrid.py $DB "" 13 > gpurun_out/${TAG}_all_bygrid.txt; python tools/rocpd_gaps.py $DB clip_adam 6 > gpurun_out/${TAG}_gaps.txt; python tools/pmc_mfma_util.py gpurun_out/${TAG}_pmc_mfma.csv > gpurun_out/${TAG}_mfma_util.txt 2>&1; rm -rf gpurun_out/p_${TAG}_kt gpurun_out/p_${TAG}_FETCH_SIZE gpurun_out/p_${TAG}_WRITE_SIZE gpurun_out/p_${TAG}_mfma
 head -12 gpurun_out/${TAG}_bench_kernel_stats.csv | cut -c1-120; cat gpurun_out/${TAG}_pmc_traffic.json | head -30
