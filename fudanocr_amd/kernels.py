@@ -981,115 +981,269 @@ def fe_chain_supported(feat):
                 and _lib.load().focr_fe_chain_supported(feat.shape[0] * feat.shape[1], 128))
 
 
+FE_PARAM_NAMES = ("wqkv", "bqkv", "wo", "bo", "a1", "b1", "w1", "bb1", "w2", "bb2", "a3", "b3", "wl", "bl")
+
+
+def _fe_forward(step, feat, xres, pe, heads, p_attn, p_ffn, eps, params):
+    """forward of the block on tokens feat [B, T, 64] -> (out [B, T, 64], saved tensors, cfg)"""
+    wqkv, bqkv, wo, bo, a1, b1, w1, bb1, w2, bb2, a3, b3, wl, bl = params
+    b, t, cf = feat.shape
+    rows, d = b * t, 128
+    dev = feat.device
+    tok = torch.empty((b, t, d), device=dev)
+    qkv = torch.empty((b, t, 3 * d), device=dev)
+    if pe.shape[0] != t or pe.shape[-1] != 64:
+        raise RuntimeError("positional-encoding table must be [tokens per image, 64]")
+    _lib.call("focr_fe_qkv_fwd", _p(feat), _p(pe), _p(wqkv), _p(bqkv), _p(tok), _p(qkv), rows, t, _stream())
+    o = torch.empty((b, t, d), device=dev)
+    lse = torch.empty((b, heads, t), device=dev)
+    mask, ready = step.next_mask(b, heads, t, p_attn, dev) if p_attn > 0 else (None, False)
+    scale = 1.0 / math.sqrt(d // heads)
+    if ready:
+        _lib.call("focr_attention_fwd_premasked", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _p(o), _p(lse),
+                  _p(mask), b, heads, t, 3 * d, d, scale, float(p_attn), _stream())
+    else:
+        _lib.call("focr_attention_fwd", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _p(o), _p(lse), _p(mask), b,
+                  heads, t, 3 * d, d, scale, float(p_attn), _new_seed() if p_attn > 0 else 0, _stream())
+    xhat1, xhat2, h = torch.empty_like(tok), torch.empty_like(tok), torch.empty_like(tok)
+    rinv1, rinv2 = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    out = torch.empty((b, t, cf), device=dev)
+    ks = ctypes.c_float(1.0)
+    _lib.call("focr_fe_post_fwd", _p(o), _p(tok), _p(xres), _p(wo), _p(bo), _p(a1), _p(b1), _p(w1), _p(bb1),
+              _p(w2), _p(bb2), _p(a3), _p(b3), _p(wl), _p(bl), _p(xhat1), _p(rinv1), _p(h), _p(xhat2), _p(rinv2),
+              _p(out), rows, float(eps), float(p_ffn), _new_seed() if p_ffn > 0 else 0, ctypes.byref(ks), _stream())
+    cfg = (b, t, heads, scale, float(p_attn), float(eps), float(ks.value))
+    return out, (tok, qkv, o, lse, mask, xhat1, rinv1, h, xhat2, rinv2), cfg
+
+
+def _fe_backward(step, saved, cfg, params, targets, d_out, need_dfeat, need_params, clone_for_side=None):
+    """backward of the block: -> (d_feat or None, parameter gradients (None where a flat-buffer target took them)).
+    d_out [B, T, 64] is ALSO the gradient of the block's residual input; the caller routes it.  clone_for_side: callable
+    invoked when the weight gradients go to the side stream (the caller may have to protect d_out from in-place reuse)."""
+    tok, qkv, o, lse, mask, xhat1, rinv1, h, xhat2, rinv2 = saved
+    wqkv, bqkv, wo, bo, a1, b1, w1, bb1, w2, bb2, a3, b3, wl, bl = params
+    b, t, heads, scale, p_attn, eps, keep_scale = cfg
+    rows, d = b * t, 128
+    dev = d_out.device
+    d_s2, d_hpre, d_s1, d_ctx = (torch.empty_like(tok) for _ in range(4))
+    work = torch.empty((b, heads, t), device=dev)
+    _lib.call("focr_fe_post_bwd", _p(d_out), _p(wl), _p(xhat2), _p(rinv2), _p(a3), _p(w2), _p(h), keep_scale,
+              _p(w1), _p(xhat1), _p(rinv1), _p(a1), _p(wo), _p(d_s2), _p(d_hpre), _p(d_s1), _p(d_ctx), rows, eps,
+              _p(o), _p(work), t, _stream())
+    dqkv = torch.empty_like(qkv)
+    # o = NULL: `work` already holds D = rowsum(d_ctx * o) per (b, head, token), written by the chain kernel above
+    _lib.call("focr_attention_bwd", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _NULL, _p(d_ctx), _p(lse), _p(mask),
+              _po(dqkv, 0), _po(dqkv, d), _po(dqkv, 2 * d), _p(work), b, heads, t, 3 * d, d, scale, p_attn,
+              _stream())
+    d_feat = None
+    if need_dfeat:
+        d_feat = torch.empty((b, t, 64), device=dev)
+        _lib.call("focr_fe_qkv_dgrad", _p(dqkv), _p(wqkv), _p(d_s1), _p(d_feat), rows, _stream())
+    # parameter gradients: one library call, on the side stream when every target is a flat-buffer slice
+    grads = [None] * len(FE_PARAM_NAMES)
+    if need_params:
+        tg = list(targets)
+        flat = all(x is not None for x in tg)
+        if not flat:
+            tg = [torch.empty_like(p_, memory_format=torch.contiguous_format) for p_ in params]
+            grads = list(tg)
+        side = step.side_stream() if flat else None
+        nws = _lib.load().focr_fe_wgrads_ws_floats(rows)
+        if side is not None:
+            if clone_for_side is not None:
+                clone_for_side()
+            ev = torch.cuda.Event()
+            ev.record()
+            side.wait_event(ev)
+            for x in (d_out, xhat2, d_s2, h, d_hpre, xhat1, d_s1, o, dqkv, tok):
+                x.record_stream(side)
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            ws = torch.empty(nws, device=dev)
+            g = dict(zip(FE_PARAM_NAMES, tg))
+            _lib.call("focr_fe_wgrads", _p(d_out), _p(xhat2), _p(d_s2), _p(h), _p(d_hpre), _p(xhat1), _p(d_s1),
+                      _p(o), _p(dqkv), _p(tok), _p(wl), _p(w1), _p(a1), _p(b1), _p(a3), _p(b3), _p(g["wl"]),
+                      _p(g["bl"]), _p(g["a3"]), _p(g["b3"]), _p(g["w2"]), _p(g["bb2"]), _p(g["w1"]), _p(g["bb1"]),
+                      _p(g["a1"]), _p(g["b1"]), _p(g["wo"]), _p(g["bo"]), _p(g["wqkv"]), _p(g["bqkv"]), _p(ws),
+                      nws, rows, _stream())
+    return d_feat, grads
+
+
 class _FeatureEnhancerFused(torch.autograd.Function):
-    N_PARAMS = 14          # wqkv bqkv wo bo a1 b1 w1 bb1 w2 bb2 a3 b3 wl bl
+    N_PARAMS = len(FE_PARAM_NAMES)
 
     @staticmethod
     def forward(ctx, feat, xres, pe, heads, p_attn, p_ffn, eps, defer_residual, *params):
-        wqkv, bqkv, wo, bo, a1, b1, w1, bb1, w2, bb2, a3, b3, wl, bl = params
         ctx.step = step = current_context()
-        b, t, cf = feat.shape
-        rows, d = b * t, 128
         _chk(feat, xres, pe, *params)
-        dev = feat.device
-        tok = torch.empty((b, t, d), device=dev)
-        qkv = torch.empty((b, t, 3 * d), device=dev)
-        if pe.shape[0] != t or pe.shape[-1] != 64:
-            raise RuntimeError("positional-encoding table must be [tokens per image, 64]")
-        _lib.call("focr_fe_qkv_fwd", _p(feat), _p(pe), _p(wqkv), _p(bqkv), _p(tok), _p(qkv), rows, t, _stream())
-        o = torch.empty((b, t, d), device=dev)
-        lse = torch.empty((b, heads, t), device=dev)
-        mask, ready = step.next_mask(b, heads, t, p_attn, dev) if p_attn > 0 else (None, False)
-        scale = 1.0 / math.sqrt(d // heads)
-        if ready:
-            _lib.call("focr_attention_fwd_premasked", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _p(o), _p(lse),
-                      _p(mask), b, heads, t, 3 * d, d, scale, float(p_attn), _stream())
-        else:
-            _lib.call("focr_attention_fwd", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _p(o), _p(lse), _p(mask), b,
-                      heads, t, 3 * d, d, scale, float(p_attn), _new_seed() if p_attn > 0 else 0, _stream())
-        xhat1, xhat2, h = torch.empty_like(tok), torch.empty_like(tok), torch.empty_like(tok)
-        rinv1, rinv2 = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
-        out = torch.empty((b, t, cf), device=dev)
-        ks = ctypes.c_float(1.0)
-        _lib.call("focr_fe_post_fwd", _p(o), _p(tok), _p(xres), _p(wo), _p(bo), _p(a1), _p(b1), _p(w1), _p(bb1),
-                  _p(w2), _p(bb2), _p(a3), _p(b3), _p(wl), _p(bl), _p(xhat1), _p(rinv1), _p(h), _p(xhat2), _p(rinv2),
-                  _p(out), rows, float(eps), float(p_ffn), _new_seed() if p_ffn > 0 else 0, ctypes.byref(ks), _stream())
-        ctx.cfg = (b, t, heads, scale, float(p_attn), float(eps), float(ks.value))
+        out, saved, ctx.cfg = _fe_forward(step, feat, xres, pe, heads, p_attn, p_ffn, eps, params)
         ctx.defer_residual = bool(defer_residual) and xres is not None
         ctx.res_key = _dkey(xres) if ctx.defer_residual else None
         ctx.targets = tuple(_target(p_) for p_ in params)
-        ctx.save_for_backward(tok, qkv, o, lse, mask, xhat1, rinv1, h, xhat2, rinv2, *params)
+        ctx.save_for_backward(*saved, *params)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        tok, qkv, o, lse, mask, xhat1, rinv1, h, xhat2, rinv2 = ctx.saved_tensors[:10]
-        params = ctx.saved_tensors[10:]
-        wqkv, bqkv, wo, bo, a1, b1, w1, bb1, w2, bb2, a3, b3, wl, bl = params
-        b, t, heads, scale, p_attn, eps, keep_scale = ctx.cfg
+        saved, params = ctx.saved_tensors[:10], ctx.saved_tensors[10:]
         step = ctx.step
-        rows, d = b * t, 128
-        dev = dy.device
         d_out = dy.contiguous()
-        d_s2, d_hpre, d_s1, d_ctx = (torch.empty_like(tok) for _ in range(4))
-        work = torch.empty((b, heads, t), device=dev)
-        _lib.call("focr_fe_post_bwd", _p(d_out), _p(wl), _p(xhat2), _p(rinv2), _p(a3), _p(w2), _p(h), keep_scale,
-                  _p(w1), _p(xhat1), _p(rinv1), _p(a1), _p(wo), _p(d_s2), _p(d_hpre), _p(d_s1), _p(d_ctx), rows, eps,
-                  _p(o), _p(work), t, _stream())
-        dqkv = torch.empty_like(qkv)
-        # o = NULL: `work` already holds D = rowsum(d_ctx * o) per (b, head, token), written by the chain kernel above
-        _lib.call("focr_attention_bwd", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _NULL, _p(d_ctx), _p(lse), _p(mask),
-                  _po(dqkv, 0), _po(dqkv, d), _po(dqkv, 2 * d), _p(work), b, heads, t, 3 * d, d, scale, p_attn,
-                  _stream())
-        d_feat = None
-        if ctx.needs_input_grad[0]:
-            d_feat = torch.empty((b, t, 64), device=dev)
-            _lib.call("focr_fe_qkv_dgrad", _p(dqkv), _p(wqkv), _p(d_s1), _p(d_feat), rows, _stream())
         # residual gradient of the block input: parked for the data-gradient kernel of its other consumer (the block's
         # first convolution), or handed to autograd
-        dres = None
+        box = {"dres": None}
         if ctx.needs_input_grad[1]:
             if ctx.defer_residual:
                 if ctx.res_key in step.deferred:
                     raise RuntimeError("two deferred gradients for the same tensor")
                 step.deferred[ctx.res_key] = d_out
             else:
-                dres = d_out
-        # parameter gradients: one library call, on the side stream when every target is a flat-buffer slice
-        grads = [None] * _FeatureEnhancerFused.N_PARAMS
-        if any(ctx.needs_input_grad[8:]):
-            tg = list(ctx.targets)
-            flat = all(x is not None for x in tg)
-            if not flat:
-                tg = [torch.empty_like(p_, memory_format=torch.contiguous_format) for p_ in params]
-                grads = list(tg)
-            side = step.side_stream() if flat else None
-            nws = _lib.load().focr_fe_wgrads_ws_floats(rows)
-            if side is not None:
-                if dres is not None:
-                    dres = dres.clone()      # autograd may accumulate into it in place while the side stream reads d_out
-                ev = torch.cuda.Event()
-                ev.record()
-                side.wait_event(ev)
-                for x in (d_out, xhat2, d_s2, h, d_hpre, xhat1, d_s1, o, dqkv, tok):
-                    x.record_stream(side)
-            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-                ws = torch.empty(nws, device=dev)
-                # order of the targets: wqkv bqkv wo bo a1 b1 w1 bb1 w2 bb2 a3 b3 wl bl
-                g = dict(zip(("wqkv", "bqkv", "wo", "bo", "a1", "b1", "w1", "bb1", "w2", "bb2", "a3", "b3", "wl", "bl"),
-                             tg))
-                _lib.call("focr_fe_wgrads", _p(d_out), _p(xhat2), _p(d_s2), _p(h), _p(d_hpre), _p(xhat1), _p(d_s1),
-                          _p(o), _p(dqkv), _p(tok), _p(wl), _p(w1), _p(a1), _p(b1), _p(a3), _p(b3), _p(g["wl"]),
-                          _p(g["bl"]), _p(g["a3"]), _p(g["b3"]), _p(g["w2"]), _p(g["bb2"]), _p(g["w1"]), _p(g["bb1"]),
-                          _p(g["a1"]), _p(g["b1"]), _p(g["wo"]), _p(g["bo"]), _p(g["wqkv"]), _p(g["bqkv"]), _p(ws),
-                          nws, rows, _stream())
-        return (d_feat, dres, None, None, None, None, None, None) + tuple(grads)
+                box["dres"] = d_out
+
+        def protect():      # autograd may accumulate into dres in place while the side stream still reads d_out
+            if box["dres"] is not None:
+                box["dres"] = box["dres"].clone()
+        d_feat, grads = _fe_backward(step, saved, ctx.cfg, params, ctx.targets, d_out, ctx.needs_input_grad[0],
+                                     any(ctx.needs_input_grad[8:]), protect)
+        return (d_feat, box["dres"], None, None, None, None, None, None) + tuple(grads)
 
 
 def feature_enhancer_fused(feat, xres, pe, params, heads=4, p_attn=0.0, p_ffn=0.0, eps=1e-6, defer_residual=False):
     """params: (wqkv [384,128], bqkv, wo, bo, a1, b1, w1, bb1, w2, bb2, a3, b3, wl [64,128], bl) -- tbsrn.py:76-92"""
     return _FeatureEnhancerFused.apply(feat, xres, pe, int(heads), float(p_attn), float(p_ffn), float(eps),
                                        bool(defer_residual), *params)
+
+
+# ----------------------------------------------------------------------------------------
+# A whole TBSRN residual block (reference tbsrn.py:246-257) as ONE autograd node in training mode:
+#   conv3x3 -> BatchNorm(batch statistics) -> mish -> conv3x3 -> BatchNorm -> FeatureEnhancer (+ block input).
+# Same library calls as the per-layer nodes (halo convolution with the BatchNorm partial sums in its epilogue, statistics
+# fold + apply, the fused FeatureEnhancer chains), but ~13 forward + ~17 backward calls are issued from two Python
+# functions instead of five autograd nodes each way: the host side of the step is what bounds the small-batch
+# configurations.  The block input's residual gradient rides in the epilogue of the first convolution's data gradient.
+# ----------------------------------------------------------------------------------------
+def srb_fused_supported(x, conv1, conv2, bn1, bn2):
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[-1] == 64 and x.is_contiguous()):
+        return False
+    n, h, w, c = x.shape
+    for cv in (conv1, conv2):
+        if tuple(cv.weight.shape) != (64, 64, 3, 3) or tuple(cv.padding) != (1, 1) or cv.bias is None:
+            return False
+    if not all((bn.training or not bn.track_running_stats) and bn.track_running_stats for bn in (bn1, bn2)):
+        return False
+    return bool(_halo_ok(h, w, 64, 64, 3, 3, 1, 1) and _lib.load().focr_fe_chain_supported(n * h * w, 128))
+
+
+class _SRBFused(torch.autograd.Function):
+    N_CONV = 8           # w1 c1 g1 be1 w2 c2 g2 be2 (conv weight / bias, BatchNorm weight / bias, twice)
+
+    @staticmethod
+    def forward(ctx, x, pe, heads, p_attn, p_ffn, eps_ln, bn_cfg, bn_bufs, *params):
+        """bn_cfg: ((momentum1, eps1), (momentum2, eps2)); bn_bufs: running_mean / running_var / num_batches_tracked of
+        the two BatchNorms (updated in place, as nn.BatchNorm2d does); params: the 8 conv / BatchNorm tensors, then the
+        14 FeatureEnhancer tensors (FE_PARAM_NAMES)"""
+        ctx.step = step = current_context()
+        cparams, fparams = params[:_SRBFused.N_CONV], params[_SRBFused.N_CONV:]
+        _chk(x, pe, *params)
+        n, h, w, c = x.shape
+        rows = n * h * w
+        dev = x.device
+        lib = _lib.load()
+        tiles = lib.focr_conv3x3_frag_tiles(n, h, w)
+        ys, zs, means, invs = [], [], [], []
+        inp = x
+        for i in range(2):
+            wgt, bias, gamma, beta = cparams[4 * i:4 * i + 4]
+            rmean, rvar, nbt = bn_bufs[3 * i:3 * i + 3]
+            mom, eps_bn = bn_cfg[i]
+            frag = _frag_weights(step, wgt, _ohwi(wgt), 64, 3, 3, 64, False)
+            y = torch.empty((n, h, w, 64), device=dev)
+            stats = torch.empty((tiles, 64, 2), device=dev)
+            _lib.call("focr_conv3x3_frag_fwd", _p(inp), ctypes.c_void_p(frag.data_ptr()), _p(bias), _NULL, _p(y),
+                      _p(stats), n, h, w, 64, 64, 1.0, 0, 2, 0, 0, 0, _stream())
+            z = torch.empty_like(y)
+            mean, invstd = torch.empty(64, device=dev), torch.empty(64, device=dev)
+            _lib.call("focr_bn_train_fwd_stats", _p(y), _p(stats), tiles, _p(gamma), _p(beta), _p(rmean), _p(rvar),
+                      _p(nbt), _NULL, _p(z), _p(mean), _p(invstd), rows, 64, float(mom), float(eps_bn),
+                      ACT_MISH if i == 0 else ACT_NONE, _stream())
+            ys.append(y), zs.append(z), means.append(mean), invs.append(invstd)
+            inp = z
+        out, fsaved, ctx.cfg = _fe_forward(step, zs[1].view(n, h * w, 64), x.view(n, h * w, 64), pe, heads, p_attn,
+                                           p_ffn, eps_ln, fparams)
+        ctx.geom = (n, h, w)
+        ctx.targets = tuple(_target(p_) for p_ in params)
+        ctx.save_for_backward(x, ys[0], zs[0], ys[1], means[0], invs[0], means[1], invs[1], *fsaved, *params)
+        return out.view(n, h, w, 64)
+
+    @staticmethod
+    def backward(ctx, dy):
+        t = ctx.saved_tensors
+        x, y1, z1, y2, mean1, inv1, mean2, inv2 = t[:8]
+        fsaved, params = t[8:18], t[18:]
+        cparams, fparams = params[:_SRBFused.N_CONV], params[_SRBFused.N_CONV:]
+        step = ctx.step
+        n, h, w = ctx.geom
+        rows = n * h * w
+        dev = dy.device
+        lib = _lib.load()
+        d_out = dy.contiguous().view(n, h * w, 64)
+        need_p = any(ctx.needs_input_grad[8:])
+        d_feat, fgrads = _fe_backward(step, fsaved, ctx.cfg, fparams, ctx.targets[_SRBFused.N_CONV:], d_out, True,
+                                      need_p)
+        grads = [None] * _SRBFused.N_CONV
+        planes = 1 if _lib.get_precision() == 3 else 2
+        dz = d_feat.view(n, h, w, 64)
+        dx = None
+        for i in (1, 0):
+            wgt, bias, gamma, beta = cparams[4 * i:4 * i + 4]
+            tw, tb, tg, tbe = ctx.targets[4 * i:4 * i + 4]
+            yy, mean, invstd = (y2, mean2, inv2) if i == 1 else (y1, mean1, inv1)
+            cin = z1 if i == 1 else x
+            # BatchNorm backward (batch statistics): dgamma / dbeta straight into their targets, then d(conv output)
+            dg = tg if tg is not None else torch.empty(64, device=dev)
+            db = tbe if tbe is not None else torch.empty(64, device=dev)
+            ws = torch.empty(lib.focr_bn_bwd_ws_floats(rows, 64), device=dev)
+            dyc = torch.empty_like(yy)
+            _lib.call("focr_bn_bwd", _p(dz), _p(yy), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(dyc), _p(dg), _p(db),
+                      _p(ws), rows, 64, ACT_MISH if i == 0 else ACT_NONE, 1, 0, _stream())
+            if tg is None:
+                grads[4 * i + 2] = dg
+            if tbe is None:
+                grads[4 * i + 3] = db
+            # convolution weight / bias gradient: side stream when the targets are flat-buffer slices
+            if need_p:
+                flat = tw is not None and tb is not None
+                dw = tw if flat else torch.empty((64, 3, 3, 64), device=dev).permute(0, 3, 1, 2)
+                dbias = tb if flat else torch.empty(64, device=dev)
+                side = step.side_stream() if flat else None
+                if side is not None:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    side.wait_event(ev)
+                    cin.record_stream(side)
+                    dyc.record_stream(side)
+                with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                    nws = lib.focr_conv2d_wgrad_ws_floats(n, h, w, 64, 64, 3, 3, 1, 1)
+                    wsw = torch.empty(nws, device=dev) if nws > 0 else None
+                    _lib.call("focr_conv2d_wgrad", _p(cin), _p(dyc), _p(dw), _p(dbias), n, h, w, 64, 64, 3, 3, 1, 1, 0,
+                              0, int(flat), _p(wsw), nws, _stream())
+                if not flat:
+                    grads[4 * i], grads[4 * i + 1] = dw, dbias
+            # data gradient on the halo kernel (flipped fragment weights); the block input's residual gradient (= d_out)
+            # is added in the epilogue of the FIRST convolution's data gradient
+            wf = _frag_weights(step, wgt, _ohwi(wgt), 64, 3, 3, 64, True)
+            dzn = torch.empty((n, h, w, 64), device=dev)
+            _lib.call("focr_conv3x3_frag_fwd", _p(dyc), ctypes.c_void_p(wf.data_ptr()), _NULL,
+                      _p(d_out) if i == 0 else _NULL, _p(dzn), _NULL, n, h, w, 64, 64, 1.0, 0, planes, 0, 0, 0, _stream())
+            dz = dzn
+        dx = dz if ctx.needs_input_grad[0] else None
+        return (dx, None, None, None, None, None, None, None) + tuple(grads) + tuple(fgrads)
+
+
+def srb_fused(x, pe, conv1, bn1, conv2, bn2, fe_params, heads=4, p_attn=0.0, p_ffn=0.0, eps_ln=1e-6):
+    bufs = (bn1.running_mean, bn1.running_var, bn1.num_batches_tracked, bn2.running_mean, bn2.running_var,
+            bn2.num_batches_tracked)
+    cfgs = ((bn1.momentum, bn1.eps), (bn2.momentum, bn2.eps))
+    return _SRBFused.apply(x, pe, int(heads), float(p_attn), float(p_ffn), float(eps_ln), cfgs, bufs, conv1.weight,
+                           conv1.bias, bn1.weight, bn1.bias, conv2.weight, conv2.bias, bn2.weight, bn2.bias, *fe_params)
 
 
 class _Dropout(torch.autograd.Function):

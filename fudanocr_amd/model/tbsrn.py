@@ -19,6 +19,8 @@ from .tps_spatial_transformer import TPSSpatialTransformer
 
 # FOCR_FE_FUSED=0: the FeatureEnhancer as separate per-layer kernels (A/B measurements; precision mode 0 always does)
 _FE_FUSED = os.environ.get("FOCR_FE_FUSED", "1") != "0"
+# FOCR_SRB_FUSED=0: one autograd node per layer of a residual block instead of one per block (A/B: host time)
+_SRB_FUSED = os.environ.get("FOCR_SRB_FUSED", "1") != "0"
 
 
 def positionalencoding2d(d_model, height, width):
@@ -111,6 +113,22 @@ class FeatureEnhancer(nn.Module):
             self._pe = positionalencoding2d(64, 16, 64).reshape(64, 1024).t().contiguous().to(device)
         return self._pe
 
+    def _fused_params(self):
+        """the 14 tensors of kernels.FE_PARAM_NAMES (packed q | k | v projection first)"""
+        mh, ln1, ln3, pff = self.multihead, self.mul_layernorm1, self.mul_layernorm3, self.pff
+        assert ln1.eps == ln3.eps and mh.h == 4
+        if mh._packed_qkv is not None and mh._packed_qkv[0].data_ptr() == mh.linears[0].weight.data_ptr():
+            wqkv, bqkv = mh._packed_qkv       # views of the engine's flat buffers
+        else:
+            wqkv = torch.cat([mh.linears[0].weight, mh.linears[1].weight, mh.linears[2].weight], 0)
+            bqkv = torch.cat([mh.linears[0].bias, mh.linears[1].bias, mh.linears[2].bias], 0)
+        return (wqkv, bqkv, mh.linears[3].weight, mh.linears[3].bias, ln1.a_2, ln1.b_2, pff.w_1.weight, pff.w_1.bias,
+                pff.w_2.weight, pff.w_2.bias, ln3.a_2, ln3.b_2, self.linear.weight, self.linear.bias)
+
+    def _fused_dropout(self):
+        mh, pff = self.multihead, self.pff
+        return (mh.dropout.p if mh.dropout.training else 0.0, pff.dropout.p if pff.dropout.training else 0.0)
+
     def forward(self, conv_feature, residual=None, defer_block_input=False):
         """conv_feature: [B, 1024, 64] tokens (channel-last) -> [B, 1024, 64] (+ residual)."""
         # Each of tok / r / the block input feeds a GEMM AND a later residual slot: the residual consumer parks its
@@ -119,19 +137,10 @@ class FeatureEnhancer(nn.Module):
         g = torch.is_grad_enabled() and conv_feature.requires_grad
         if _FE_FUSED and K.fe_chain_supported(conv_feature):
             # one autograd node for the whole block: the row-local layers run as fused chains (csrc/fe_chain.hip)
-            mh, ln1, ln3, pff = self.multihead, self.mul_layernorm1, self.mul_layernorm3, self.pff
-            assert ln1.eps == ln3.eps and mh.h == 4
-            if mh._packed_qkv is not None and mh._packed_qkv[0].data_ptr() == mh.linears[0].weight.data_ptr():
-                wqkv, bqkv = mh._packed_qkv       # views of the engine's flat buffers
-            else:
-                wqkv = torch.cat([mh.linears[0].weight, mh.linears[1].weight, mh.linears[2].weight], 0)
-                bqkv = torch.cat([mh.linears[0].bias, mh.linears[1].bias, mh.linears[2].bias], 0)
-            params = (wqkv, bqkv, mh.linears[3].weight, mh.linears[3].bias, ln1.a_2, ln1.b_2, pff.w_1.weight,
-                      pff.w_1.bias, pff.w_2.weight, pff.w_2.bias, ln3.a_2, ln3.b_2, self.linear.weight, self.linear.bias)
+            p_attn, p_ffn = self._fused_dropout()
             return K.feature_enhancer_fused(
-                conv_feature, residual, self._pe_table(conv_feature.device), params, heads=mh.h,
-                p_attn=mh.dropout.p if mh.dropout.training else 0.0,
-                p_ffn=pff.dropout.p if pff.dropout.training else 0.0, eps=ln1.eps,
+                conv_feature, residual, self._pe_table(conv_feature.device), self._fused_params(), heads=self.multihead.h,
+                p_attn=p_attn, p_ffn=p_ffn, eps=self.mul_layernorm1.eps,
                 defer_residual=g and residual is not None and defer_block_input)
         tok = K.concat_pe(conv_feature, self._pe_table(conv_feature.device))
         att, _ = self.multihead(tok, tok, tok, mask=None, take_deferred=g)
@@ -180,6 +189,12 @@ class RecurrentResidualBlock(nn.Module):
 
     def forward(self, x):
         g = torch.is_grad_enabled() and x.requires_grad
+        if _SRB_FUSED and _FE_FUSED and K.srb_fused_supported(x, self.conv1, self.conv2, self.bn1, self.bn2):
+            # training mode: the whole block is one autograd node (kernels._SRBFused), same library calls
+            fe = self.feature_enhancer
+            p_attn, p_ffn = fe._fused_dropout()
+            return K.srb_fused(x, fe._pe_table(x.device), self.conv1, self.bn1, self.conv2, self.bn2, fe._fused_params(),
+                               heads=fe.multihead.h, p_attn=p_attn, p_ffn=p_ffn, eps_ln=fe.mul_layernorm1.eps)
         r = K.conv_bn(x, self.conv1, self.bn1, act=K.ACT_MISH, take_deferred=g)
         r = K.conv_bn(r, self.conv2, self.bn2)
         n, h, w, c = r.shape
