@@ -34,7 +34,10 @@ typedef __attribute__((ext_vector_type(4))) __bf16 hbf16x4;
 #define H3_PLANE_BYTES (H3_HR * H3_HP * 128)       // one bf16 plane of the halo: 26112 B
 #define H3_KSC 2                                   // MFMA k-steps (16 channels) per weight chunk
 #define H3_NCHUNK 18                               // 9 taps x 4 k-steps / 2
-#define H3_NBUF 3                                  // weight chunk buffers: chunk c + 2 is in flight while c is contracted
+#ifndef H3_DIST
+#define H3_DIST 2                                  // weight chunks in flight ahead of the one being contracted
+#endif
+#define H3_NBUF (H3_DIST + 1)                      // weight chunk buffers: chunk c + H3_DIST is in flight while c is contracted
 
 // byte offset (inside one halo plane) of the 16-byte chunk c (channels 8c..8c+7) of halo pixel (r, p):
 // a pixel is 128 B; the chunk index is XORed with bits 1..3 of p so that the 16 lanes of a ds_read_b128 group
@@ -296,8 +299,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   constexpr int RS = 3 * PLANES;                    // LDS reads per k-step
 
   constexpr int NW = NP / 4;                        // DMA instructions per wave and chunk
-  issue_chunk(cg0, 0, 0, 0);
-  issue_chunk(cg0, 0, 1, 1);
+#pragma unroll
+  for (int c = 0; c < H3_DIST; ++c) issue_chunk(cg0, 0, c, c);
   for (int gi = 0; gi < g.cg_loop; ++gi) {
     const int cg = cg0 + gi;
     f32x16 acc[2];
@@ -332,13 +335,13 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       // vmcnt: the pieces of C+2 stay in flight), barrier | read fa<-step0 of chunk C+1 | MFMA fb
 #define H3_CHUNK(C)                                                                              \
   {                                                                                              \
-    if ((C) + 2 < H3_NCHUNK) issue_chunk(cg, s, (C) + 2, ((C) + 2) % H3_NBUF);                   \
-    else if (more) issue_chunk(ncg, nsl, (C) + 2 - H3_NCHUNK, ((C) + 2) % H3_NBUF);              \
+    if ((C) + H3_DIST < H3_NCHUNK) issue_chunk(cg, s, (C) + H3_DIST, ((C) + H3_DIST) % H3_NBUF); \
+    else if (more) issue_chunk(ncg, nsl, (C) + H3_DIST - H3_NCHUNK, ((C) + H3_DIST) % H3_NBUF);  \
     h3_read_step<PLANES, (C), 1>(fb, aoff, boff);                                                \
     h3_wait<PLANES, RS>(fa);                                                                     \
     h3_mfma_step<PLANES>(acc, fa);                                                               \
     h3_wait<PLANES, 0>(fb);                                                                      \
-    if ((C) + 2 < H3_NCHUNK || more) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NW) : "memory");   \
+    if ((C) + H3_DIST < H3_NCHUNK || more) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((H3_DIST - 1) * NW) : "memory"); \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
     __builtin_amdgcn_s_barrier();                                                                \
     if ((C) + 1 < H3_NCHUNK) h3_read_step<PLANES, ((C) + 1) % H3_NCHUNK, 0>(fa, aoff, boff);     \

@@ -1142,7 +1142,9 @@ class _SRBFused(torch.autograd.Function):
         14 FeatureEnhancer tensors (FE_PARAM_NAMES)"""
         ctx.step = step = current_context()
         cparams, fparams = params[:_SRBFused.N_CONV], params[_SRBFused.N_CONV:]
-        _chk(x, pe, *params)
+        _chk(x, pe, *[_ohwi(p_) if p_.dim() == 4 else p_ for p_ in params])
+        if any(_ohwi(p_).data_ptr() != p_.data_ptr() for p_ in (cparams[0], cparams[4])):
+            raise RuntimeError("the block's convolution weights must be channels_last tensors")
         n, h, w, c = x.shape
         rows = n * h * w
         dev = x.device
