@@ -54,7 +54,7 @@ SIGNATURES = {
     "focr_fe_qkv_fwd": [P, P, P, P, P, P, L, I, P],
     "focr_fe_qkv_dgrad": [P, P, P, P, L, P],
     "focr_fe_wgrads_ws_floats": [L],
-    "focr_fe_wgrads": [P] * 31 + [L, L, P],
+    "focr_fe_wgrads": [P] * 31 + [L, L, I, P],
     "focr_mse_fwd": [P, P, P, L, P],
     "focr_mse_bwd": [P, P, P, P, L, P],
     "focr_axpy": [P, P, P, L, F, P],

@@ -818,11 +818,16 @@ extern "C" int focr_fe_wgrads(const float* d_out, const float* xhat2, const floa
                               const float* b1, const float* a3, const float* b3, float* g_wl, float* g_bl, float* g_a3,
                               float* g_b3, float* g_w2, float* g_bb2, float* g_w1, float* g_bb1, float* g_a1,
                               float* g_b1, float* g_wo, float* g_bo, float* g_wqkv, float* g_bqkv, float* ws,
-                              long ws_floats, long rows, hipStream_t stream) {
-  FOCR_CHECK_ARG(d_out && xhat2 && d_s2 && h && d_hpre && xhat1 && d_s1 && ctx && dqkv && tok && wl && w1 && a1 && b1 &&
-                     a3 && b3 && g_wl && g_bl && g_a3 && g_b3 && g_w2 && g_bb2 && g_w1 && g_bb1 && g_a1 && g_b1 && g_wo &&
-                     g_bo && g_wqkv && g_bqkv && ws,
-                 "null pointer");
+                              long ws_floats, long rows, int parts, hipStream_t stream) {
+  // parts: bit 0 = the four linears that only need the backward chains' outputs (O-proj, w_2, LN1 -> w_1, LN3 -> linear);
+  // bit 1 = the packed q | k | v projection, which needs the attention backward's dqkv.  The caller issues part 1 BEFORE
+  // the attention backward (VALU-bound, light on HBM: a good partner for these streaming kernels) and part 2 after it.
+  FOCR_CHECK_ARG(parts >= 1 && parts <= 3 && ws, "parts must be 1, 2 or 3");
+  FOCR_CHECK_ARG(!(parts & 1) || (d_out && xhat2 && d_s2 && h && d_hpre && xhat1 && d_s1 && ctx && wl && w1 && a1 && b1 &&
+                                  a3 && b3 && g_wl && g_bl && g_a3 && g_b3 && g_w2 && g_bb2 && g_w1 && g_bb1 && g_a1 &&
+                                  g_b1 && g_wo && g_bo),
+                 "null pointer (part 1)");
+  FOCR_CHECK_ARG(!(parts & 2) || (dqkv && tok && g_wqkv && g_bqkv), "null pointer (part 2)");
   FOCR_CHECK_ARG(focr_fe_chain_supported(rows, FC_D), "rows must be a positive multiple of 32 (precision mode != 0)");
   FOCR_CHECK_ARG(ws_floats >= focr_fe_wgrads_ws_floats(rows), "workspace too small");
   const long tail = (FC_D * FC_D + FC_D) + (long)FC_CS_BLOCKS * 256 + 256 + 64;
@@ -833,7 +838,12 @@ extern "C" int focr_fe_wgrads(const float* d_out, const float* xhat2, const floa
   const int M = (int)rows;
   int rc;
   // packed q/k/v projection: X = tok, dY = dqkv
-  if ((rc = focr_conv2d_wgrad(tok, dqkv, g_wqkv, g_bqkv, M, 1, 1, FC_D, 384, 1, 1, 0, 0, 0, 0, 0, ws, wsg, stream))) return rc;
+  if (parts & 2)
+    if ((rc = focr_conv2d_wgrad(tok, dqkv, g_wqkv, g_bqkv, M, 1, 1, FC_D, 384, 1, 1, 0, 0, 0, 0, 0, ws, wsg, stream))) return rc;
+  if (!(parts & 1)) {
+    FOCR_LAUNCH_CHECK();
+    return FOCR_OK;
+  }
   // O-proj: X = ctx, dY = d_s1 (the gradient of LN1's input sum)
   if ((rc = focr_conv2d_wgrad(ctx, d_s1, g_wo, g_bo, M, 1, 1, FC_D, FC_D, 1, 1, 0, 0, 0, 0, 0, ws, wsg, stream))) return rc;
   // w_2: X = h, dY = d_s2

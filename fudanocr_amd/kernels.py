@@ -981,6 +981,8 @@ def fe_chain_supported(feat):
                 and _lib.load().focr_fe_chain_supported(feat.shape[0] * feat.shape[1], 128))
 
 
+# FOCR_FE_WGRAD_EARLY=0: all weight gradients of a FeatureEnhancer after its attention backward (A/B measurements)
+_FE_WGRAD_EARLY = os.environ.get("FOCR_FE_WGRAD_EARLY", "1") != "0"
 FE_PARAM_NAMES = ("wqkv", "bqkv", "wo", "bo", "a1", "b1", "w1", "bb1", "w2", "bb2", "a3", "b3", "wl", "bl")
 
 
@@ -1019,7 +1021,12 @@ def _fe_forward(step, feat, xres, pe, heads, p_attn, p_ffn, eps, params):
 def _fe_backward(step, saved, cfg, params, targets, d_out, need_dfeat, need_params, clone_for_side=None):
     """backward of the block: -> (d_feat or None, parameter gradients (None where a flat-buffer target took them)).
     d_out [B, T, 64] is ALSO the gradient of the block's residual input; the caller routes it.  clone_for_side: callable
-    invoked when the weight gradients go to the side stream (the caller may have to protect d_out from in-place reuse)."""
+    invoked when the weight gradients go to the side stream (the caller may have to protect d_out from in-place reuse).
+
+    Weight gradients in two side-stream calls: the four linears whose operands the chain kernels produce are issued
+    BEFORE the attention backward -- those streaming kernels (0.5 GB of operands) then share the chip with the VALU-bound
+    attention kernels instead of with the HBM-bound BatchNorm / convolution data-gradient kernels that follow; only the
+    packed q | k | v projection has to wait for dqkv."""
     tok, qkv, o, lse, mask, xhat1, rinv1, h, xhat2, rinv2 = saved
     wqkv, bqkv, wo, bo, a1, b1, w1, bb1, w2, bb2, a3, b3, wl, bl = params
     b, t, heads, scale, p_attn, eps, keep_scale = cfg
@@ -1030,6 +1037,37 @@ def _fe_backward(step, saved, cfg, params, targets, d_out, need_dfeat, need_para
     _lib.call("focr_fe_post_bwd", _p(d_out), _p(wl), _p(xhat2), _p(rinv2), _p(a3), _p(w2), _p(h), keep_scale,
               _p(w1), _p(xhat1), _p(rinv1), _p(a1), _p(wo), _p(d_s2), _p(d_hpre), _p(d_s1), _p(d_ctx), rows, eps,
               _p(o), _p(work), t, _stream())
+    grads = [None] * len(FE_PARAM_NAMES)
+    side, g, nws = None, None, 0
+    if need_params:
+        tg = list(targets)
+        flat = all(x is not None for x in tg)
+        if not flat:
+            tg = [torch.empty_like(p_, memory_format=torch.contiguous_format) for p_ in params]
+            grads = list(tg)
+        side = step.side_stream() if flat else None
+        nws = _lib.load().focr_fe_wgrads_ws_floats(rows)
+        g = dict(zip(FE_PARAM_NAMES, tg))
+        if side is not None and clone_for_side is not None:
+            clone_for_side()
+
+    def wgrads(parts, used):
+        if side is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            side.wait_event(ev)
+            for x in used:
+                x.record_stream(side)
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            ws = torch.empty(nws, device=dev)
+            _lib.call("focr_fe_wgrads", _p(d_out), _p(xhat2), _p(d_s2), _p(h), _p(d_hpre), _p(xhat1), _p(d_s1),
+                      _p(o), _p(dqkv), _p(tok), _p(wl), _p(w1), _p(a1), _p(b1), _p(a3), _p(b3), _p(g["wl"]),
+                      _p(g["bl"]), _p(g["a3"]), _p(g["b3"]), _p(g["w2"]), _p(g["bb2"]), _p(g["w1"]), _p(g["bb1"]),
+                      _p(g["a1"]), _p(g["b1"]), _p(g["wo"]), _p(g["bo"]), _p(g["wqkv"]), _p(g["bqkv"]), _p(ws),
+                      nws, rows, parts, _stream())
+    dqkv = None
+    if need_params and _FE_WGRAD_EARLY:
+        wgrads(1, (d_out, xhat2, d_s2, h, d_hpre, xhat1, d_s1, o))
     dqkv = torch.empty_like(qkv)
     # o = NULL: `work` already holds D = rowsum(d_ctx * o) per (b, head, token), written by the chain kernel above
     _lib.call("focr_attention_bwd", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _NULL, _p(d_ctx), _p(lse), _p(mask),
@@ -1039,32 +1077,11 @@ def _fe_backward(step, saved, cfg, params, targets, d_out, need_dfeat, need_para
     if need_dfeat:
         d_feat = torch.empty((b, t, 64), device=dev)
         _lib.call("focr_fe_qkv_dgrad", _p(dqkv), _p(wqkv), _p(d_s1), _p(d_feat), rows, _stream())
-    # parameter gradients: one library call, on the side stream when every target is a flat-buffer slice
-    grads = [None] * len(FE_PARAM_NAMES)
     if need_params:
-        tg = list(targets)
-        flat = all(x is not None for x in tg)
-        if not flat:
-            tg = [torch.empty_like(p_, memory_format=torch.contiguous_format) for p_ in params]
-            grads = list(tg)
-        side = step.side_stream() if flat else None
-        nws = _lib.load().focr_fe_wgrads_ws_floats(rows)
-        if side is not None:
-            if clone_for_side is not None:
-                clone_for_side()
-            ev = torch.cuda.Event()
-            ev.record()
-            side.wait_event(ev)
-            for x in (d_out, xhat2, d_s2, h, d_hpre, xhat1, d_s1, o, dqkv, tok):
-                x.record_stream(side)
-        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-            ws = torch.empty(nws, device=dev)
-            g = dict(zip(FE_PARAM_NAMES, tg))
-            _lib.call("focr_fe_wgrads", _p(d_out), _p(xhat2), _p(d_s2), _p(h), _p(d_hpre), _p(xhat1), _p(d_s1),
-                      _p(o), _p(dqkv), _p(tok), _p(wl), _p(w1), _p(a1), _p(b1), _p(a3), _p(b3), _p(g["wl"]),
-                      _p(g["bl"]), _p(g["a3"]), _p(g["b3"]), _p(g["w2"]), _p(g["bb2"]), _p(g["w1"]), _p(g["bb1"]),
-                      _p(g["a1"]), _p(g["b1"]), _p(g["wo"]), _p(g["bo"]), _p(g["wqkv"]), _p(g["bqkv"]), _p(ws),
-                      nws, rows, _stream())
+        if _FE_WGRAD_EARLY:
+            wgrads(2, (dqkv, tok))
+        else:
+            wgrads(3, (d_out, xhat2, d_s2, h, d_hpre, xhat1, d_s1, o, dqkv, tok))
     return d_feat, grads
 
 

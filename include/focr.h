@@ -227,7 +227,9 @@ int focr_slice_cols(const float* x, const float* add, float* out, long rows, int
  *                      the token, tbsrn.py:83-86, has no gradient consumer).
  *   focr_fe_wgrads   : every parameter gradient of these layers in one call (targets are overwritten); the LayerNorm
  *                      a_2 / b_2 gradients and the weight gradients of the linears fed by a LayerNorm come out of one
- *                      weight-gradient GEMM on xhat.  ws: focr_fe_wgrads_ws_floats(rows) floats. */
+ *                      weight-gradient GEMM on xhat.  ws: focr_fe_wgrads_ws_floats(rows) floats.  parts: bit 0 = the
+ *                      four linears fed by the backward chains (may run before the attention backward), bit 1 = the
+ *                      packed q | k | v projection (needs dqkv); operands of an unselected part may be NULL. */
 int focr_fe_chain_supported(long rows, int d_model);
 int focr_fe_post_fwd(const float* ctx, const float* tok, const float* xin, const float* wo, const float* bo,
                      const float* a1, const float* b1, const float* w1, const float* bb1, const float* w2,
@@ -249,7 +251,7 @@ int focr_fe_wgrads(const float* d_out, const float* xhat2, const float* d_s2, co
                    const float* wl, const float* w1, const float* a1, const float* b1, const float* a3,
                    const float* b3, float* g_wl, float* g_bl, float* g_a3, float* g_b3, float* g_w2, float* g_bb2,
                    float* g_w1, float* g_bb1, float* g_a1, float* g_b1, float* g_wo, float* g_bo, float* g_wqkv,
-                   float* g_bqkv, float* ws, long ws_floats, long rows, focr_stream_t stream);
+                   float* g_bqkv, float* ws, long ws_floats, long rows, int parts, focr_stream_t stream);
 /* nn.Dropout tbsrn.py:160,163 : y = keep ? x/(1-p) : 0 ; the same call is its backward */
 int focr_dropout(const float* x, float* y, long n, float p, uint64_t seed, focr_stream_t stream);
 /* nn.MSELoss loss/text_focus_loss.py:44,86 ; upstream = device scalar */
