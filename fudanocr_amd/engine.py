@@ -351,6 +351,7 @@ class TrainStep:
                 c.side_enabled = True
                 c.side_stream().wait_stream(torch.cuda.current_stream())
             (loss * 100).backward()
+            c.flush_side()             # weight gradients the last block parked (kernels.StepContext.defer_side)
         finally:
             c.side_enabled = False
             c.flips = None

@@ -101,6 +101,7 @@ class StepContext:
         self.mask_prefetch = False       # engine-owned contexts draw the attention keep bits ahead of time
         self._masks = []                 # per attention call of a step: {"key", "mask", "event"}
         self._mask_cursor = 0
+        self._pending_side = []          # weight-gradient launches parked for a better moment (defer_side)
 
     # -- attention dropout keep bits.  They depend on (shape, p, seed) only, so the engine draws the bits of ALL
     # attention layers at the start of the step on the side stream (idle during the forward pass) instead of in front
@@ -167,8 +168,24 @@ class StepContext:
         self.side_used = True
         return self.side_stream_obj
 
+    # -- parked side-stream work.  Weight-gradient kernels stream their operands once (HBM-bound); issued right away they
+    # run beside the equally HBM-bound BatchNorm / convolution data-gradient kernels of the main stream and both slow
+    # down.  A residual block therefore parks the weight gradients of its convolutions and of its QKV projection, and
+    # the NEXT block (in backward order) issues them when its attention backward starts: ~0.7 ms of VALU-bound kernels
+    # that barely touch HBM.  Every joiner of the side stream flushes first, so nothing can be left behind.
+    def defer_side(self, fn):
+        if self.side_enabled and _DEFER_SIDE:
+            self._pending_side.append(fn)
+        else:
+            fn()
+
+    def flush_side(self):
+        while self._pending_side:
+            self._pending_side.pop(0)()
+
     def join_side_stream(self, stream=None):
         """make `stream` (default: current) wait for everything queued on the weight-gradient side stream"""
+        self.flush_side()
         if self.side_used and self.side_stream_obj is not None:
             (stream or torch.cuda.current_stream()).wait_stream(self.side_stream_obj)
 
@@ -981,6 +998,8 @@ def fe_chain_supported(feat):
                 and _lib.load().focr_fe_chain_supported(feat.shape[0] * feat.shape[1], 128))
 
 
+# FOCR_DEFER_SIDE=0: weight gradients are issued where they are produced instead of beside the next attention backward
+_DEFER_SIDE = os.environ.get("FOCR_DEFER_SIDE", "1") != "0"
 # FOCR_FE_WGRAD_EARLY=0: all weight gradients of a FeatureEnhancer after its attention backward (A/B measurements)
 _FE_WGRAD_EARLY = os.environ.get("FOCR_FE_WGRAD_EARLY", "1") != "0"
 FE_PARAM_NAMES = ("wqkv", "bqkv", "wo", "bo", "a1", "b1", "w1", "bb1", "w2", "bb2", "a3", "b3", "wl", "bl")
@@ -1066,6 +1085,7 @@ def _fe_backward(step, saved, cfg, params, targets, d_out, need_dfeat, need_para
                       _p(g["a1"]), _p(g["b1"]), _p(g["wo"]), _p(g["bo"]), _p(g["wqkv"]), _p(g["bqkv"]), _p(ws),
                       nws, rows, parts, _stream())
     dqkv = None
+    step.flush_side()          # the previous block's parked weight gradients: beside THIS block's attention backward
     if need_params and _FE_WGRAD_EARLY:
         wgrads(1, (d_out, xhat2, d_s2, h, d_hpre, xhat1, d_s1, o))
     dqkv = torch.empty_like(qkv)
@@ -1079,9 +1099,9 @@ def _fe_backward(step, saved, cfg, params, targets, d_out, need_dfeat, need_para
         _lib.call("focr_fe_qkv_dgrad", _p(dqkv), _p(wqkv), _p(d_s1), _p(d_feat), rows, _stream())
     if need_params:
         if _FE_WGRAD_EARLY:
-            wgrads(2, (dqkv, tok))
+            step.defer_side(lambda: wgrads(2, (dqkv, tok)))
         else:
-            wgrads(3, (d_out, xhat2, d_s2, h, d_hpre, xhat1, d_s1, o, dqkv, tok))
+            step.defer_side(lambda: wgrads(3, (d_out, xhat2, d_s2, h, d_hpre, xhat1, d_s1, o, dqkv, tok)))
     return d_feat, grads
 
 
@@ -1232,19 +1252,24 @@ class _SRBFused(torch.autograd.Function):
                 flat = tw is not None and tb is not None
                 dw = tw if flat else torch.empty((64, 3, 3, 64), device=dev).permute(0, 3, 1, 2)
                 dbias = tb if flat else torch.empty(64, device=dev)
-                side = step.side_stream() if flat else None
-                if side is not None:
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    side.wait_event(ev)
-                    cin.record_stream(side)
-                    dyc.record_stream(side)
-                with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-                    nws = lib.focr_conv2d_wgrad_ws_floats(n, h, w, 64, 64, 3, 3, 1, 1)
-                    wsw = torch.empty(nws, device=dev) if nws > 0 else None
-                    _lib.call("focr_conv2d_wgrad", _p(cin), _p(dyc), _p(dw), _p(dbias), n, h, w, 64, 64, 3, 3, 1, 1, 0,
-                              0, int(flat), _p(wsw), nws, _stream())
-                if not flat:
+
+                def conv_wgrad(cin=cin, dyc=dyc, dw=dw, dbias=dbias, flat=flat):
+                    side = step.side_stream() if flat else None
+                    if side is not None:
+                        ev = torch.cuda.Event()
+                        ev.record()
+                        side.wait_event(ev)
+                        cin.record_stream(side)
+                        dyc.record_stream(side)
+                    with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                        nws = lib.focr_conv2d_wgrad_ws_floats(n, h, w, 64, 64, 3, 3, 1, 1)
+                        wsw = torch.empty(nws, device=dev) if nws > 0 else None
+                        _lib.call("focr_conv2d_wgrad", _p(cin), _p(dyc), _p(dw), _p(dbias), n, h, w, 64, 64, 3, 3, 1, 1,
+                                  0, 0, int(flat), _p(wsw), nws, _stream())
+                if flat:
+                    step.defer_side(conv_wgrad)      # issued beside the next block's attention backward
+                else:
+                    conv_wgrad()
                     grads[4 * i], grads[4 * i + 1] = dw, dbias
             # data gradient on the halo kernel (flipped fragment weights); the block input's residual gradient (= d_out)
             # is added in the epilogue of the FIRST convolution's data gradient
