@@ -168,11 +168,10 @@ class StepContext:
         self.side_used = True
         return self.side_stream_obj
 
-    # -- parked side-stream work.  Weight-gradient kernels stream their operands once (HBM-bound); issued right away they
-    # run beside the equally HBM-bound BatchNorm / convolution data-gradient kernels of the main stream and both slow
-    # down.  A residual block therefore parks the weight gradients of its convolutions and of its QKV projection, and
-    # the NEXT block (in backward order) issues them when its attention backward starts: ~0.7 ms of VALU-bound kernels
-    # that barely touch HBM.  Every joiner of the side stream flushes first, so nothing can be left behind.
+    # -- parked side-stream work (experiment switch FOCR_DEFER_SIDE, off by default -- see _DEFER_SIDE): a residual block
+    # may park the weight gradients of its convolutions and of its QKV projection, and the NEXT block (in backward order)
+    # issues them when its attention backward starts.  Every joiner of the side stream flushes first, so nothing can be
+    # left behind.
     def defer_side(self, fn):
         if self.side_enabled and _DEFER_SIDE:
             self._pending_side.append(fn)
@@ -998,8 +997,10 @@ def fe_chain_supported(feat):
                 and _lib.load().focr_fe_chain_supported(feat.shape[0] * feat.shape[1], 128))
 
 
-# FOCR_DEFER_SIDE=0: weight gradients are issued where they are produced instead of beside the next attention backward
-_DEFER_SIDE = os.environ.get("FOCR_DEFER_SIDE", "1") != "0"
+# FOCR_DEFER_SIDE=1: park the convolution / QKV weight gradients of a residual block and issue them beside the NEXT
+# block's attention backward.  Measured (same box, interleaved): 15.32 ms vs 15.13 ms without -- the attention kernels lose
+# more to the extra company than the HBM-bound kernels gain; off by default, kept as an A/B switch.
+_DEFER_SIDE = os.environ.get("FOCR_DEFER_SIDE", "0") == "1"
 # FOCR_FE_WGRAD_EARLY=0: all weight gradients of a FeatureEnhancer after its attention backward (A/B measurements)
 _FE_WGRAD_EARLY = os.environ.get("FOCR_FE_WGRAD_EARLY", "1") != "0"
 FE_PARAM_NAMES = ("wqkv", "bqkv", "wo", "bo", "a1", "b1", "w1", "bb1", "w2", "bb2", "a3", "b3", "wl", "bl")
