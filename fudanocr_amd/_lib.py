@@ -50,8 +50,13 @@ SIGNATURES = {
     "focr_dropout": [P, P, L, F, U, P],
     "focr_fe_chain_supported": [L, I],
     "focr_fe_post_fwd": [P] * 21 + [L, F, F, U, P, P],
-    "focr_fe_post_bwd": [P] * 7 + [F] + [P] * 9 + [L, F, P, P, I, P],
-    "focr_fe_qkv_fwd": [P, P, P, P, P, P, L, I, P],
+    "focr_fe_post_bwd": [P] * 7 + [F] + [P] * 9 + [L, F, P, P, I, P, F, P],
+    "focr_fe_qkv_fwd": [P, P, P, P, P, P, L, I, P, F, P],
+    "focr_attention_planes_supported": [I, I, I],
+    "focr_attention_keep_scale": [F],
+    "focr_attention_make_planes": [P, P, L, I, F, P],
+    "focr_attention_planes_fwd": [P, P, P, P, P, P, I, I, I, I, F, U, I, P],
+    "focr_attention_planes_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, P],
     "focr_fe_qkv_dgrad": [P, P, P, P, L, P],
     "focr_fe_wgrads_ws_floats": [L],
     "focr_fe_wgrads": [P] * 31 + [L, L, I, P],
@@ -139,6 +144,7 @@ def load():
     lib.focr_weight_frag_bytes.restype = ctypes.c_long
     lib.focr_psnr_ssim_ws_floats.restype = ctypes.c_long
     lib.focr_fe_wgrads_ws_floats.restype = ctypes.c_long
+    lib.focr_attention_keep_scale.restype = ctypes.c_float
     _lib = lib
     if os.environ.get("FOCR_PRECISION"):          # 0 fp32 | 1 bf16x3 | 2 (default) + bf16 attention-gradient sums | 3 + bf16 dgrad
         rc = lib.focr_set_precision(int(os.environ["FOCR_PRECISION"]))

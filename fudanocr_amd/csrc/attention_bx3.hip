@@ -93,6 +93,30 @@ __device__ __forceinline__ void row_frag(const float* p, float sc, bf16x8& hi, b
   }
 }
 
+// ---- pre-split operand planes ("PL" kernel variants) -----------------------------------------------------------
+// The producers of Q / K / V (the packed projection, csrc/fe_chain.hip fe_qkv_fwd_kernel) and of dO (fe_bwd_b_kernel)
+// can write their results ALREADY split: bf16 hi plane [rows][128] followed by the lo plane `pls` elements later, Q
+// pre-multiplied by scale * log2(e), dO by 1 / P(keep).  The PL variants of the three big kernels then stage tiles by
+// copying 8-byte words (global -> LDS, transposition = one v_perm per word pair) and take their register fragments
+// straight from memory: the per-block fp32 -> bf16 hi/lo split of every K / V / Q / dO tile (a quarter of the dK/dV
+// pass's VALU work) is done once by the producer instead of by every consumer block.  Same values as the fp32 path
+// (the split is the same arithmetic), except that the dropout scale rides on dO instead of V in the dK/dV pass.
+__device__ __forceinline__ bf16x8 pl_frag(const __bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+// two rows (2 rp, 2 rp + 1) x 4 columns (c0 ..) of one plane, held as two 8-byte words
+__device__ __forceinline__ void pl_put_rows(__bf16* T, int rp, int c0, uint2 r0, uint2 r1) {
+  *reinterpret_cast<uint2*>(&T[(2 * rp) * RP + c0]) = r0;
+  *reinterpret_cast<uint2*>(&T[(2 * rp + 1) * RP + c0]) = r1;
+}
+// transposed: T[c0 + e][2 rp .. 2 rp + 1] = (r0[e], r1[e])
+__device__ __forceinline__ void pl_put_cols(__bf16* T, int rp, int c0, uint2 r0, uint2 r1) {
+  uint32_t* t = reinterpret_cast<uint32_t*>(T);
+  t[((c0 + 0) * TP + 2 * rp) >> 1] = __builtin_amdgcn_perm(r1.x, r0.x, 0x05040100u);
+  t[((c0 + 1) * TP + 2 * rp) >> 1] = __builtin_amdgcn_perm(r1.x, r0.x, 0x07060302u);
+  t[((c0 + 2) * TP + 2 * rp) >> 1] = __builtin_amdgcn_perm(r1.y, r0.y, 0x05040100u);
+  t[((c0 + 3) * TP + 2 * rp) >> 1] = __builtin_amdgcn_perm(r1.y, r0.y, 0x07060302u);
+}
+__device__ __forceinline__ uint2 pl_ld(const __bf16* p) { return *reinterpret_cast<const uint2*>(p); }
+
 // =======================================================================================
 // forward
 // =======================================================================================
@@ -216,12 +240,16 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_bx3_kernel(const float* __res
 //   read from LDS feeds two MFMA triples instead of one, and the per-block K/V staging is shared by 256 queries.
 // =======================================================================================
 __device__ __forceinline__ void hi_regs(const f32x16& s, int m, bf16x8& hi);
-template <bool DROPOUT>
+// PL: Q / K / V point to bf16 hi planes (row pitch ld = 128 elements, lo plane `pls` elements behind), Q pre-scaled
+template <bool DROPOUT, bool PL>
 __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                             const float* __restrict__ V, float* __restrict__ O,
                                                             float* __restrict__ LSE, const uint32_t* __restrict__ MASK,
                                                             int Ntok, int ld, int ldo, float scale, float p_drop,
-                                                            uint64_t seed, int nheads) {
+                                                            uint64_t seed, int nheads, long pls) {
+  const __bf16* const Qp = reinterpret_cast<const __bf16*>(Q);
+  const __bf16* const Kp = reinterpret_cast<const __bf16*>(K);
+  const __bf16* const Vp = reinterpret_cast<const __bf16*>(V);
   __shared__ __attribute__((aligned(16))) __bf16 Kh[64 * RP], Kl[64 * RP];
   __shared__ __attribute__((aligned(16))) __bf16 Vth[32 * TP], Vtl[32 * TP];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
@@ -236,8 +264,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __re
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-      row_frag(Q + base + (size_t)(q0 + 32 * t) * ld + 16 * m + 8 * lh, scale * LOG2E, qh[t][m], ql[t][m]);
+    for (int m = 0; m < 2; ++m) {
+      if (PL) {
+        const size_t o_ = base + (size_t)(q0 + 32 * t) * ld + 16 * m + 8 * lh;
+        qh[t][m] = pl_frag(Qp + o_);
+        ql[t][m] = pl_frag(Qp + pls + o_);
+      } else {
+        row_frag(Q + base + (size_t)(q0 + 32 * t) * ld + 16 * m + 8 * lh, scale * LOG2E, qh[t][m], ql[t][m]);
+      }
+    }
   f32x16 oacc[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -252,19 +287,39 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __re
 
   const int rp = tid >> 3, c0 = (tid & 7) * 4;         // key pair, first of 4 d columns
   float4 k0, k1, v0, v1;
+  uint2 pk[8];                                         // PL: K hi (2 rows), K lo, V hi, V lo
+#define PL_LOAD_KV(kt)                                                                \
+  do {                                                                                \
+    const size_t o0_ = base + (size_t)((kt) * 64 + 2 * rp) * ld + c0;                 \
+    pk[0] = pl_ld(Kp + o0_); pk[1] = pl_ld(Kp + o0_ + ld);                            \
+    pk[2] = pl_ld(Kp + pls + o0_); pk[3] = pl_ld(Kp + pls + o0_ + ld);                \
+    pk[4] = pl_ld(Vp + o0_); pk[5] = pl_ld(Vp + o0_ + ld);                            \
+    pk[6] = pl_ld(Vp + pls + o0_); pk[7] = pl_ld(Vp + pls + o0_ + ld);                \
+  } while (0)
   const int ntiles = Ntok / 64;
-  LOAD_KV(0);
+  if (PL) PL_LOAD_KV(0);
+  else LOAD_KV(0);
   for (int kt = 0; kt < ntiles; ++kt) {
 #ifdef ATTN_ABL_STAGE
     if (kt == 0)
 #endif
     {
-      put_rows(Kh, Kl, rp, c0, k0, k1);
-      put_cols(Vth, Vtl, rp, c0, v0, v1);
+      if (PL) {
+        pl_put_rows(Kh, rp, c0, pk[0], pk[1]);
+        pl_put_rows(Kl, rp, c0, pk[2], pk[3]);
+        pl_put_cols(Vth, rp, c0, pk[4], pk[5]);
+        pl_put_cols(Vtl, rp, c0, pk[6], pk[7]);
+      } else {
+        put_rows(Kh, Kl, rp, c0, k0, k1);
+        put_cols(Vth, Vtl, rp, c0, v0, v1);
+      }
     }
     __syncthreads();
 #ifndef ATTN_ABL_STAGE
-    if (kt + 1 < ntiles) LOAD_KV(kt + 1);
+    if (kt + 1 < ntiles) {
+      if (PL) PL_LOAD_KV(kt + 1);
+      else LOAD_KV(kt + 1);
+    }
 #endif
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
@@ -602,12 +657,18 @@ __device__ __forceinline__ void put_cols_hi(__bf16* Th, int rp, int c0, float4 r
   }
 }
 
-template <bool DROPOUT, bool FAST>
+// PL: Q (pre-scaled) / K / V / dO (pre-multiplied by 1 / P(keep)) are bf16 hi planes (pitch ld = ldo = 128, lo plane `pls`
+// elements behind); dK / dV are written with row pitch ldg
+template <bool DROPOUT, bool FAST, bool PL>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ Dv,
     float* __restrict__ dK, float* __restrict__ dV, const uint32_t* __restrict__ MASK, int Ntok, int ld, int ldo,
-    float scale, float p_drop, int nheads) {
+    float scale, float p_drop, int nheads, long pls, int ldg) {
+  const __bf16* const Qp = reinterpret_cast<const __bf16*>(Q);
+  const __bf16* const Kp = reinterpret_cast<const __bf16*>(K);
+  const __bf16* const Vp = reinterpret_cast<const __bf16*>(V);
+  const __bf16* const Gp = reinterpret_cast<const __bf16*>(dO);
   __shared__ __attribute__((aligned(16))) __bf16 Qh[64 * RP], Ql[64 * RP], Gh[64 * RP], Gl[64 * RP];
   __shared__ __attribute__((aligned(16))) __bf16 Qth[32 * TP], Qtl[32 * TP], Gth[32 * TP], Gtl[32 * TP];
   __shared__ float Ls[64], Ds[64];
@@ -624,9 +685,15 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
   bf16x8 kh[2], kl[2], vh[2], vl[2];
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
-    row_frag(K + base + (size_t)key * ld + 16 * m + 8 * lh, 1.f, kh[m], kl[m]);
-    // V carries the dropout scale 1/(1-p): dP' = dO (V/(1-p))^T is all the dS formula below needs of it
-    row_frag(V + base + (size_t)key * ld + 16 * m + 8 * lh, inv_keep, vh[m], vl[m]);
+    if (PL) {        // the dropout scale rides on the dO planes
+      const size_t o_ = base + (size_t)key * ld + 16 * m + 8 * lh;
+      kh[m] = pl_frag(Kp + o_); kl[m] = pl_frag(Kp + pls + o_);
+      vh[m] = pl_frag(Vp + o_); vl[m] = pl_frag(Vp + pls + o_);
+    } else {
+      row_frag(K + base + (size_t)key * ld + 16 * m + 8 * lh, 1.f, kh[m], kl[m]);
+      // V carries the dropout scale 1/(1-p): dP' = dO (V/(1-p))^T is all the dS formula below needs of it
+      row_frag(V + base + (size_t)key * ld + 16 * m + 8 * lh, inv_keep, vh[m], vl[m]);
+    }
   }
   f32x16 dkacc, dvacc;
 #pragma unroll
@@ -655,23 +722,57 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
     }                                                                                 \
   } while (0)
   const int ntiles = Ntok / 64;
-  LOAD_QG(0);
+  uint2 pq[8];                                          // PL: Q hi (2 rows), Q lo, dO hi, dO lo
+#define PL_LOAD_QG(qt)                                                                \
+  do {                                                                                \
+    const size_t o0_ = base + (size_t)((qt) * 64 + 2 * rp) * ld + c0;                 \
+    pq[0] = pl_ld(Qp + o0_); pq[1] = pl_ld(Qp + o0_ + ld);                            \
+    pq[2] = pl_ld(Qp + pls + o0_); pq[3] = pl_ld(Qp + pls + o0_ + ld);                \
+    pq[4] = pl_ld(Gp + o0_); pq[5] = pl_ld(Gp + o0_ + ld);                            \
+    pq[6] = pl_ld(Gp + pls + o0_); pq[7] = pl_ld(Gp + pls + o0_ + ld);                \
+    if (tid < 64) {                                                                   \
+      lreg = LSE[sbase + (qt) * 64 + tid];                                            \
+      dreg = Dv[sbase + (qt) * 64 + tid];                                             \
+    }                                                                                 \
+    if (DROPOUT) {                                                                    \
+      mreg0 = mkey[(size_t)((qt) * 2) * NG * 32];                                     \
+      mreg1 = mkey[(size_t)((qt) * 2 + 1) * NG * 32];                                 \
+    }                                                                                 \
+  } while (0)
+  if (PL) PL_LOAD_QG(0);
+  else LOAD_QG(0);
   for (int qt = 0; qt < ntiles; ++qt) {
-    q0 = scale4(q0, scale * LOG2E);     // log2 units: p = exp2(s - lse*log2e); dK is rescaled by ln2 at the end
-    q1 = scale4(q1, scale * LOG2E);
     const uint32_t mcur0 = mreg0 >> (4 * lh), mcur1 = mreg1 >> (4 * lh);
-    put_rows(Qh, Ql, rp, c0, q0, q1);
-    put_rows(Gh, Gl, rp, c0, g0, g1);
-    if (FAST) {
-      put_cols_hi(Qth, rp, c0, q0, q1);
-      put_cols_hi(Gth, rp, c0, g0, g1);
+    if (PL) {
+      pl_put_rows(Qh, rp, c0, pq[0], pq[1]);
+      pl_put_rows(Ql, rp, c0, pq[2], pq[3]);
+      pl_put_rows(Gh, rp, c0, pq[4], pq[5]);
+      pl_put_rows(Gl, rp, c0, pq[6], pq[7]);
+      pl_put_cols(Qth, rp, c0, pq[0], pq[1]);
+      pl_put_cols(Gth, rp, c0, pq[4], pq[5]);
+      if (!FAST) {
+        pl_put_cols(Qtl, rp, c0, pq[2], pq[3]);
+        pl_put_cols(Gtl, rp, c0, pq[6], pq[7]);
+      }
     } else {
-      put_cols(Qth, Qtl, rp, c0, q0, q1);
-      put_cols(Gth, Gtl, rp, c0, g0, g1);
+      q0 = scale4(q0, scale * LOG2E);     // log2 units: p = exp2(s - lse*log2e); dK is rescaled by ln2 at the end
+      q1 = scale4(q1, scale * LOG2E);
+      put_rows(Qh, Ql, rp, c0, q0, q1);
+      put_rows(Gh, Gl, rp, c0, g0, g1);
+      if (FAST) {
+        put_cols_hi(Qth, rp, c0, q0, q1);
+        put_cols_hi(Gth, rp, c0, g0, g1);
+      } else {
+        put_cols(Qth, Qtl, rp, c0, q0, q1);
+        put_cols(Gth, Gtl, rp, c0, g0, g1);
+      }
     }
     if (tid < 64) { Ls[tid] = -lreg * LOG2E; Ds[tid] = dreg; }     // -LSE: the score accumulators START there
     __syncthreads();
-    if (qt + 1 < ntiles) LOAD_QG(qt + 1);
+    if (qt + 1 < ntiles) {
+      if (PL) PL_LOAD_QG(qt + 1);
+      else LOAD_QG(qt + 1);
+    }
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       // s starts at -LSE of its query row (register r <-> query key_of_b(r, lh)): the MFMAs deliver s - lse for free
@@ -727,15 +828,16 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
     }
     __syncthreads();
   }
-  float* dkrow = dK + base + (size_t)key * ld;
-  float* dvrow = dV + base + (size_t)key * ld;
+  const size_t gbase = (size_t)b * Ntok * ldg + h * 32;
+  float* dkrow = dK + gbase + (size_t)key * ldg;
+  float* dvrow = dV + gbase + (size_t)key * ldg;
+  const float vsc = PL ? 1.f : inv_keep;               // PL: dO already carries 1 / P(keep)
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     *reinterpret_cast<float4*>(dkrow + 8 * g + 4 * lh) =
         make_float4(dkacc[4 * g] * LN2, dkacc[4 * g + 1] * LN2, dkacc[4 * g + 2] * LN2, dkacc[4 * g + 3] * LN2);
     *reinterpret_cast<float4*>(dvrow + 8 * g + 4 * lh) =
-        make_float4(dvacc[4 * g] * inv_keep, dvacc[4 * g + 1] * inv_keep, dvacc[4 * g + 2] * inv_keep,
-                    dvacc[4 * g + 3] * inv_keep);
+        make_float4(dvacc[4 * g] * vsc, dvacc[4 * g + 1] * vsc, dvacc[4 * g + 2] * vsc, dvacc[4 * g + 3] * vsc);
   }
 }
 
@@ -844,12 +946,16 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_bx3_kernel(
 
 // dQ with two query tiles per wave (block = 256 queries): the K / V staging of a 64-key tile (global loads, hi/lo split,
 // transposed copy: ~75 VALU instructions per thread) and every K / V fragment read serve 256 queries instead of 128.
-template <bool DROPOUT, bool FAST>
+template <bool DROPOUT, bool FAST, bool PL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_bx3_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ Dv,
     float* __restrict__ dQ, const uint32_t* __restrict__ MASK, int Ntok, int ld, int ldo, float scale, float p_drop,
-    int nheads) {
+    int nheads, long pls, int ldg) {
+  const __bf16* const Qp = reinterpret_cast<const __bf16*>(Q);
+  const __bf16* const Kp = reinterpret_cast<const __bf16*>(K);
+  const __bf16* const Vp = reinterpret_cast<const __bf16*>(V);
+  const __bf16* const Gp = reinterpret_cast<const __bf16*>(dO);
   __shared__ __attribute__((aligned(16))) __bf16 Kh[64 * RP], Kl[64 * RP], Vh[64 * RP], Vl[64 * RP];
   __shared__ __attribute__((aligned(16))) __bf16 Kth[32 * TP], Ktl[32 * TP];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
@@ -870,9 +976,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_bx3_kernel(
     const int q = q0 + 32 * t;
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      row_frag(Q + base + (size_t)q * ld + 16 * m + 8 * lh, scale * LOG2E, qh[t][m], ql[t][m]);
-      // dO carries the dropout scale 1/(1-p) (dP' = V dO'^T); D was computed from the unscaled dO by the prep kernel
-      row_frag(dO + baseo + (size_t)q * ldo + 16 * m + 8 * lh, inv_keep, gh[t][m], gl[t][m]);
+      if (PL) {
+        const size_t o_ = base + (size_t)q * ld + 16 * m + 8 * lh;
+        qh[t][m] = pl_frag(Qp + o_); ql[t][m] = pl_frag(Qp + pls + o_);
+        gh[t][m] = pl_frag(Gp + o_); gl[t][m] = pl_frag(Gp + pls + o_);
+      } else {
+        row_frag(Q + base + (size_t)q * ld + 16 * m + 8 * lh, scale * LOG2E, qh[t][m], ql[t][m]);
+        // dO carries the dropout scale 1/(1-p) (dP' = V dO'^T); D was computed from the unscaled dO by the prep kernel
+        row_frag(dO + baseo + (size_t)q * ldo + 16 * m + 8 * lh, inv_keep, gh[t][m], gl[t][m]);
+      }
     }
     lse[t] = LSE[sbase + q] * LOG2E;
     dd[t] = Dv[sbase + q];
@@ -885,15 +997,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_bx3_kernel(
 
   const int rp = tid >> 3, c0 = (tid & 7) * 4;
   float4 k0, k1, v0, v1;
+  uint2 pk[8];                                         // PL: K hi (2 rows), K lo, V hi, V lo
   const int ntiles = Ntok / 64;
-  LOAD_KV(0);
+  if (PL) PL_LOAD_KV(0);
+  else LOAD_KV(0);
   for (int kt = 0; kt < ntiles; ++kt) {
-    put_rows(Kh, Kl, rp, c0, k0, k1);
-    if (FAST) put_cols_hi(Kth, rp, c0, k0, k1);
-    else put_cols(Kth, Ktl, rp, c0, k0, k1);
-    put_rows(Vh, Vl, rp, c0, v0, v1);
+    if (PL) {
+      pl_put_rows(Kh, rp, c0, pk[0], pk[1]);
+      pl_put_rows(Kl, rp, c0, pk[2], pk[3]);
+      pl_put_cols(Kth, rp, c0, pk[0], pk[1]);
+      if (!FAST) pl_put_cols(Ktl, rp, c0, pk[2], pk[3]);
+      pl_put_rows(Vh, rp, c0, pk[4], pk[5]);
+      pl_put_rows(Vl, rp, c0, pk[6], pk[7]);
+    } else {
+      put_rows(Kh, Kl, rp, c0, k0, k1);
+      if (FAST) put_cols_hi(Kth, rp, c0, k0, k1);
+      else put_cols(Kth, Ktl, rp, c0, k0, k1);
+      put_rows(Vh, Vl, rp, c0, v0, v1);
+    }
     __syncthreads();
-    if (kt + 1 < ntiles) LOAD_KV(kt + 1);
+    if (kt + 1 < ntiles) {
+      if (PL) PL_LOAD_KV(kt + 1);
+      else LOAD_KV(kt + 1);
+    }
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       uint64_t mk[2][16];
@@ -956,9 +1082,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_bx3_kernel(
     }
     __syncthreads();
   }
+  const size_t gbase = (size_t)b * Ntok * ldg + h * 32;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    float* row = dQ + base + (size_t)(q0 + 32 * t) * ld;
+    float* row = dQ + gbase + (size_t)(q0 + 32 * t) * ldg;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
       *reinterpret_cast<float4*>(row + 8 * g + 4 * lh) =
@@ -985,11 +1112,11 @@ int focr_attn_fwd_bx3(const float* q, const float* k, const float* v, float* o, 
   if (focr_get_tuning(FOCR_TUNE_ATTN_FWD_VARIANT) == 1 && Ntok % 256 == 0) {
     dim3 grid2(B * H * (Ntok / 256));
     if (p_drop > 0.f)
-      hipLaunchKernelGGL((attn_fwd2_bx3_kernel<true>), grid2, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ld, ldo,
-                         scale, p_drop, seed, H);
+      hipLaunchKernelGGL((attn_fwd2_bx3_kernel<true, false>), grid2, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ld, ldo,
+                         scale, p_drop, seed, H, 0L);
     else
-      hipLaunchKernelGGL((attn_fwd2_bx3_kernel<false>), grid2, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ld, ldo,
-                         scale, p_drop, seed, H);
+      hipLaunchKernelGGL((attn_fwd2_bx3_kernel<false, false>), grid2, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ld, ldo,
+                         scale, p_drop, seed, H, 0L);
     return 0;
   }
   dim3 grid(B * H * (Ntok / 128));
@@ -1009,11 +1136,11 @@ int focr_attn_bwd_bx3(const float* q, const float* k, const float* v, const floa
   const bool dq2 = focr_get_tuning(FOCR_TUNE_ATTN_BWD_DQ_VARIANT) == 1 && Ntok % 256 == 0;      // two query tiles per wave in the dQ pass
 #define LAUNCH_BWD(DR, FA)                                                                                        \
   do {                                                                                                            \
-    hipLaunchKernelGGL((attn_bwd_dkv_bx3_kernel<DR, FA>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dk, dv, \
-                       mask, Ntok, ld, ldo, scale, p_drop, H);                                                    \
+    hipLaunchKernelGGL((attn_bwd_dkv_bx3_kernel<DR, FA, false>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dk, dv, \
+                       mask, Ntok, ld, ldo, scale, p_drop, H, 0L, ld);                                            \
     if (dq2)                                                                                                      \
-      hipLaunchKernelGGL((attn_bwd_dq2_bx3_kernel<DR, FA>), dim3(B * H * (Ntok / 256)), 256, 0, stream, q, k, v, d_o, \
-                         lse, dwork, dq, mask, Ntok, ld, ldo, scale, p_drop, H);                                  \
+      hipLaunchKernelGGL((attn_bwd_dq2_bx3_kernel<DR, FA, false>), dim3(B * H * (Ntok / 256)), 256, 0, stream, q, k, v, d_o, \
+                         lse, dwork, dq, mask, Ntok, ld, ldo, scale, p_drop, H, 0L, ld);                          \
     else                                                                                                          \
       hipLaunchKernelGGL((attn_bwd_dq_bx3_kernel<DR, FA>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dq, mask, \
                          Ntok, ld, ldo, scale, p_drop, H);                                                        \
@@ -1024,6 +1151,76 @@ int focr_attn_bwd_bx3(const float* q, const float* k, const float* v, const floa
   } else {
     if (fast) LAUNCH_BWD(false, true);
     else LAUNCH_BWD(false, false);
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pre-split operand planes: producer for arbitrary fp32 inputs + the launchers of the PL kernel variants
+// ---------------------------------------------------------------------------------------------------------------
+// x [rows][ld] (128 columns used) -> hi plane [rows][128] bf16, lo plane `pls` elements behind; values multiplied by `mul`
+__global__ __launch_bounds__(256) void attn_make_planes_kernel(const float* __restrict__ x, __bf16* __restrict__ out,
+                                                               long rows, int ld, long pls, float mul) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;          // one float4 each
+  if (i >= rows * 32) return;
+  const long r = i >> 5;
+  const int c = (int)(i & 31) * 4;
+  const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
+  const float a[4] = {v.x * mul, v.y * mul, v.z * mul, v.w * mul};
+  bf16x4 h, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    __bf16 hh, ll;
+    split1(a[e], hh, ll);
+    h[e] = hh;
+    l[e] = ll;
+  }
+  *reinterpret_cast<bf16x4*>(out + r * 128 + c) = h;
+  *reinterpret_cast<bf16x4*>(out + pls + r * 128 + c) = l;
+}
+int focr_attn_make_planes(const float* x, void* planes, long rows, int ld, float mul, hipStream_t stream) {
+  hipLaunchKernelGGL(attn_make_planes_kernel, dim3((unsigned)((rows * 32 + 255) / 256)), 256, 0, stream, x,
+                     reinterpret_cast<__bf16*>(planes), rows, ld, rows * 128, mul);
+  return 0;
+}
+// qp / kp / vp (/ gp): hi planes [B * Ntok][128] bf16, lo planes rows * 128 elements behind.  Ntok % 256 == 0, H = 4.
+int focr_attn_fwd_bx3_planes(const void* qp, const void* kp, const void* vp, float* o, float* lse, const uint32_t* mask,
+                             int B, int H, int Ntok, int ldo, float p_drop, hipStream_t stream) {
+  const long pls = (long)B * Ntok * 128;
+  const float* q = reinterpret_cast<const float*>(qp);
+  const float* k = reinterpret_cast<const float*>(kp);
+  const float* v = reinterpret_cast<const float*>(vp);
+  dim3 grid2(B * H * (Ntok / 256));
+  if (p_drop > 0.f)
+    hipLaunchKernelGGL((attn_fwd2_bx3_kernel<true, true>), grid2, 256, 0, stream, q, k, v, o, lse, mask, Ntok, 128, ldo,
+                       1.f, p_drop, (uint64_t)0, H, pls);
+  else
+    hipLaunchKernelGGL((attn_fwd2_bx3_kernel<false, true>), grid2, 256, 0, stream, q, k, v, o, lse, mask, Ntok, 128, ldo,
+                       1.f, p_drop, (uint64_t)0, H, pls);
+  return 0;
+}
+int focr_attn_bwd_bx3_planes(const void* qp, const void* kp, const void* vp, const void* gp, const float* lse,
+                             const float* dwork, const uint32_t* mask, float* dq, float* dk, float* dv, int B, int H,
+                             int Ntok, int ldg, float scale, float p_drop, hipStream_t stream) {
+  const long pls = (long)B * Ntok * 128;
+  const float* q = reinterpret_cast<const float*>(qp);
+  const float* k = reinterpret_cast<const float*>(kp);
+  const float* v = reinterpret_cast<const float*>(vp);
+  const float* g = reinterpret_cast<const float*>(gp);
+  const bool fast = focr_get_precision() >= 2;
+#define LAUNCH_BWD_PL(DR, FA)                                                                                      \
+  do {                                                                                                             \
+    hipLaunchKernelGGL((attn_bwd_dkv_bx3_kernel<DR, FA, true>), dim3(B * H * (Ntok / 128)), 256, 0, stream, q, k, v, g, \
+                       lse, dwork, dk, dv, mask, Ntok, 128, 128, scale, p_drop, H, pls, ldg);                      \
+    hipLaunchKernelGGL((attn_bwd_dq2_bx3_kernel<DR, FA, true>), dim3(B * H * (Ntok / 256)), 256, 0, stream, q, k, v, g, \
+                       lse, dwork, dq, mask, Ntok, 128, 128, scale, p_drop, H, pls, ldg);                          \
+  } while (0)
+  if (p_drop > 0.f) {
+    if (fast) LAUNCH_BWD_PL(true, true);
+    else LAUNCH_BWD_PL(true, false);
+  } else {
+    if (fast) LAUNCH_BWD_PL(false, true);
+    else LAUNCH_BWD_PL(false, false);
   }
   return 0;
 }

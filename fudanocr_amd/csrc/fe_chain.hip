@@ -110,6 +110,25 @@ __device__ __forceinline__ void fc_store_row(float* __restrict__ p, int lh, cons
       *reinterpret_cast<float4*>(p + 32 * j + 8 * g + 4 * lh) =
           make_float4(v[j][4 * g], v[j][4 * g + 1], v[j][4 * g + 2], v[j][4 * g + 3]);
 }
+// the row as bf16 hi / lo planes (x * mul = hi + lo; lo plane `pls` elements behind the hi plane)
+template <int NT>
+__device__ __forceinline__ void fc_store_planes(__bf16* __restrict__ p, long pls, int lh, const f32x16 (&v)[NT], float mul) {
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      fc_bf16x4 h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = v[j][4 * g + e] * mul;
+        const __bf16 t = (__bf16)x;
+        h[e] = t;
+        l[e] = (__bf16)(x - (float)t);
+      }
+      *reinterpret_cast<fc_bf16x4*>(p + 32 * j + 8 * g + 4 * lh) = h;
+      *reinterpret_cast<fc_bf16x4*>(p + pls + 32 * j + 8 * g + 4 * lh) = l;
+    }
+}
 // a vector over the columns (bias, LayerNorm a / b) from LDS, in the lane layout (two distinct addresses per read)
 template <int NT>
 __device__ __forceinline__ void fc_load_vec(const float* s, int lh, f32x16 (&v)[NT]) {
@@ -433,7 +452,7 @@ __global__ __launch_bounds__(FC_THREADS, 1) void fe_bwd_b_kernel(
     const float* __restrict__ dhpre, const float* __restrict__ ds2, const float* __restrict__ W1,
     const float* __restrict__ xhat1, const float* __restrict__ rinv1, const float* __restrict__ a1,
     const float* __restrict__ Wo, float* __restrict__ ds1, float* __restrict__ dctx, int ntiles, float eps,
-    const float* __restrict__ octx, float* __restrict__ Dw, int ntok) {
+    const float* __restrict__ octx, float* __restrict__ Dw, int ntok, __bf16* __restrict__ dop, long pls, float gmul) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fc_smem[];
   __bf16* W1th = reinterpret_cast<__bf16*>(fc_smem);
   __bf16* W1tl = W1th + WSZ128;
@@ -464,7 +483,8 @@ __global__ __launch_bounds__(FC_THREADS, 1) void fe_bwd_b_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) d[j][r] = 0.f;
     fc_gemm<4, 8, KP128>(Woth + z, Wotl + z, 0, li, lh, xh, xl, d);
-    fc_store_row<4>(dctx + row * FC_D, lh, d);
+    if (dctx) fc_store_row<4>(dctx + row * FC_D, lh, d);
+    if (dop) fc_store_planes<4>(dop + row * FC_D, pls, lh, d, gmul);     // dO / P(keep), pre-split for the attention backward
     if (Dw) {
       // D[b][head][token] = sum over the head's 32 columns of dO * O (the attention backward's row term): accumulator
       // tile j IS head j, so this is an in-lane sum + one exchange -- the separate prep pass over dO and O is gone
@@ -490,7 +510,8 @@ __global__ __launch_bounds__(FC_THREADS, 1) void fe_bwd_b_kernel(
 __global__ __launch_bounds__(256, 2) void fe_qkv_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ pe,
                                                            const float* __restrict__ Wqkv,
                                                            const float* __restrict__ bqkv, float* __restrict__ tok,
-                                                           float* __restrict__ qkv, int ntiles, int ntok) {
+                                                           float* __restrict__ qkv, int ntiles, int ntok,
+                                                           __bf16* __restrict__ planes, long pls, float qmul) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fc_smem[];
   __bf16* Wh = reinterpret_cast<__bf16*>(fc_smem);
   __bf16* Wl = Wh + WSZ128;
@@ -533,7 +554,9 @@ __global__ __launch_bounds__(256, 2) void fe_qkv_fwd_kernel(const float* __restr
     const int z = fc_opaque_zero();
     fc_load_vec<4>(vb + z, lh, v);
     fc_gemm<4, 8, KP128>(Wh + z, Wl + z, 0, li, lh, xh, xl, v);
-    fc_store_row<4>(qkv + row * 384 + 128 * y, lh, v);
+    if (qkv) fc_store_row<4>(qkv + row * 384 + 128 * y, lh, v);
+    // pre-split bf16 hi / lo planes of Q (x scale log2 e), K, V for the attention kernels' PL variants
+    if (planes) fc_store_planes<4>(planes + (size_t)(2 * y) * pls + row * FC_D, pls, lh, v, y == 0 ? qmul : 1.f);
   }
 }
 
@@ -735,9 +758,9 @@ extern "C" int focr_fe_post_bwd(const float* d_out, const float* wl, const float
                                 const float* a3, const float* w2, const float* h, float keep_scale, const float* w1,
                                 const float* xhat1, const float* rinv1, const float* a1, const float* wo, float* d_s2,
                                 float* d_hpre, float* d_s1, float* d_ctx, long rows, float eps, const float* ctx,
-                                float* dwork, int ntok, hipStream_t stream) {
+                                float* dwork, int ntok, void* d_ctx_planes, float planes_mul, hipStream_t stream) {
   FOCR_CHECK_ARG(d_out && wl && xhat2 && rinv2 && a3 && w2 && h && w1 && xhat1 && rinv1 && a1 && wo && d_s2 && d_hpre &&
-                     d_s1 && d_ctx,
+                     d_s1 && (d_ctx || d_ctx_planes),
                  "null pointer");
   FOCR_CHECK_ARG(focr_fe_chain_supported(rows, FC_D), "rows must be a positive multiple of 32 (precision mode != 0)");
   FOCR_CHECK_ARG(!dwork || (ctx && ntok > 0 && rows % ntok == 0), "dwork needs ctx and the tokens per image");
@@ -753,15 +776,16 @@ extern "C" int focr_fe_post_bwd(const float* d_out, const float* wl, const float
   hipLaunchKernelGGL(fe_bwd_a_kernel, dim3(nb), FC_THREADS, FC_LDS_BWD_A, stream, d_out, wl, xhat2, rinv2, a3, w2, h,
                      d_s2, d_hpre, ntiles, eps, keep_scale);
   hipLaunchKernelGGL(fe_bwd_b_kernel, dim3(nb), FC_THREADS, FC_LDS_BWD_B, stream, (const float*)d_hpre,
-                     (const float*)d_s2, w1, xhat1, rinv1, a1, wo, d_s1, d_ctx, ntiles, eps, ctx, dwork, ntok);
+                     (const float*)d_s2, w1, xhat1, rinv1, a1, wo, d_s1, d_ctx, ntiles, eps, ctx, dwork, ntok,
+                     reinterpret_cast<__bf16*>(d_ctx_planes), rows * FC_D, planes_mul);
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }
 
 // tok [rows,128] = [feat | pe[row % ntok]], qkv [rows,384] = tok Wqkv^T + bqkv (packed q | k | v projection)
 extern "C" int focr_fe_qkv_fwd(const float* feat, const float* pe, const float* wqkv, const float* bqkv, float* tok,
-                               float* qkv, long rows, int ntok, hipStream_t stream) {
-  FOCR_CHECK_ARG(feat && pe && wqkv && tok && qkv && ntok > 0, "bad argument");
+                               float* qkv, long rows, int ntok, void* planes, float q_mul, hipStream_t stream) {
+  FOCR_CHECK_ARG(feat && pe && wqkv && tok && (qkv || planes) && ntok > 0, "bad argument");
   FOCR_CHECK_ARG(focr_fe_chain_supported(rows, FC_D), "rows must be a positive multiple of 32 (precision mode != 0)");
   static bool attr = false;
   if (!attr) {
@@ -775,7 +799,7 @@ extern "C" int focr_fe_qkv_fwd(const float* feat, const float* pe, const float* 
   int nb = (ntiles + 3) / 4;
   if (nb > 171) nb = 171;                   // x 3 column groups = 513 blocks: one round at two blocks per CU
   hipLaunchKernelGGL(fe_qkv_fwd_kernel, dim3(nb, 3), 256, FC_LDS_QKV_FWD, stream, feat, pe, wqkv, bqkv, tok, qkv, ntiles,
-                     ntok);
+                     ntok, reinterpret_cast<__bf16*>(planes), rows * FC_D, q_mul);
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }

@@ -997,6 +997,9 @@ def fe_chain_supported(feat):
                 and _lib.load().focr_fe_chain_supported(feat.shape[0] * feat.shape[1], 128))
 
 
+# FOCR_ATTN_PLANES=0: fp32 q | k | v between the projection and the attention kernels (each block splits its tiles itself)
+_ATTN_PLANES = os.environ.get("FOCR_ATTN_PLANES", "1") != "0"
+_LOG2E = 1.4426950408889634
 # FOCR_DEFER_SIDE=1: park the convolution / QKV weight gradients of a residual block and issue them beside the NEXT
 # block's attention backward.  Measured (same box, interleaved): 15.32 ms vs 15.13 ms without -- the attention kernels lose
 # more to the extra company than the HBM-bound kernels gain; off by default, kept as an A/B switch.
@@ -1013,20 +1016,31 @@ def _fe_forward(step, feat, xres, pe, heads, p_attn, p_ffn, eps, params):
     rows, d = b * t, 128
     dev = feat.device
     tok = torch.empty((b, t, d), device=dev)
-    qkv = torch.empty((b, t, 3 * d), device=dev)
     if pe.shape[0] != t or pe.shape[-1] != 64:
         raise RuntimeError("positional-encoding table must be [tokens per image, 64]")
-    _lib.call("focr_fe_qkv_fwd", _p(feat), _p(pe), _p(wqkv), _p(bqkv), _p(tok), _p(qkv), rows, t, _stream())
     o = torch.empty((b, t, d), device=dev)
     lse = torch.empty((b, heads, t), device=dev)
     mask, ready = step.next_mask(b, heads, t, p_attn, dev) if p_attn > 0 else (None, False)
     scale = 1.0 / math.sqrt(d // heads)
-    if ready:
-        _lib.call("focr_attention_fwd_premasked", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _p(o), _p(lse),
-                  _p(mask), b, heads, t, 3 * d, d, scale, float(p_attn), _stream())
+    if _ATTN_PLANES and _lib.load().focr_attention_planes_supported(heads, t, d):
+        # the projection writes Q * scale * log2(e), K, V ALREADY split into bf16 hi / lo planes ([3][2][rows][128], the
+        # bytes of the fp32 tensor): the attention kernels stage them by plain copies (csrc/attention_bx3.hip PL variants)
+        qkv = torch.empty((3, 2, rows, d), device=dev, dtype=torch.bfloat16)
+        _lib.call("focr_fe_qkv_fwd", _p(feat), _p(pe), _p(wqkv), _p(bqkv), _p(tok), _NULL, rows, t, _p(qkv),
+                  scale * _LOG2E, _stream())
+        pq, pk, pv = (ctypes.c_void_p(qkv.data_ptr() + i * 2 * rows * d * 2) for i in range(3))
+        _lib.call("focr_attention_planes_fwd", pq, pk, pv, _p(o), _p(lse), _p(mask), b, heads, t, d, float(p_attn),
+                  _new_seed() if (p_attn > 0 and not ready) else 0, int(ready), _stream())
     else:
-        _lib.call("focr_attention_fwd", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _p(o), _p(lse), _p(mask), b,
-                  heads, t, 3 * d, d, scale, float(p_attn), _new_seed() if p_attn > 0 else 0, _stream())
+        qkv = torch.empty((b, t, 3 * d), device=dev)
+        _lib.call("focr_fe_qkv_fwd", _p(feat), _p(pe), _p(wqkv), _p(bqkv), _p(tok), _p(qkv), rows, t, _NULL, 1.0,
+                  _stream())
+        if ready:
+            _lib.call("focr_attention_fwd_premasked", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _p(o), _p(lse),
+                      _p(mask), b, heads, t, 3 * d, d, scale, float(p_attn), _stream())
+        else:
+            _lib.call("focr_attention_fwd", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _p(o), _p(lse), _p(mask), b,
+                      heads, t, 3 * d, d, scale, float(p_attn), _new_seed() if p_attn > 0 else 0, _stream())
     xhat1, xhat2, h = torch.empty_like(tok), torch.empty_like(tok), torch.empty_like(tok)
     rinv1, rinv2 = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
     out = torch.empty((b, t, cf), device=dev)
@@ -1052,11 +1066,21 @@ def _fe_backward(step, saved, cfg, params, targets, d_out, need_dfeat, need_para
     b, t, heads, scale, p_attn, eps, keep_scale = cfg
     rows, d = b * t, 128
     dev = d_out.device
-    d_s2, d_hpre, d_s1, d_ctx = (torch.empty_like(tok) for _ in range(4))
+    d_s2, d_hpre, d_s1 = (torch.empty_like(tok) for _ in range(3))
     work = torch.empty((b, heads, t), device=dev)
-    _lib.call("focr_fe_post_bwd", _p(d_out), _p(wl), _p(xhat2), _p(rinv2), _p(a3), _p(w2), _p(h), keep_scale,
-              _p(w1), _p(xhat1), _p(rinv1), _p(a1), _p(wo), _p(d_s2), _p(d_hpre), _p(d_s1), _p(d_ctx), rows, eps,
-              _p(o), _p(work), t, _stream())
+    planes = qkv.dtype == torch.bfloat16          # the forward ran on pre-split planes: so does the backward
+    if planes:
+        # the chain kernel hands the attention backward dO / P(keep) as bf16 hi / lo planes (no fp32 d_ctx at all)
+        d_ctx = torch.empty((2, rows, d), device=dev, dtype=torch.bfloat16)
+        ik = _lib.load().focr_attention_keep_scale(float(p_attn))
+        _lib.call("focr_fe_post_bwd", _p(d_out), _p(wl), _p(xhat2), _p(rinv2), _p(a3), _p(w2), _p(h), keep_scale,
+                  _p(w1), _p(xhat1), _p(rinv1), _p(a1), _p(wo), _p(d_s2), _p(d_hpre), _p(d_s1), _NULL, rows, eps,
+                  _p(o), _p(work), t, _p(d_ctx), float(ik), _stream())
+    else:
+        d_ctx = torch.empty_like(tok)
+        _lib.call("focr_fe_post_bwd", _p(d_out), _p(wl), _p(xhat2), _p(rinv2), _p(a3), _p(w2), _p(h), keep_scale,
+                  _p(w1), _p(xhat1), _p(rinv1), _p(a1), _p(wo), _p(d_s2), _p(d_hpre), _p(d_s1), _p(d_ctx), rows, eps,
+                  _p(o), _p(work), t, _NULL, 1.0, _stream())
     grads = [None] * len(FE_PARAM_NAMES)
     side, g, nws = None, None, 0
     if need_params:
@@ -1089,11 +1113,16 @@ def _fe_backward(step, saved, cfg, params, targets, d_out, need_dfeat, need_para
     step.flush_side()          # the previous block's parked weight gradients: beside THIS block's attention backward
     if need_params and _FE_WGRAD_EARLY:
         wgrads(1, (d_out, xhat2, d_s2, h, d_hpre, xhat1, d_s1, o))
-    dqkv = torch.empty_like(qkv)
-    # o = NULL: `work` already holds D = rowsum(d_ctx * o) per (b, head, token), written by the chain kernel above
-    _lib.call("focr_attention_bwd", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _NULL, _p(d_ctx), _p(lse), _p(mask),
-              _po(dqkv, 0), _po(dqkv, d), _po(dqkv, 2 * d), _p(work), b, heads, t, 3 * d, d, scale, p_attn,
-              _stream())
+    dqkv = torch.empty((b, t, 3 * d), device=dev)
+    # `work` already holds D = rowsum(d_ctx * o) per (b, head, token), written by the chain kernel above
+    if planes:
+        pq, pk, pv = (ctypes.c_void_p(qkv.data_ptr() + i * 2 * rows * d * 2) for i in range(3))
+        _lib.call("focr_attention_planes_bwd", pq, pk, pv, _p(d_ctx), _p(lse), _p(work), _p(mask), _po(dqkv, 0),
+                  _po(dqkv, d), _po(dqkv, 2 * d), b, heads, t, 3 * d, scale, p_attn, _stream())
+    else:
+        _lib.call("focr_attention_bwd", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _NULL, _p(d_ctx), _p(lse), _p(mask),
+                  _po(dqkv, 0), _po(dqkv, d), _po(dqkv, 2 * d), _p(work), b, heads, t, 3 * d, d, scale, p_attn,
+                  _stream())
     d_feat = None
     if need_dfeat:
         d_feat = torch.empty((b, t, 64), device=dev)

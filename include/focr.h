@@ -154,6 +154,21 @@ int focr_attention_fwd_premasked(const float* q, const float* k, const float* v,
                                  const uint32_t* mask, int B, int H, int Ntok, int ld, int ldo, float scale,
                                  float p_drop, focr_stream_t stream);
 /* dwork: B*H*Ntok floats */
+/* ---- attention on pre-split operand planes (csrc/attention_bx3.hip PL variants): a plane set of a [rows][128] tensor is
+ * the bf16 hi plane followed by the lo plane (x = hi + lo, 2 * rows * 128 elements).  Q planes hold Q * scale * log2(e),
+ * dO planes dO * focr_attention_keep_scale(p_drop); the kernels then stage their tiles by plain copies -- the fp32 ->
+ * bf16 split is done once by the producer (focr_fe_qkv_fwd / focr_fe_post_bwd, or focr_attention_make_planes for any
+ * fp32 tensor) instead of by every consumer block.  4 heads of 32, Ntok % 256 == 0, precision mode != 0.
+ * focr_attention_planes_bwd: dwork = D = rowsum(dO * O) from the UNSCALED dO; dq / dk / dv fp32 with row pitch ldg. */
+int focr_attention_planes_supported(int H, int Ntok, int d_model);
+float focr_attention_keep_scale(float p_drop);
+int focr_attention_make_planes(const float* x, void* planes, long rows, int ld, float mul, focr_stream_t stream);
+int focr_attention_planes_fwd(const void* qp, const void* kp, const void* vp, float* o, float* lse, uint32_t* mask,
+                              int B, int H, int Ntok, int ldo, float p_drop, uint64_t seed, int mask_ready,
+                              focr_stream_t stream);
+int focr_attention_planes_bwd(const void* qp, const void* kp, const void* vp, const void* dop, const float* lse,
+                              const float* dwork, const uint32_t* mask, float* dq, float* dk, float* dv, int B, int H,
+                              int Ntok, int ldg, float scale, float p_drop, focr_stream_t stream);
 /* o == NULL: dwork already holds D = rowsum(d_o * o) per (b, head, token) (see focr_fe_post_bwd) */
 int focr_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o,
                        const float* lse, const uint32_t* mask, float* dq, float* dk, float* dv,
@@ -223,6 +238,9 @@ int focr_slice_cols(const float* x, const float* add, float* out, long rows, int
  *                      With dwork != NULL it also writes D[b][head][token] = sum_d d_ctx * ctx (ntok tokens per image),
  *                      the row term of the attention backward: focr_attention_bwd is then called with o = NULL.
  *   focr_fe_qkv_fwd  : tok = [feat | pe[row % ntok]] (tbsrn.py:83-86) and the packed q | k | v projection in one kernel.
+ *                      planes != NULL: Q * q_mul, K, V are (also, or with qkv = NULL: only) written as pre-split bf16
+ *                      planes [3 tensors][hi, lo][rows][128] for focr_attention_planes_*; focr_fe_post_bwd's d_ctx_planes
+ *                      likewise receives d_ctx * planes_mul as [hi, lo][rows][128] (d_ctx itself may then be NULL).
  *   focr_fe_qkv_dgrad: d_feat[rows,64] = dqkv[rows,384] Wqkv[:, 0:64] + d_s1[:, 0:64] (the positional-encoding half of
  *                      the token, tbsrn.py:83-86, has no gradient consumer).
  *   focr_fe_wgrads   : every parameter gradient of these layers in one call (targets are overwritten); the LayerNorm
@@ -240,9 +258,9 @@ int focr_fe_post_bwd(const float* d_out, const float* wl, const float* xhat2, co
                      const float* w2, const float* h, float keep_scale, const float* w1, const float* xhat1,
                      const float* rinv1, const float* a1, const float* wo, float* d_s2, float* d_hpre, float* d_s1,
                      float* d_ctx, long rows, float eps, const float* ctx, float* dwork, int ntok,
-                     focr_stream_t stream);
+                     void* d_ctx_planes, float planes_mul, focr_stream_t stream);
 int focr_fe_qkv_fwd(const float* feat, const float* pe, const float* wqkv, const float* bqkv, float* tok,
-                    float* qkv, long rows, int ntok, focr_stream_t stream);
+                    float* qkv, long rows, int ntok, void* planes, float q_mul, focr_stream_t stream);
 int focr_fe_qkv_dgrad(const float* dqkv, const float* wqkv, const float* d_s1, float* d_feat, long rows,
                       focr_stream_t stream);
 long focr_fe_wgrads_ws_floats(long rows);

@@ -17,7 +17,7 @@ def _header_functions():
     text = open(os.path.join(ROOT, "include", "focr.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     out = {}
-    for m in re.finditer(r"\b(?:int|long|const char\*)\s+(focr_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+    for m in re.finditer(r"\b(?:int|long|float|const char\*)\s+(focr_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
         args = m.group(2).strip()
         out[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
     return out

@@ -82,6 +82,41 @@ int main(int argc, char** argv) {
     double eq = maxdiff(dq0, dq1, n, &m1), ek = maxdiff(dk0, dk1, n, &m2), ev = maxdiff(dv0, dv1, n, &m3);
     printf("bwd p=%.1f: variant0 %7.1f us  variant1 %7.1f us  max diff dq %.2e/%.2e dk %.2e/%.2e dv %.2e/%.2e\n", p, b0, b1, eq, m1, ek, m2, ev, m3);
     fflush(stdout);
+    // ---- pre-split operand planes (PL kernel variants) against the fp32-input kernels above (variant 1 / dq2)
+    {
+      const long rows = (long)B * N;
+      static void *qp = nullptr, *kp, *vp, *gp;
+      if (!qp) { CK(hipMalloc(&qp, rows * 512)); CK(hipMalloc(&kp, rows * 512)); CK(hipMalloc(&vp, rows * 512)); CK(hipMalloc(&gp, rows * 512)); }
+      const float ik = focr_attention_keep_scale(p);
+      focr_attention_make_planes(q, qp, rows, D, scale * LOG2E, 0);
+      focr_attention_make_planes(k, kp, rows, D, 1.f, 0);
+      focr_attention_make_planes(v, vp, rows, D, 1.f, 0);
+      focr_attention_make_planes(dO, gp, rows, D, ik, 0);
+      float tmk = timeit([&]() { focr_attention_make_planes(q, qp, rows, D, scale * LOG2E, 0); });
+      g_tune[FOCR_TUNE_ATTN_FWD_VARIANT] = 1;
+      focr_attention_fwd(q, k, v, o0, lse0, mask, B, H, N, D, D, scale, p, 1234, 0);
+      int rc = focr_attention_planes_fwd(qp, kp, vp, o1, lse1, mask, B, H, N, D, p, 1234, 1, 0);
+      if (rc) { printf("planes fwd failed %d\n", rc); return 1; }
+      float f0 = timeit([&]() { focr_attention_fwd_premasked(q, k, v, o0, lse0, mask, B, H, N, D, D, scale, p > 0 ? p : 0.1f, 0); }, 8);
+      if (p == 0.f) f0 = timeit([&]() { focr_attention_fwd(q, k, v, o0, lse0, mask, B, H, N, D, D, scale, 0.f, 1234, 0); }, 8);
+      float f1 = timeit([&]() { focr_attention_planes_fwd(qp, kp, vp, o1, lse1, mask, B, H, N, D, p, 1234, 1, 0); }, 8);
+      CK(hipDeviceSynchronize());
+      double mxo, eo = maxdiff(o0, o1, n, &mxo), mxl, el = maxdiff(lse0, lse1, (long)B * H * N, &mxl);
+      // backward: D from the reference path's prep (work), same keep bits
+      g_tune[FOCR_TUNE_ATTN_BWD_DQ_VARIANT] = 1;
+      focr_attention_bwd(q, k, v, o0, dO, lse0, mask, dq0, dk0, dv0, work, B, H, N, D, D, scale, p, 0);
+      rc = focr_attention_planes_bwd(qp, kp, vp, gp, lse0, work, mask, dq1, dk1, dv1, B, H, N, D, scale, p, 0);
+      if (rc) { printf("planes bwd failed %d\n", rc); return 1; }
+      float bb0 = timeit([&]() { focr_attention_bwd(q, k, v, nullptr, dO, lse0, mask, dq0, dk0, dv0, work, B, H, N, D, D, scale, p, 0); }, 8);
+      float bb1 = timeit([&]() { focr_attention_planes_bwd(qp, kp, vp, gp, lse0, work, mask, dq1, dk1, dv1, B, H, N, D, scale, p, 0); }, 8);
+      CK(hipDeviceSynchronize());
+      double a1, a2, a3;
+      double dq_e = maxdiff(dq0, dq1, n, &a1), dk_e = maxdiff(dk0, dk1, n, &a2), dv_e = maxdiff(dv0, dv1, n, &a3);
+      printf("PLANES p=%.1f: fwd fp32-in %7.1f us  planes %7.1f us (make_planes %5.1f us each)  max|dO| %.2e of %.2e  max|dLSE| %.2e\n"
+             "              bwd (no prep) fp32-in %7.1f us  planes %7.1f us  max diff dq %.2e/%.2e dk %.2e/%.2e dv %.2e/%.2e\n",
+             p, f0, f1, tmk, eo, mxo, el, bb0, bb1, dq_e, a1, dk_e, a2, dv_e, a3);
+      fflush(stdout);
+    }
   }
   return 0;
 }

@@ -138,7 +138,7 @@ int main(int argc, char** argv) {
   // ---- backward (on the reference forward's saved rows, so that the comparison is exact in its inputs)
   float *dwk = buf(M * 4), *rdwk = buf(M * 4);
   rc = focr_fe_post_bwd(dout, p.wl, rxhat2, rrinv2, p.a3, p.w2, rh, 1.25f, p.w1, rxhat1, rrinv1, p.a1, p.wo, ds2, dhpre, ds1,
-                        dctx, M, eps, ctx, dwk, 1024, 0);
+                        dctx, M, eps, ctx, dwk, 1024, nullptr, 1.f, 0);
   if (rc) { printf("focr_fe_post_bwd failed %d\n", rc); return 1; }
   rc = focr_fe_qkv_dgrad(dqkv, p.wqkv, ds1, dfeat, M, 0);
   if (rc) { printf("focr_fe_qkv_dgrad failed %d\n", rc); return 1; }
@@ -154,13 +154,13 @@ int main(int argc, char** argv) {
   {
     float* feat = dalloc(M * 64, 30, 1.f); float* pe = dalloc(1024 * 64, 31, 1.f); float* bqkv = dalloc(384, 32, 0.1f);
     float *tk = buf(M * D), *qk = buf(M * 384), *rtk = buf(M * D), *rqk = buf(M * 384);
-    rc = focr_fe_qkv_fwd(feat, pe, p.wqkv, bqkv, tk, qk, M, 1024, 0);
+    rc = focr_fe_qkv_fwd(feat, pe, p.wqkv, bqkv, tk, qk, M, 1024, nullptr, 1.f, 0);
     if (rc) { printf("focr_fe_qkv_fwd failed %d\n", rc); return 1; }
     hipLaunchKernelGGL(ref_qkv, dim3((M + 63) / 64), 64, 0, 0, p, feat, pe, bqkv, rtk, rqk, M, 1024);
     CK(hipDeviceSynchronize());
     printf("qkv forward:\n");
     cmp("tok", tk, rtk, M * D, 0.0); cmp("qkv", qk, rqk, M * 384, 2e-5);
-    float tq = timeit([&] { focr_fe_qkv_fwd(feat, pe, p.wqkv, bqkv, tk, qk, M, 1024, 0); });
+    float tq = timeit([&] { focr_fe_qkv_fwd(feat, pe, p.wqkv, bqkv, tk, qk, M, 1024, nullptr, 1.f, 0); });
     printf("fe_qkv_fwd %7.1f us  %.2f TB/s (5.5 row matrices)\n", tq, 5.5 * (double)M * D * 4 / tq * 1e-6);
   }
   // ---- dropout statistics: kept elements equal scale * reference, dropped fraction of the positive ones ~ p
@@ -183,7 +183,7 @@ int main(int argc, char** argv) {
   printf("fe_fwd_b   %7.1f us  %.2f TB/s (4 row matrices)\n", t, 4 * T / t * 1e-6);
   t = timeit([&] { hipLaunchKernelGGL(fe_bwd_a_kernel, dim3(fc_blocks(M / 32)), FC_THREADS, FC_LDS_BWD_A, 0, dout, p.wl, rxhat2, rrinv2, p.a3, p.w2, rh, ds2, dhpre, (int)(M / 32), eps, 1.25f); });
   printf("fe_bwd_a   %7.1f us  %.2f TB/s (4.5 row matrices)\n", t, 4.5 * T / t * 1e-6);
-  t = timeit([&] { hipLaunchKernelGGL(fe_bwd_b_kernel, dim3(fc_blocks(M / 32)), FC_THREADS, FC_LDS_BWD_B, 0, (const float*)dhpre, (const float*)ds2, p.w1, rxhat1, rrinv1, p.a1, p.wo, ds1, dctx, (int)(M / 32), eps, (const float*)ctx, dwk, 1024); });
+  t = timeit([&] { hipLaunchKernelGGL(fe_bwd_b_kernel, dim3(fc_blocks(M / 32)), FC_THREADS, FC_LDS_BWD_B, 0, (const float*)dhpre, (const float*)ds2, p.w1, rxhat1, rrinv1, p.a1, p.wo, ds1, dctx, (int)(M / 32), eps, (const float*)ctx, dwk, 1024, (__bf16*)nullptr, 0L, 1.f); });
   printf("fe_bwd_b   %7.1f us  %.2f TB/s (6 row matrices, incl. D)\n", t, 6 * T / t * 1e-6);
   t = timeit([&] { hipLaunchKernelGGL(fe_bwd_qkv_kernel, dim3(fc_blocks(M / 32)), FC_THREADS, FC_LDS_BWD_QKV, 0, dqkv, p.wqkv, (const float*)ds1, dfeat, (int)(M / 32), D); });
   printf("fe_bwd_qkv %7.1f us  %.2f TB/s (4 row matrices)\n", t, 4 * T / t * 1e-6);
