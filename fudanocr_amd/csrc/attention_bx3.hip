@@ -95,13 +95,23 @@ __device__ __forceinline__ void row_frag(const float* p, float sc, bf16x8& hi, b
 
 // ---- pre-split operand planes ("PL" kernel variants) -----------------------------------------------------------
 // The producers of Q / K / V (the packed projection, csrc/fe_chain.hip fe_qkv_fwd_kernel) and of dO (fe_bwd_b_kernel)
-// can write their results ALREADY split: bf16 hi plane [rows][128] followed by the lo plane `pls` elements later, Q
-// pre-multiplied by scale * log2(e), dO by 1 / P(keep).  The PL variants of the three big kernels then stage tiles by
-// copying 8-byte words (global -> LDS, transposition = one v_perm per word pair) and take their register fragments
-// straight from memory: the per-block fp32 -> bf16 hi/lo split of every K / V / Q / dO tile (a quarter of the dK/dV
+// can write their results ALREADY split, as rows of 256 bf16 in which every group of four columns is stored as
+// [hi x 4 | lo x 4] (x = hi + lo; 512 bytes per row, the bytes of the fp32 row: producers and consumers move 16 bytes per
+// lane and instruction exactly as with fp32, no extra memory instructions), Q pre-multiplied by scale * log2(e), dO by
+// 1 / P(keep).  The PL variants of the three big kernels then stage tiles by copying words (global -> LDS,
+// transposition = one v_perm per word pair) and take their register fragments straight from memory: the per-block fp32 -> bf16 hi/lo split of every K / V / Q / dO tile (a quarter of the dK/dV
 // pass's VALU work) is done once by the producer instead of by every consumer block.  Same values as the fp32 path
 // (the split is the same arithmetic), except that the dropout scale rides on dO instead of V in the dK/dV pass.
-__device__ __forceinline__ bf16x8 pl_frag(const __bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+// eight consecutive columns (from a multiple of 8) of one row: two 16-byte words [hi4 | lo4][hi4 | lo4] -> hi / lo fragments
+__device__ __forceinline__ void pl_frag(const __bf16* p, bf16x8& hi, bf16x8& lo) {
+  typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+  const u4 a = *reinterpret_cast<const u4*>(p), b = *reinterpret_cast<const u4*>(p + 8);
+  const u4 h = {a[0], a[1], b[0], b[1]}, l = {a[2], a[3], b[2], b[3]};
+  hi = __builtin_bit_cast(bf16x8, h);
+  lo = __builtin_bit_cast(bf16x8, l);
+}
+// element offset of column c (multiple of 4) inside a 256-element row
+#define PLC(c) (2 * (c))
 // two rows (2 rp, 2 rp + 1) x 4 columns (c0 ..) of one plane, held as two 8-byte words
 __device__ __forceinline__ void pl_put_rows(__bf16* T, int rp, int c0, uint2 r0, uint2 r1) {
   *reinterpret_cast<uint2*>(&T[(2 * rp) * RP + c0]) = r0;
@@ -115,7 +125,9 @@ __device__ __forceinline__ void pl_put_cols(__bf16* T, int rp, int c0, uint2 r0,
   t[((c0 + 2) * TP + 2 * rp) >> 1] = __builtin_amdgcn_perm(r1.y, r0.y, 0x05040100u);
   t[((c0 + 3) * TP + 2 * rp) >> 1] = __builtin_amdgcn_perm(r1.y, r0.y, 0x07060302u);
 }
-__device__ __forceinline__ uint2 pl_ld(const __bf16* p) { return *reinterpret_cast<const uint2*>(p); }
+__device__ __forceinline__ uint4 pl_ld(const __bf16* p) { return *reinterpret_cast<const uint4*>(p); }   // [hi4 | lo4]
+__device__ __forceinline__ uint2 pl_hi(uint4 w) { return make_uint2(w.x, w.y); }
+__device__ __forceinline__ uint2 pl_lo(uint4 w) { return make_uint2(w.z, w.w); }
 
 // =======================================================================================
 // forward
@@ -266,9 +278,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __re
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       if (PL) {
-        const size_t o_ = base + (size_t)(q0 + 32 * t) * ld + 16 * m + 8 * lh;
-        qh[t][m] = pl_frag(Qp + o_);
-        ql[t][m] = pl_frag(Qp + pls + o_);
+        pl_frag(Qp + 2 * base + (size_t)(q0 + 32 * t) * 256 + PLC(16 * m + 8 * lh), qh[t][m], ql[t][m]);
       } else {
         row_frag(Q + base + (size_t)(q0 + 32 * t) * ld + 16 * m + 8 * lh, scale * LOG2E, qh[t][m], ql[t][m]);
       }
@@ -287,14 +297,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __re
 
   const int rp = tid >> 3, c0 = (tid & 7) * 4;         // key pair, first of 4 d columns
   float4 k0, k1, v0, v1;
-  uint2 pk[8];                                         // PL: K hi (2 rows), K lo, V hi, V lo
+  uint4 pk[4];                                         // PL: K rows 2 rp, 2 rp + 1, V rows: [hi4 | lo4] each
 #define PL_LOAD_KV(kt)                                                                \
   do {                                                                                \
-    const size_t o0_ = base + (size_t)((kt) * 64 + 2 * rp) * ld + c0;                 \
-    pk[0] = pl_ld(Kp + o0_); pk[1] = pl_ld(Kp + o0_ + ld);                            \
-    pk[2] = pl_ld(Kp + pls + o0_); pk[3] = pl_ld(Kp + pls + o0_ + ld);                \
-    pk[4] = pl_ld(Vp + o0_); pk[5] = pl_ld(Vp + o0_ + ld);                            \
-    pk[6] = pl_ld(Vp + pls + o0_); pk[7] = pl_ld(Vp + pls + o0_ + ld);                \
+    const size_t o0_ = 2 * base + (size_t)((kt) * 64 + 2 * rp) * 256 + PLC(c0);      \
+    pk[0] = pl_ld(Kp + o0_); pk[1] = pl_ld(Kp + o0_ + 256);                           \
+    pk[2] = pl_ld(Vp + o0_); pk[3] = pl_ld(Vp + o0_ + 256);                           \
   } while (0)
   const int ntiles = Ntok / 64;
   if (PL) PL_LOAD_KV(0);
@@ -305,10 +313,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __re
 #endif
     {
       if (PL) {
-        pl_put_rows(Kh, rp, c0, pk[0], pk[1]);
-        pl_put_rows(Kl, rp, c0, pk[2], pk[3]);
-        pl_put_cols(Vth, rp, c0, pk[4], pk[5]);
-        pl_put_cols(Vtl, rp, c0, pk[6], pk[7]);
+        pl_put_rows(Kh, rp, c0, pl_hi(pk[0]), pl_hi(pk[1]));
+        pl_put_rows(Kl, rp, c0, pl_lo(pk[0]), pl_lo(pk[1]));
+        pl_put_cols(Vth, rp, c0, pl_hi(pk[2]), pl_hi(pk[3]));
+        pl_put_cols(Vtl, rp, c0, pl_lo(pk[2]), pl_lo(pk[3]));
       } else {
         put_rows(Kh, Kl, rp, c0, k0, k1);
         put_cols(Vth, Vtl, rp, c0, v0, v1);
@@ -686,9 +694,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
     if (PL) {        // the dropout scale rides on the dO planes
-      const size_t o_ = base + (size_t)key * ld + 16 * m + 8 * lh;
-      kh[m] = pl_frag(Kp + o_); kl[m] = pl_frag(Kp + pls + o_);
-      vh[m] = pl_frag(Vp + o_); vl[m] = pl_frag(Vp + pls + o_);
+      const size_t o_ = 2 * base + (size_t)key * 256 + PLC(16 * m + 8 * lh);
+      pl_frag(Kp + o_, kh[m], kl[m]);
+      pl_frag(Vp + o_, vh[m], vl[m]);
     } else {
       row_frag(K + base + (size_t)key * ld + 16 * m + 8 * lh, 1.f, kh[m], kl[m]);
       // V carries the dropout scale 1/(1-p): dP' = dO (V/(1-p))^T is all the dS formula below needs of it
@@ -722,14 +730,12 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
     }                                                                                 \
   } while (0)
   const int ntiles = Ntok / 64;
-  uint2 pq[8];                                          // PL: Q hi (2 rows), Q lo, dO hi, dO lo
+  uint4 pq[4];                                          // PL: Q rows 2 rp, 2 rp + 1, dO rows: [hi4 | lo4] each
 #define PL_LOAD_QG(qt)                                                                \
   do {                                                                                \
-    const size_t o0_ = base + (size_t)((qt) * 64 + 2 * rp) * ld + c0;                 \
-    pq[0] = pl_ld(Qp + o0_); pq[1] = pl_ld(Qp + o0_ + ld);                            \
-    pq[2] = pl_ld(Qp + pls + o0_); pq[3] = pl_ld(Qp + pls + o0_ + ld);                \
-    pq[4] = pl_ld(Gp + o0_); pq[5] = pl_ld(Gp + o0_ + ld);                            \
-    pq[6] = pl_ld(Gp + pls + o0_); pq[7] = pl_ld(Gp + pls + o0_ + ld);                \
+    const size_t o0_ = 2 * base + (size_t)((qt) * 64 + 2 * rp) * 256 + PLC(c0);      \
+    pq[0] = pl_ld(Qp + o0_); pq[1] = pl_ld(Qp + o0_ + 256);                           \
+    pq[2] = pl_ld(Gp + o0_); pq[3] = pl_ld(Gp + o0_ + 256);                           \
     if (tid < 64) {                                                                   \
       lreg = LSE[sbase + (qt) * 64 + tid];                                            \
       dreg = Dv[sbase + (qt) * 64 + tid];                                             \
@@ -744,15 +750,15 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
   for (int qt = 0; qt < ntiles; ++qt) {
     const uint32_t mcur0 = mreg0 >> (4 * lh), mcur1 = mreg1 >> (4 * lh);
     if (PL) {
-      pl_put_rows(Qh, rp, c0, pq[0], pq[1]);
-      pl_put_rows(Ql, rp, c0, pq[2], pq[3]);
-      pl_put_rows(Gh, rp, c0, pq[4], pq[5]);
-      pl_put_rows(Gl, rp, c0, pq[6], pq[7]);
-      pl_put_cols(Qth, rp, c0, pq[0], pq[1]);
-      pl_put_cols(Gth, rp, c0, pq[4], pq[5]);
+      pl_put_rows(Qh, rp, c0, pl_hi(pq[0]), pl_hi(pq[1]));
+      pl_put_rows(Ql, rp, c0, pl_lo(pq[0]), pl_lo(pq[1]));
+      pl_put_rows(Gh, rp, c0, pl_hi(pq[2]), pl_hi(pq[3]));
+      pl_put_rows(Gl, rp, c0, pl_lo(pq[2]), pl_lo(pq[3]));
+      pl_put_cols(Qth, rp, c0, pl_hi(pq[0]), pl_hi(pq[1]));
+      pl_put_cols(Gth, rp, c0, pl_hi(pq[2]), pl_hi(pq[3]));
       if (!FAST) {
-        pl_put_cols(Qtl, rp, c0, pq[2], pq[3]);
-        pl_put_cols(Gtl, rp, c0, pq[6], pq[7]);
+        pl_put_cols(Qtl, rp, c0, pl_lo(pq[0]), pl_lo(pq[1]));
+        pl_put_cols(Gtl, rp, c0, pl_lo(pq[2]), pl_lo(pq[3]));
       }
     } else {
       q0 = scale4(q0, scale * LOG2E);     // log2 units: p = exp2(s - lse*log2e); dK is rescaled by ln2 at the end
@@ -977,9 +983,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_bx3_kernel(
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       if (PL) {
-        const size_t o_ = base + (size_t)q * ld + 16 * m + 8 * lh;
-        qh[t][m] = pl_frag(Qp + o_); ql[t][m] = pl_frag(Qp + pls + o_);
-        gh[t][m] = pl_frag(Gp + o_); gl[t][m] = pl_frag(Gp + pls + o_);
+        const size_t o_ = 2 * base + (size_t)q * 256 + PLC(16 * m + 8 * lh);
+        pl_frag(Qp + o_, qh[t][m], ql[t][m]);
+        pl_frag(Gp + o_, gh[t][m], gl[t][m]);
       } else {
         row_frag(Q + base + (size_t)q * ld + 16 * m + 8 * lh, scale * LOG2E, qh[t][m], ql[t][m]);
         // dO carries the dropout scale 1/(1-p) (dP' = V dO'^T); D was computed from the unscaled dO by the prep kernel
@@ -997,18 +1003,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_bx3_kernel(
 
   const int rp = tid >> 3, c0 = (tid & 7) * 4;
   float4 k0, k1, v0, v1;
-  uint2 pk[8];                                         // PL: K hi (2 rows), K lo, V hi, V lo
+  uint4 pk[4];                                         // PL: K rows 2 rp, 2 rp + 1, V rows: [hi4 | lo4] each
   const int ntiles = Ntok / 64;
   if (PL) PL_LOAD_KV(0);
   else LOAD_KV(0);
   for (int kt = 0; kt < ntiles; ++kt) {
     if (PL) {
-      pl_put_rows(Kh, rp, c0, pk[0], pk[1]);
-      pl_put_rows(Kl, rp, c0, pk[2], pk[3]);
-      pl_put_cols(Kth, rp, c0, pk[0], pk[1]);
-      if (!FAST) pl_put_cols(Ktl, rp, c0, pk[2], pk[3]);
-      pl_put_rows(Vh, rp, c0, pk[4], pk[5]);
-      pl_put_rows(Vl, rp, c0, pk[6], pk[7]);
+      pl_put_rows(Kh, rp, c0, pl_hi(pk[0]), pl_hi(pk[1]));
+      pl_put_rows(Kl, rp, c0, pl_lo(pk[0]), pl_lo(pk[1]));
+      pl_put_cols(Kth, rp, c0, pl_hi(pk[0]), pl_hi(pk[1]));
+      if (!FAST) pl_put_cols(Ktl, rp, c0, pl_lo(pk[0]), pl_lo(pk[1]));
+      pl_put_rows(Vh, rp, c0, pl_hi(pk[2]), pl_hi(pk[3]));
+      pl_put_rows(Vl, rp, c0, pl_lo(pk[2]), pl_lo(pk[3]));
     } else {
       put_rows(Kh, Kl, rp, c0, k0, k1);
       if (FAST) put_cols_hi(Kth, rp, c0, k0, k1);
@@ -1158,9 +1164,9 @@ int focr_attn_bwd_bx3(const float* q, const float* k, const float* v, const floa
 // ---------------------------------------------------------------------------------------------------------------
 // pre-split operand planes: producer for arbitrary fp32 inputs + the launchers of the PL kernel variants
 // ---------------------------------------------------------------------------------------------------------------
-// x [rows][ld] (128 columns used) -> hi plane [rows][128] bf16, lo plane `pls` elements behind; values multiplied by `mul`
+// x [rows][ld] (128 columns used) -> rows of 256 bf16, every 4 columns as [hi4 | lo4]; values multiplied by `mul`
 __global__ __launch_bounds__(256) void attn_make_planes_kernel(const float* __restrict__ x, __bf16* __restrict__ out,
-                                                               long rows, int ld, long pls, float mul) {
+                                                               long rows, int ld, float mul) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;          // one float4 each
   if (i >= rows * 32) return;
   const long r = i >> 5;
@@ -1175,18 +1181,17 @@ __global__ __launch_bounds__(256) void attn_make_planes_kernel(const float* __re
     h[e] = hh;
     l[e] = ll;
   }
-  *reinterpret_cast<bf16x4*>(out + r * 128 + c) = h;
-  *reinterpret_cast<bf16x4*>(out + pls + r * 128 + c) = l;
+  *reinterpret_cast<bf16x8*>(out + r * 256 + 2 * c) = cat44(h, l);
 }
 int focr_attn_make_planes(const float* x, void* planes, long rows, int ld, float mul, hipStream_t stream) {
   hipLaunchKernelGGL(attn_make_planes_kernel, dim3((unsigned)((rows * 32 + 255) / 256)), 256, 0, stream, x,
-                     reinterpret_cast<__bf16*>(planes), rows, ld, rows * 128, mul);
+                     reinterpret_cast<__bf16*>(planes), rows, ld, mul);
   return 0;
 }
-// qp / kp / vp (/ gp): hi planes [B * Ntok][128] bf16, lo planes rows * 128 elements behind.  Ntok % 256 == 0, H = 4.
+// qp / kp / vp (/ gp): [B * Ntok][256] bf16 split rows ([hi4 | lo4] per 4 columns).  Ntok % 256 == 0, H = 4.
 int focr_attn_fwd_bx3_planes(const void* qp, const void* kp, const void* vp, float* o, float* lse, const uint32_t* mask,
                              int B, int H, int Ntok, int ldo, float p_drop, hipStream_t stream) {
-  const long pls = (long)B * Ntok * 128;
+  const long pls = 0;
   const float* q = reinterpret_cast<const float*>(qp);
   const float* k = reinterpret_cast<const float*>(kp);
   const float* v = reinterpret_cast<const float*>(vp);
@@ -1202,7 +1207,7 @@ int focr_attn_fwd_bx3_planes(const void* qp, const void* kp, const void* vp, flo
 int focr_attn_bwd_bx3_planes(const void* qp, const void* kp, const void* vp, const void* gp, const float* lse,
                              const float* dwork, const uint32_t* mask, float* dq, float* dk, float* dv, int B, int H,
                              int Ntok, int ldg, float scale, float p_drop, hipStream_t stream) {
-  const long pls = (long)B * Ntok * 128;
+  const long pls = 0;
   const float* q = reinterpret_cast<const float*>(qp);
   const float* k = reinterpret_cast<const float*>(kp);
   const float* v = reinterpret_cast<const float*>(vp);

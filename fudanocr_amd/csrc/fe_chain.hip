@@ -110,9 +110,10 @@ __device__ __forceinline__ void fc_store_row(float* __restrict__ p, int lh, cons
       *reinterpret_cast<float4*>(p + 32 * j + 8 * g + 4 * lh) =
           make_float4(v[j][4 * g], v[j][4 * g + 1], v[j][4 * g + 2], v[j][4 * g + 3]);
 }
-// the row as bf16 hi / lo planes (x * mul = hi + lo; lo plane `pls` elements behind the hi plane)
+// the row pre-split for the attention kernels: 256 bf16 per row, every 4 columns as [hi4 | lo4] (x * mul = hi + lo): one
+// 16-byte store per register group, exactly like the fp32 row
 template <int NT>
-__device__ __forceinline__ void fc_store_planes(__bf16* __restrict__ p, long pls, int lh, const f32x16 (&v)[NT], float mul) {
+__device__ __forceinline__ void fc_store_planes(__bf16* __restrict__ p, int lh, const f32x16 (&v)[NT], float mul) {
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -125,8 +126,7 @@ __device__ __forceinline__ void fc_store_planes(__bf16* __restrict__ p, long pls
         h[e] = t;
         l[e] = (__bf16)(x - (float)t);
       }
-      *reinterpret_cast<fc_bf16x4*>(p + 32 * j + 8 * g + 4 * lh) = h;
-      *reinterpret_cast<fc_bf16x4*>(p + pls + 32 * j + 8 * g + 4 * lh) = l;
+      *reinterpret_cast<fc_bf16x8*>(p + 2 * (32 * j + 8 * g + 4 * lh)) = __builtin_shufflevector(h, l, 0, 1, 2, 3, 4, 5, 6, 7);
     }
 }
 // a vector over the columns (bias, LayerNorm a / b) from LDS, in the lane layout (two distinct addresses per read)
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(FC_THREADS, 1) void fe_bwd_b_kernel(
       for (int r = 0; r < 16; ++r) d[j][r] = 0.f;
     fc_gemm<4, 8, KP128>(Woth + z, Wotl + z, 0, li, lh, xh, xl, d);
     if (dctx) fc_store_row<4>(dctx + row * FC_D, lh, d);
-    if (dop) fc_store_planes<4>(dop + row * FC_D, pls, lh, d, gmul);     // dO / P(keep), pre-split for the attention backward
+    if (dop) fc_store_planes<4>(dop + row * 256, lh, d, gmul);           // dO / P(keep), pre-split for the attention backward
     if (Dw) {
       // D[b][head][token] = sum over the head's 32 columns of dO * O (the attention backward's row term): accumulator
       // tile j IS head j, so this is an in-lane sum + one exchange -- the separate prep pass over dO and O is gone
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void fe_qkv_fwd_kernel(const float* __restr
     fc_gemm<4, 8, KP128>(Wh + z, Wl + z, 0, li, lh, xh, xl, v);
     if (qkv) fc_store_row<4>(qkv + row * 384 + 128 * y, lh, v);
     // pre-split bf16 hi / lo planes of Q (x scale log2 e), K, V for the attention kernels' PL variants
-    if (planes) fc_store_planes<4>(planes + (size_t)(2 * y) * pls + row * FC_D, pls, lh, v, y == 0 ? qmul : 1.f);
+    if (planes) fc_store_planes<4>(planes + (size_t)y * pls + row * 256, lh, v, y == 0 ? qmul : 1.f);
   }
 }
 
@@ -777,7 +777,7 @@ extern "C" int focr_fe_post_bwd(const float* d_out, const float* wl, const float
                      d_s2, d_hpre, ntiles, eps, keep_scale);
   hipLaunchKernelGGL(fe_bwd_b_kernel, dim3(nb), FC_THREADS, FC_LDS_BWD_B, stream, (const float*)d_hpre,
                      (const float*)d_s2, w1, xhat1, rinv1, a1, wo, d_s1, d_ctx, ntiles, eps, ctx, dwork, ntok,
-                     reinterpret_cast<__bf16*>(d_ctx_planes), rows * FC_D, planes_mul);
+                     reinterpret_cast<__bf16*>(d_ctx_planes), 0L, planes_mul);
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }
@@ -799,7 +799,7 @@ extern "C" int focr_fe_qkv_fwd(const float* feat, const float* pe, const float* 
   int nb = (ntiles + 3) / 4;
   if (nb > 171) nb = 171;                   // x 3 column groups = 513 blocks: one round at two blocks per CU
   hipLaunchKernelGGL(fe_qkv_fwd_kernel, dim3(nb, 3), 256, FC_LDS_QKV_FWD, stream, feat, pe, wqkv, bqkv, tok, qkv, ntiles,
-                     ntok, reinterpret_cast<__bf16*>(planes), rows * FC_D, q_mul);
+                     ntok, reinterpret_cast<__bf16*>(planes), rows * 256, q_mul);
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }

@@ -1023,8 +1023,8 @@ def _fe_forward(step, feat, xres, pe, heads, p_attn, p_ffn, eps, params):
     mask, ready = step.next_mask(b, heads, t, p_attn, dev) if p_attn > 0 else (None, False)
     scale = 1.0 / math.sqrt(d // heads)
     if _ATTN_PLANES and _lib.load().focr_attention_planes_supported(heads, t, d):
-        # the projection writes Q * scale * log2(e), K, V ALREADY split into bf16 hi / lo planes ([3][2][rows][128], the
-        # bytes of the fp32 tensor): the attention kernels stage them by plain copies (csrc/attention_bx3.hip PL variants)
+        # the projection writes Q * scale * log2(e), K, V ALREADY split to bf16 hi / lo ([3][rows][256]: every 4 columns as
+        # [hi4 | lo4], the bytes of the fp32 tensor): the attention kernels stage them by plain copies (attention_bx3.hip)
         qkv = torch.empty((3, 2, rows, d), device=dev, dtype=torch.bfloat16)
         _lib.call("focr_fe_qkv_fwd", _p(feat), _p(pe), _p(wqkv), _p(bqkv), _p(tok), _NULL, rows, t, _p(qkv),
                   scale * _LOG2E, _stream())

@@ -154,8 +154,9 @@ int focr_attention_fwd_premasked(const float* q, const float* k, const float* v,
                                  const uint32_t* mask, int B, int H, int Ntok, int ld, int ldo, float scale,
                                  float p_drop, focr_stream_t stream);
 /* dwork: B*H*Ntok floats */
-/* ---- attention on pre-split operand planes (csrc/attention_bx3.hip PL variants): a plane set of a [rows][128] tensor is
- * the bf16 hi plane followed by the lo plane (x = hi + lo, 2 * rows * 128 elements).  Q planes hold Q * scale * log2(e),
+/* ---- attention on pre-split operands (csrc/attention_bx3.hip PL variants): the split form of a [rows][128] fp32 tensor
+ * is [rows][256] bf16 in which every group of four columns is stored as [hi x 4 | lo x 4] (x = hi + lo; the bytes of
+ * the fp32 row, so producers and consumers move 16 bytes per lane exactly as with fp32).  Q planes hold Q * scale * log2(e),
  * dO planes dO * focr_attention_keep_scale(p_drop); the kernels then stage their tiles by plain copies -- the fp32 ->
  * bf16 split is done once by the producer (focr_fe_qkv_fwd / focr_fe_post_bwd, or focr_attention_make_planes for any
  * fp32 tensor) instead of by every consumer block.  4 heads of 32, Ntok % 256 == 0, precision mode != 0.
@@ -238,9 +239,9 @@ int focr_slice_cols(const float* x, const float* add, float* out, long rows, int
  *                      With dwork != NULL it also writes D[b][head][token] = sum_d d_ctx * ctx (ntok tokens per image),
  *                      the row term of the attention backward: focr_attention_bwd is then called with o = NULL.
  *   focr_fe_qkv_fwd  : tok = [feat | pe[row % ntok]] (tbsrn.py:83-86) and the packed q | k | v projection in one kernel.
- *                      planes != NULL: Q * q_mul, K, V are (also, or with qkv = NULL: only) written as pre-split bf16
- *                      planes [3 tensors][hi, lo][rows][128] for focr_attention_planes_*; focr_fe_post_bwd's d_ctx_planes
- *                      likewise receives d_ctx * planes_mul as [hi, lo][rows][128] (d_ctx itself may then be NULL).
+ *                      planes != NULL: Q * q_mul, K, V are (also, or with qkv = NULL: only) written pre-split as
+ *                      [3 tensors][rows][256] bf16 for focr_attention_planes_* (layout there); focr_fe_post_bwd's
+ *                      d_ctx_planes likewise receives d_ctx * planes_mul as [rows][256] (d_ctx itself may then be NULL).
  *   focr_fe_qkv_dgrad: d_feat[rows,64] = dqkv[rows,384] Wqkv[:, 0:64] + d_s1[:, 0:64] (the positional-encoding half of
  *                      the token, tbsrn.py:83-86, has no gradient consumer).
  *   focr_fe_wgrads   : every parameter gradient of these layers in one call (targets are overwritten); the LayerNorm
