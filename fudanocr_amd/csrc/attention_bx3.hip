@@ -270,6 +270,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __re
   const int H = nheads, h = bh_ % nheads, b = bh_ / nheads;
   const size_t base = (size_t)b * Ntok * ld + h * 32;
   const size_t baseo = (size_t)b * Ntok * ldo + h * 32;
+  const size_t pbase = (size_t)b * Ntok * ld + h * 64;      // PL: ld = row pitch of the split rows in bf16 elements
   const int q0 = qb_ * 256 + wave * 64 + li;                 // tile t: query q0 + 32 t
 
   bf16x8 qh[2][2], ql[2][2];
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __re
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       if (PL) {
-        pl_frag(Qp + 2 * base + (size_t)(q0 + 32 * t) * 256 + PLC(16 * m + 8 * lh), qh[t][m], ql[t][m]);
+        pl_frag(Qp + pbase + (size_t)(q0 + 32 * t) * ld + PLC(16 * m + 8 * lh), qh[t][m], ql[t][m]);
       } else {
         row_frag(Q + base + (size_t)(q0 + 32 * t) * ld + 16 * m + 8 * lh, scale * LOG2E, qh[t][m], ql[t][m]);
       }
@@ -300,9 +301,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __re
   uint4 pk[4];                                         // PL: K rows 2 rp, 2 rp + 1, V rows: [hi4 | lo4] each
 #define PL_LOAD_KV(kt)                                                                \
   do {                                                                                \
-    const size_t o0_ = 2 * base + (size_t)((kt) * 64 + 2 * rp) * 256 + PLC(c0);      \
-    pk[0] = pl_ld(Kp + o0_); pk[1] = pl_ld(Kp + o0_ + 256);                           \
-    pk[2] = pl_ld(Vp + o0_); pk[3] = pl_ld(Vp + o0_ + 256);                           \
+    const size_t o0_ = pbase + (size_t)((kt) * 64 + 2 * rp) * ld + PLC(c0);          \
+    pk[0] = pl_ld(Kp + o0_); pk[1] = pl_ld(Kp + o0_ + ld);                            \
+    pk[2] = pl_ld(Vp + o0_); pk[3] = pl_ld(Vp + o0_ + ld);                            \
   } while (0)
   const int ntiles = Ntok / 64;
   if (PL) PL_LOAD_KV(0);
@@ -687,6 +688,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
   const size_t base = (size_t)b * Ntok * ld + h * 32;
   const size_t baseo = (size_t)b * Ntok * ldo + h * 32;
   const size_t sbase = (size_t)(b * H + h) * Ntok;
+  const size_t pbase = (size_t)b * Ntok * ld + h * 64;      // PL: ld / ldo = row pitches of the split Q|K|V / dO rows
+  const size_t pgbase = (size_t)b * Ntok * ldo + h * 64;
   const int key = qb_ * 128 + wave * 32 + li;
 
   const float inv_keep = DROPOUT ? 1.f / (1.f - (float)attn_drop_thr16(p_drop) / 65536.f) : 1.f;
@@ -694,7 +697,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
     if (PL) {        // the dropout scale rides on the dO planes
-      const size_t o_ = 2 * base + (size_t)key * 256 + PLC(16 * m + 8 * lh);
+      const size_t o_ = pbase + (size_t)key * ld + PLC(16 * m + 8 * lh);
       pl_frag(Kp + o_, kh[m], kl[m]);
       pl_frag(Vp + o_, vh[m], vl[m]);
     } else {
@@ -733,9 +736,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
   uint4 pq[4];                                          // PL: Q rows 2 rp, 2 rp + 1, dO rows: [hi4 | lo4] each
 #define PL_LOAD_QG(qt)                                                                \
   do {                                                                                \
-    const size_t o0_ = 2 * base + (size_t)((qt) * 64 + 2 * rp) * 256 + PLC(c0);      \
-    pq[0] = pl_ld(Qp + o0_); pq[1] = pl_ld(Qp + o0_ + 256);                           \
-    pq[2] = pl_ld(Gp + o0_); pq[3] = pl_ld(Gp + o0_ + 256);                           \
+    const size_t o0_ = pbase + (size_t)((qt) * 64 + 2 * rp) * ld + PLC(c0);          \
+    const size_t g0_ = pgbase + (size_t)((qt) * 64 + 2 * rp) * ldo + PLC(c0);        \
+    pq[0] = pl_ld(Qp + o0_); pq[1] = pl_ld(Qp + o0_ + ld);                            \
+    pq[2] = pl_ld(Gp + g0_); pq[3] = pl_ld(Gp + g0_ + ldo);                           \
     if (tid < 64) {                                                                   \
       lreg = LSE[sbase + (qt) * 64 + tid];                                            \
       dreg = Dv[sbase + (qt) * 64 + tid];                                             \
@@ -971,6 +975,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_bx3_kernel(
   const size_t base = (size_t)b * Ntok * ld + h * 32;
   const size_t baseo = (size_t)b * Ntok * ldo + h * 32;
   const size_t sbase = (size_t)(b * H + h) * Ntok;
+  const size_t pbase = (size_t)b * Ntok * ld + h * 64;      // PL: ld / ldo = row pitches of the split Q|K|V / dO rows
+  const size_t pgbase = (size_t)b * Ntok * ldo + h * 64;
   const int q0 = qb_ * 256 + wave * 64 + li;                 // tile t: query q0 + 32 t
   const float inv_keep = DROPOUT ? 1.f / (1.f - (float)attn_drop_thr16(p_drop) / 65536.f) : 1.f;
 
@@ -983,9 +989,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_bx3_kernel(
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       if (PL) {
-        const size_t o_ = 2 * base + (size_t)q * 256 + PLC(16 * m + 8 * lh);
-        pl_frag(Qp + o_, qh[t][m], ql[t][m]);
-        pl_frag(Gp + o_, gh[t][m], gl[t][m]);
+        pl_frag(Qp + pbase + (size_t)q * ld + PLC(16 * m + 8 * lh), qh[t][m], ql[t][m]);
+        pl_frag(Gp + pgbase + (size_t)q * ldo + PLC(16 * m + 8 * lh), gh[t][m], gl[t][m]);
       } else {
         row_frag(Q + base + (size_t)q * ld + 16 * m + 8 * lh, scale * LOG2E, qh[t][m], ql[t][m]);
         // dO carries the dropout scale 1/(1-p) (dP' = V dO'^T); D was computed from the unscaled dO by the prep kernel
@@ -1190,23 +1195,23 @@ int focr_attn_make_planes(const float* x, void* planes, long rows, int ld, float
 }
 // qp / kp / vp (/ gp): [B * Ntok][256] bf16 split rows ([hi4 | lo4] per 4 columns).  Ntok % 256 == 0, H = 4.
 int focr_attn_fwd_bx3_planes(const void* qp, const void* kp, const void* vp, float* o, float* lse, const uint32_t* mask,
-                             int B, int H, int Ntok, int ldo, float p_drop, hipStream_t stream) {
+                             int B, int H, int Ntok, int ldp, int ldo, float p_drop, hipStream_t stream) {
   const long pls = 0;
   const float* q = reinterpret_cast<const float*>(qp);
   const float* k = reinterpret_cast<const float*>(kp);
   const float* v = reinterpret_cast<const float*>(vp);
   dim3 grid2(B * H * (Ntok / 256));
   if (p_drop > 0.f)
-    hipLaunchKernelGGL((attn_fwd2_bx3_kernel<true, true>), grid2, 256, 0, stream, q, k, v, o, lse, mask, Ntok, 128, ldo,
+    hipLaunchKernelGGL((attn_fwd2_bx3_kernel<true, true>), grid2, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ldp, ldo,
                        1.f, p_drop, (uint64_t)0, H, pls);
   else
-    hipLaunchKernelGGL((attn_fwd2_bx3_kernel<false, true>), grid2, 256, 0, stream, q, k, v, o, lse, mask, Ntok, 128, ldo,
+    hipLaunchKernelGGL((attn_fwd2_bx3_kernel<false, true>), grid2, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ldp, ldo,
                        1.f, p_drop, (uint64_t)0, H, pls);
   return 0;
 }
 int focr_attn_bwd_bx3_planes(const void* qp, const void* kp, const void* vp, const void* gp, const float* lse,
                              const float* dwork, const uint32_t* mask, float* dq, float* dk, float* dv, int B, int H,
-                             int Ntok, int ldg, float scale, float p_drop, hipStream_t stream) {
+                             int Ntok, int ldp, int ldgp, int ldg, float scale, float p_drop, hipStream_t stream) {
   const long pls = 0;
   const float* q = reinterpret_cast<const float*>(qp);
   const float* k = reinterpret_cast<const float*>(kp);
@@ -1216,9 +1221,9 @@ int focr_attn_bwd_bx3_planes(const void* qp, const void* kp, const void* vp, con
 #define LAUNCH_BWD_PL(DR, FA)                                                                                      \
   do {                                                                                                             \
     hipLaunchKernelGGL((attn_bwd_dkv_bx3_kernel<DR, FA, true>), dim3(B * H * (Ntok / 128)), 256, 0, stream, q, k, v, g, \
-                       lse, dwork, dk, dv, mask, Ntok, 128, 128, scale, p_drop, H, pls, ldg);                      \
+                       lse, dwork, dk, dv, mask, Ntok, ldp, ldgp, scale, p_drop, H, pls, ldg);                     \
     hipLaunchKernelGGL((attn_bwd_dq2_bx3_kernel<DR, FA, true>), dim3(B * H * (Ntok / 256)), 256, 0, stream, q, k, v, g, \
-                       lse, dwork, dq, mask, Ntok, 128, 128, scale, p_drop, H, pls, ldg);                          \
+                       lse, dwork, dq, mask, Ntok, ldp, ldgp, scale, p_drop, H, pls, ldg);                         \
   } while (0)
   if (p_drop > 0.f) {
     if (fast) LAUNCH_BWD_PL(true, true);

@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void fe_qkv_fwd_kernel(const float* __restr
     fc_gemm<4, 8, KP128>(Wh + z, Wl + z, 0, li, lh, xh, xl, v);
     if (qkv) fc_store_row<4>(qkv + row * 384 + 128 * y, lh, v);
     // pre-split bf16 hi / lo planes of Q (x scale log2 e), K, V for the attention kernels' PL variants
-    if (planes) fc_store_planes<4>(planes + (size_t)y * pls + row * 256, lh, v, y == 0 ? qmul : 1.f);
+    if (planes) fc_store_planes<4>(planes + row * 768 + 256 * y, lh, v, y == 0 ? qmul : 1.f);   // packed [rows][Q | K | V]
   }
 }
 

@@ -1025,12 +1025,12 @@ def _fe_forward(step, feat, xres, pe, heads, p_attn, p_ffn, eps, params):
     if _ATTN_PLANES and _lib.load().focr_attention_planes_supported(heads, t, d):
         # the projection writes Q * scale * log2(e), K, V ALREADY split to bf16 hi / lo ([3][rows][256]: every 4 columns as
         # [hi4 | lo4], the bytes of the fp32 tensor): the attention kernels stage them by plain copies (attention_bx3.hip)
-        qkv = torch.empty((3, 2, rows, d), device=dev, dtype=torch.bfloat16)
+        qkv = torch.empty((rows, 6 * d), device=dev, dtype=torch.bfloat16)       # [rows][Q | K | V], 256 bf16 each
         _lib.call("focr_fe_qkv_fwd", _p(feat), _p(pe), _p(wqkv), _p(bqkv), _p(tok), _NULL, rows, t, _p(qkv),
                   scale * _LOG2E, _stream())
-        pq, pk, pv = (ctypes.c_void_p(qkv.data_ptr() + i * 2 * rows * d * 2) for i in range(3))
-        _lib.call("focr_attention_planes_fwd", pq, pk, pv, _p(o), _p(lse), _p(mask), b, heads, t, d, float(p_attn),
-                  _new_seed() if (p_attn > 0 and not ready) else 0, int(ready), _stream())
+        pq, pk, pv = (ctypes.c_void_p(qkv.data_ptr() + i * 2 * d * 2) for i in range(3))
+        _lib.call("focr_attention_planes_fwd", pq, pk, pv, _p(o), _p(lse), _p(mask), b, heads, t, 6 * d, d,
+                  float(p_attn), _new_seed() if (p_attn > 0 and not ready) else 0, int(ready), _stream())
     else:
         qkv = torch.empty((b, t, 3 * d), device=dev)
         _lib.call("focr_fe_qkv_fwd", _p(feat), _p(pe), _p(wqkv), _p(bqkv), _p(tok), _p(qkv), rows, t, _NULL, 1.0,
@@ -1116,9 +1116,9 @@ def _fe_backward(step, saved, cfg, params, targets, d_out, need_dfeat, need_para
     dqkv = torch.empty((b, t, 3 * d), device=dev)
     # `work` already holds D = rowsum(d_ctx * o) per (b, head, token), written by the chain kernel above
     if planes:
-        pq, pk, pv = (ctypes.c_void_p(qkv.data_ptr() + i * 2 * rows * d * 2) for i in range(3))
+        pq, pk, pv = (ctypes.c_void_p(qkv.data_ptr() + i * 2 * d * 2) for i in range(3))
         _lib.call("focr_attention_planes_bwd", pq, pk, pv, _p(d_ctx), _p(lse), _p(work), _p(mask), _po(dqkv, 0),
-                  _po(dqkv, d), _po(dqkv, 2 * d), b, heads, t, 3 * d, scale, p_attn, _stream())
+                  _po(dqkv, d), _po(dqkv, 2 * d), b, heads, t, 6 * d, 2 * d, 3 * d, scale, p_attn, _stream())
     else:
         _lib.call("focr_attention_bwd", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _NULL, _p(d_ctx), _p(lse), _p(mask),
                   _po(dqkv, 0), _po(dqkv, d), _po(dqkv, 2 * d), _p(work), b, heads, t, 3 * d, d, scale, p_attn,

@@ -160,16 +160,18 @@ int focr_attention_fwd_premasked(const float* q, const float* k, const float* v,
  * dO planes dO * focr_attention_keep_scale(p_drop); the kernels then stage their tiles by plain copies -- the fp32 ->
  * bf16 split is done once by the producer (focr_fe_qkv_fwd / focr_fe_post_bwd, or focr_attention_make_planes for any
  * fp32 tensor) instead of by every consumer block.  4 heads of 32, Ntok % 256 == 0, precision mode != 0.
+ * ldp / ldop: row pitch (bf16 elements) of the split Q | K | V rows / of the split dO rows: 256 for separate tensors,
+ * 768 for the packed [rows][Q | K | V] form focr_fe_qkv_fwd writes.
  * focr_attention_planes_bwd: dwork = D = rowsum(dO * O) from the UNSCALED dO; dq / dk / dv fp32 with row pitch ldg. */
 int focr_attention_planes_supported(int H, int Ntok, int d_model);
 float focr_attention_keep_scale(float p_drop);
 int focr_attention_make_planes(const float* x, void* planes, long rows, int ld, float mul, focr_stream_t stream);
 int focr_attention_planes_fwd(const void* qp, const void* kp, const void* vp, float* o, float* lse, uint32_t* mask,
-                              int B, int H, int Ntok, int ldo, float p_drop, uint64_t seed, int mask_ready,
+                              int B, int H, int Ntok, int ldp, int ldo, float p_drop, uint64_t seed, int mask_ready,
                               focr_stream_t stream);
 int focr_attention_planes_bwd(const void* qp, const void* kp, const void* vp, const void* dop, const float* lse,
                               const float* dwork, const uint32_t* mask, float* dq, float* dk, float* dv, int B, int H,
-                              int Ntok, int ldg, float scale, float p_drop, focr_stream_t stream);
+                              int Ntok, int ldp, int ldop, int ldg, float scale, float p_drop, focr_stream_t stream);
 /* o == NULL: dwork already holds D = rowsum(d_o * o) per (b, head, token) (see focr_fe_post_bwd) */
 int focr_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o,
                        const float* lse, const uint32_t* mask, float* dq, float* dk, float* dv,

@@ -95,20 +95,20 @@ int main(int argc, char** argv) {
       float tmk = timeit([&]() { focr_attention_make_planes(q, qp, rows, D, scale * LOG2E, 0); });
       g_tune[FOCR_TUNE_ATTN_FWD_VARIANT] = 1;
       focr_attention_fwd(q, k, v, o0, lse0, mask, B, H, N, D, D, scale, p, 1234, 0);
-      int rc = focr_attention_planes_fwd(qp, kp, vp, o1, lse1, mask, B, H, N, D, p, 1234, 1, 0);
+      int rc = focr_attention_planes_fwd(qp, kp, vp, o1, lse1, mask, B, H, N, 256, D, p, 1234, 1, 0);
       if (rc) { printf("planes fwd failed %d\n", rc); return 1; }
       float f0 = timeit([&]() { focr_attention_fwd_premasked(q, k, v, o0, lse0, mask, B, H, N, D, D, scale, p > 0 ? p : 0.1f, 0); }, 8);
       if (p == 0.f) f0 = timeit([&]() { focr_attention_fwd(q, k, v, o0, lse0, mask, B, H, N, D, D, scale, 0.f, 1234, 0); }, 8);
-      float f1 = timeit([&]() { focr_attention_planes_fwd(qp, kp, vp, o1, lse1, mask, B, H, N, D, p, 1234, 1, 0); }, 8);
+      float f1 = timeit([&]() { focr_attention_planes_fwd(qp, kp, vp, o1, lse1, mask, B, H, N, 256, D, p, 1234, 1, 0); }, 8);
       CK(hipDeviceSynchronize());
       double mxo, eo = maxdiff(o0, o1, n, &mxo), mxl, el = maxdiff(lse0, lse1, (long)B * H * N, &mxl);
       // backward: D from the reference path's prep (work), same keep bits
       g_tune[FOCR_TUNE_ATTN_BWD_DQ_VARIANT] = 1;
       focr_attention_bwd(q, k, v, o0, dO, lse0, mask, dq0, dk0, dv0, work, B, H, N, D, D, scale, p, 0);
-      rc = focr_attention_planes_bwd(qp, kp, vp, gp, lse0, work, mask, dq1, dk1, dv1, B, H, N, D, scale, p, 0);
+      rc = focr_attention_planes_bwd(qp, kp, vp, gp, lse0, work, mask, dq1, dk1, dv1, B, H, N, 256, 256, D, scale, p, 0);
       if (rc) { printf("planes bwd failed %d\n", rc); return 1; }
       float bb0 = timeit([&]() { focr_attention_bwd(q, k, v, nullptr, dO, lse0, mask, dq0, dk0, dv0, work, B, H, N, D, D, scale, p, 0); }, 8);
-      float bb1 = timeit([&]() { focr_attention_planes_bwd(qp, kp, vp, gp, lse0, work, mask, dq1, dk1, dv1, B, H, N, D, scale, p, 0); }, 8);
+      float bb1 = timeit([&]() { focr_attention_planes_bwd(qp, kp, vp, gp, lse0, work, mask, dq1, dk1, dv1, B, H, N, 256, 256, D, scale, p, 0); }, 8);
       CK(hipDeviceSynchronize());
       double a1, a2, a3;
       double dq_e = maxdiff(dq0, dq1, n, &a1), dk_e = maxdiff(dk0, dk1, n, &a2), dv_e = maxdiff(dv0, dv1, n, &a3);
