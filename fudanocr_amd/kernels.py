@@ -997,8 +997,12 @@ def fe_chain_supported(feat):
                 and _lib.load().focr_fe_chain_supported(feat.shape[0] * feat.shape[1], 128))
 
 
-# FOCR_ATTN_PLANES=0: fp32 q | k | v between the projection and the attention kernels (each block splits its tiles itself)
-_ATTN_PLANES = os.environ.get("FOCR_ATTN_PLANES", "1") != "0"
+# FOCR_ATTN_PLANES=1: the QKV projection / the backward chain hand the attention kernels PRE-SPLIT operands (bf16 hi / lo,
+# same bytes) and the kernels stage tiles by plain copies (csrc/attention_bx3.hip PL variants).  Standalone the kernels
+# gain (forward 310 -> 292 us, backward 682 -> 636 us on separate arrays, profiles/r03_attention_planes.md); inside the
+# step the forward is bound by the latency of its keep-bit scalar loads, which the longer fp32 staging phase happens to
+# cover: split forward +25 us, backward -12 us per block, step +0.1 ms.  Off by default, kept tested behind the switch.
+_ATTN_PLANES = os.environ.get("FOCR_ATTN_PLANES", "0") == "1"
 _LOG2E = 1.4426950408889634
 # FOCR_DEFER_SIDE=1: park the convolution / QKV weight gradients of a residual block and issue them beside the NEXT
 # block's attention backward.  Measured (same box, interleaved): 15.32 ms vs 15.13 ms without -- the attention kernels lose

@@ -1,0 +1,3 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+timeout 300 build/attn_ubench 128 2>&1 | grep -E "PLANES|PACKED|bwd \(no" | tee gpurun_out/c15_attn.log

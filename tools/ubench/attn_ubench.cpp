@@ -116,6 +116,27 @@ int main(int argc, char** argv) {
              "              bwd (no prep) fp32-in %7.1f us  planes %7.1f us  max diff dq %.2e/%.2e dk %.2e/%.2e dv %.2e/%.2e\n",
              p, f0, f1, tmk, eo, mxo, el, bb0, bb1, dq_e, a1, dk_e, a2, dv_e, a3);
       fflush(stdout);
+      // the same two forwards on the PACKED layouts the training step uses: fp32 [rows][q | k | v] (pitch 384 floats),
+      // split rows [rows][Q | K | V] (pitch 768 bf16)
+      static float* qkv3 = nullptr; static void* qkvp3 = nullptr;
+      if (!qkv3) { CK(hipMalloc(&qkv3, rows * 384 * 4)); CK(hipMalloc(&qkvp3, rows * 768 * 2)); }
+      CK(hipMemcpy2D(qkv3, 384 * 4, q, 128 * 4, 128 * 4, rows, hipMemcpyDeviceToDevice));
+      CK(hipMemcpy2D(qkv3 + 128, 384 * 4, k, 128 * 4, 128 * 4, rows, hipMemcpyDeviceToDevice));
+      CK(hipMemcpy2D(qkv3 + 256, 384 * 4, v, 128 * 4, 128 * 4, rows, hipMemcpyDeviceToDevice));
+      CK(hipMemcpy2D(qkvp3, 1536, qp, 512, 512, rows, hipMemcpyDeviceToDevice));
+      CK(hipMemcpy2D((char*)qkvp3 + 512, 1536, kp, 512, 512, rows, hipMemcpyDeviceToDevice));
+      CK(hipMemcpy2D((char*)qkvp3 + 1024, 1536, vp, 512, 512, rows, hipMemcpyDeviceToDevice));
+      const float pp = p > 0 ? p : 0.f;
+      auto fpk = [&]() { if (pp > 0) focr_attention_fwd_premasked(qkv3, qkv3 + 128, qkv3 + 256, o0, lse0, mask, B, H, N, 384, D, scale, pp, 0);
+                         else focr_attention_fwd(qkv3, qkv3 + 128, qkv3 + 256, o0, lse0, mask, B, H, N, 384, D, scale, 0.f, 1, 0); };
+      auto ppk = [&]() { focr_attention_planes_fwd(qkvp3, (char*)qkvp3 + 512, (char*)qkvp3 + 1024, o1, lse1, mask, B, H, N, 768, D, pp, 1, 1, 0); };
+      fpk(); ppk();
+      float g0 = 1e9f, g1 = 1e9f;
+      for (int rep = 0; rep < 3; ++rep) { g0 = std::min(g0, timeit(fpk, 6)); g1 = std::min(g1, timeit(ppk, 6)); }
+      CK(hipDeviceSynchronize());
+      double mq, eq2 = maxdiff(o0, o1, n, &mq);
+      printf("PACKED p=%.1f: fwd fp32 packed %7.1f us  split packed %7.1f us  max|dO| %.2e\n", p, g0, g1, eq2);
+      fflush(stdout);
     }
   }
   return 0;
