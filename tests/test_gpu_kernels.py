@@ -982,13 +982,17 @@ def _fe_reference(feat, xres, pe, P, heads=4, eps=1e-6):
     return out + xres if xres is not None else out
 
 
+@pytest.mark.parametrize("planes", [False, True], ids=["fp32-qkv", "split-qkv"])
 @pytest.mark.parametrize("b,with_res", [(2, True), (1, False)])
-def test_feature_enhancer_fused_chain(b, with_res, precision):
+def test_feature_enhancer_fused_chain(b, with_res, planes, precision, monkeypatch):
     """csrc/fe_chain.hip through kernels.feature_enhancer_fused: output, input gradients and ALL 14 parameter gradients
-    (incl. the LayerNorm a_2 / b_2 gradients that come out of the weight-gradient GEMMs on xhat) vs float64"""
+    (incl. the LayerNorm a_2 / b_2 gradients that come out of the weight-gradient GEMMs on xhat) vs float64.
+    split-qkv: the projection / backward chain hand the attention kernels pre-split bf16 hi / lo operands
+    (focr_attention_planes_*, the PL kernel variants) instead of fp32 -- same tolerances."""
     k = K()
     if precision == 0:
         pytest.skip("the fused chains are bf16x3 kernels; mode 0 keeps the per-layer fp32 path")
+    monkeypatch.setattr(k, "_ATTN_PLANES", bool(planes))
     t = 1024
     feat = rnd(b, t, 64, seed=1)
     xres = rnd(b, t, 64, seed=2) if with_res else None
@@ -1053,3 +1057,46 @@ def test_feature_enhancer_fused_dropout_statistics():
     assert abs(dropped - 0.25) < 0.01, dropped
     kept = pos & (h1 != 0)
     assert torch.allclose(h1[kept], h0[kept] * ks, rtol=1e-5, atol=1e-6)
+
+
+def test_attention_planes_c_abi(precision):
+    """focr_attention_make_planes + focr_attention_planes_fwd / _bwd against the fp32-input entry points on the same
+    keep bits: forward and dQ identical (the split is the same arithmetic), dK / dV equal up to where the dropout scale
+    is applied (bf16-level in modes 2 / 3)"""
+    import ctypes
+    from fudanocr_amd import _lib
+    if precision == 0:
+        pytest.skip("the PL kernel variants are bf16x3 kernels")
+    lib = _lib.load()
+    b, h, t, d = 2, 4, 1024, 128
+    rows = b * t
+    assert lib.focr_attention_planes_supported(h, t, d) == 1 and lib.focr_attention_planes_supported(h, 1000, d) == 0
+    q, kk, v, do = (dev(rnd(b, t, d, seed=i, scale=s_)) for i, s_ in ((1, 2.0), (2, 2.0), (3, 1.0), (4, 1.0)))
+    P_ = lambda x: ctypes.c_void_p(x.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    scale, p = 1.0 / math.sqrt(32), 0.1
+    o0, o1 = torch.empty_like(q), torch.empty_like(q)
+    lse0, lse1 = torch.empty(b, h, t, device="cuda"), torch.empty(b, h, t, device="cuda")
+    mask = torch.empty((b, h, t // 32, t // 32, 32), device="cuda", dtype=torch.int32)
+    _lib.call("focr_attention_fwd", P_(q), P_(kk), P_(v), P_(o0), P_(lse0), P_(mask), b, h, t, d, d, scale, p, 77, st)
+    planes = [torch.empty((rows, 2 * d), device="cuda", dtype=torch.bfloat16) for _ in range(4)]
+    ik = lib.focr_attention_keep_scale(p)
+    assert abs(ik - 1.0 / (1.0 - round(p * 4096) / 4096.0)) < 1e-6
+    for x, pl, mul in ((q, planes[0], scale * 1.4426950408889634), (kk, planes[1], 1.0), (v, planes[2], 1.0), (do, planes[3], ik)):
+        _lib.call("focr_attention_make_planes", P_(x), P_(pl), rows, d, float(mul), st)
+    _lib.call("focr_attention_planes_fwd", P_(planes[0]), P_(planes[1]), P_(planes[2]), P_(o1), P_(lse1), P_(mask), b, h, t,
+              2 * d, d, p, 0, 1, st)
+    torch.cuda.synchronize()
+    close(o1, o0, 1e-6, "planes forward o")
+    close(lse1, lse0, 1e-6, "planes forward lse")
+    work = torch.empty(b, h, t, device="cuda")
+    g0 = [torch.empty_like(q) for _ in range(3)]
+    g1 = [torch.empty_like(q) for _ in range(3)]
+    _lib.call("focr_attention_bwd", P_(q), P_(kk), P_(v), P_(o0), P_(do), P_(lse0), P_(mask), P_(g0[0]), P_(g0[1]), P_(g0[2]),
+              P_(work), b, h, t, d, d, scale, p, st)
+    _lib.call("focr_attention_planes_bwd", P_(planes[0]), P_(planes[1]), P_(planes[2]), P_(planes[3]), P_(lse0), P_(work),
+              P_(mask), P_(g1[0]), P_(g1[1]), P_(g1[2]), b, h, t, 2 * d, 2 * d, d, scale, p, st)
+    torch.cuda.synchronize()
+    close(g1[0], g0[0], 1e-6, "planes dq")
+    close(g1[1], g0[1], gtol(precision), "planes dk")
+    close(g1[2], g0[2], max(gtol(precision), 5e-3) if precision >= 2 else 1e-5, "planes dv")

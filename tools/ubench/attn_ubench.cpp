@@ -136,6 +136,16 @@ int main(int argc, char** argv) {
       CK(hipDeviceSynchronize());
       double mq, eq2 = maxdiff(o0, o1, n, &mq);
       printf("PACKED p=%.1f: fwd fp32 packed %7.1f us  split packed %7.1f us  max|dO| %.2e\n", p, g0, g1, eq2);
+      // backward on the packed fp32 layout, dO / O rows at pitch 128 floats vs embedded in a pitch-384 buffer
+      static float *dq3 = nullptr, *do3 = nullptr;
+      if (!dq3) { CK(hipMalloc(&dq3, rows * 384 * 4)); CK(hipMalloc(&do3, rows * 384 * 4)); }
+      CK(hipMemcpy2D(do3, 384 * 4, dO, 128 * 4, 128 * 4, rows, hipMemcpyDeviceToDevice));
+      auto b128 = [&]() { focr_attention_bwd(qkv3, qkv3 + 128, qkv3 + 256, nullptr, dO, lse0, mask, dq3, dq3 + 128, dq3 + 256, work, B, H, N, 384, 128, scale, pp, 0); };
+      auto b384 = [&]() { focr_attention_bwd(qkv3, qkv3 + 128, qkv3 + 256, nullptr, do3, lse0, mask, dq3, dq3 + 128, dq3 + 256, work, B, H, N, 384, 384, scale, pp, 0); };
+      b128(); b384();
+      float h0 = 1e9f, h1 = 1e9f;
+      for (int rep = 0; rep < 3; ++rep) { h0 = std::min(h0, timeit(b128, 6)); h1 = std::min(h1, timeit(b384, 6)); }
+      printf("PACKED p=%.1f: bwd (q k v dq dk dv packed) dO pitch 128: %7.1f us   dO pitch 384: %7.1f us\n", p, h0, h1);
       fflush(stdout);
     }
   }
