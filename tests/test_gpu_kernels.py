@@ -1099,4 +1099,4 @@ def test_attention_planes_c_abi(precision):
     torch.cuda.synchronize()
     close(g1[0], g0[0], 1e-6, "planes dq")
     close(g1[1], g0[1], gtol(precision), "planes dk")
-    close(g1[2], g0[2], max(gtol(precision), 5e-3) if precision >= 2 else 1e-5, "planes dv")
+    close(g1[2], g0[2], 5e-3 if precision >= 2 else 1e-4, "planes dv")
