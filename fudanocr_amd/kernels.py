@@ -1004,6 +1004,8 @@ def fe_chain_supported(feat):
 # cover: split forward +25 us, backward -12 us per block, step +0.1 ms.  Off by default, kept tested behind the switch.
 _ATTN_PLANES = os.environ.get("FOCR_ATTN_PLANES", "0") == "1"
 _LOG2E = 1.4426950408889634
+# FOCR_DGRAD_FIRST=0: enqueue a convolution's weight gradient (side stream) before its data gradient (main stream)
+_DGRAD_FIRST = os.environ.get("FOCR_DGRAD_FIRST", "1") != "0"
 # FOCR_DEFER_SIDE=1: park the convolution / QKV weight gradients of a residual block and issue them beside the NEXT
 # block's attention backward.  Measured (same box, interleaved): 15.32 ms vs 15.13 ms without -- the attention kernels lose
 # more to the extra company than the HBM-bound kernels gain; off by default, kept as an A/B switch.
@@ -1281,17 +1283,31 @@ class _SRBFused(torch.autograd.Function):
                 grads[4 * i + 2] = dg
             if tbe is None:
                 grads[4 * i + 3] = db
+            # the data gradient is on the step's critical path, the weight gradient is not: the main-stream kernel is
+            # enqueued FIRST (the side stream only needs dyc, marked by an event recorded before it), so it gets the CUs first
+            ev_dy = None
+            if _DGRAD_FIRST and need_p and step.side_enabled and not _DEFER_SIDE:
+                ev_dy = torch.cuda.Event()
+                ev_dy.record()
+            if _DGRAD_FIRST:
+                # data gradient on the halo kernel (flipped fragment weights); the block input's residual gradient (= d_out)
+                # is added in the epilogue of the FIRST convolution's data gradient
+                wf = _frag_weights(step, wgt, _ohwi(wgt), 64, 3, 3, 64, True)
+                dzn = torch.empty((n, h, w, 64), device=dev)
+                _lib.call("focr_conv3x3_frag_fwd", _p(dyc), ctypes.c_void_p(wf.data_ptr()), _NULL,
+                          _p(d_out) if i == 0 else _NULL, _p(dzn), _NULL, n, h, w, 64, 64, 1.0, 0, planes, 0, 0, 0, _stream())
             # convolution weight / bias gradient: side stream when the targets are flat-buffer slices
             if need_p:
                 flat = tw is not None and tb is not None
                 dw = tw if flat else torch.empty((64, 3, 3, 64), device=dev).permute(0, 3, 1, 2)
                 dbias = tb if flat else torch.empty(64, device=dev)
 
-                def conv_wgrad(cin=cin, dyc=dyc, dw=dw, dbias=dbias, flat=flat):
+                def conv_wgrad(cin=cin, dyc=dyc, dw=dw, dbias=dbias, flat=flat, ev=ev_dy):
                     side = step.side_stream() if flat else None
                     if side is not None:
-                        ev = torch.cuda.Event()
-                        ev.record()
+                        if ev is None:             # (also when parked: everything up to the flush point)
+                            ev = torch.cuda.Event()
+                            ev.record()
                         side.wait_event(ev)
                         cin.record_stream(side)
                         dyc.record_stream(side)
@@ -1305,12 +1321,13 @@ class _SRBFused(torch.autograd.Function):
                 else:
                     conv_wgrad()
                     grads[4 * i], grads[4 * i + 1] = dw, dbias
-            # data gradient on the halo kernel (flipped fragment weights); the block input's residual gradient (= d_out)
-            # is added in the epilogue of the FIRST convolution's data gradient
-            wf = _frag_weights(step, wgt, _ohwi(wgt), 64, 3, 3, 64, True)
-            dzn = torch.empty((n, h, w, 64), device=dev)
-            _lib.call("focr_conv3x3_frag_fwd", _p(dyc), ctypes.c_void_p(wf.data_ptr()), _NULL,
-                      _p(d_out) if i == 0 else _NULL, _p(dzn), _NULL, n, h, w, 64, 64, 1.0, 0, planes, 0, 0, 0, _stream())
+            if not _DGRAD_FIRST:
+                # data gradient on the halo kernel (flipped fragment weights); the block input's residual gradient (= d_out)
+                # is added in the epilogue of the FIRST convolution's data gradient
+                wf = _frag_weights(step, wgt, _ohwi(wgt), 64, 3, 3, 64, True)
+                dzn = torch.empty((n, h, w, 64), device=dev)
+                _lib.call("focr_conv3x3_frag_fwd", _p(dyc), ctypes.c_void_p(wf.data_ptr()), _NULL,
+                          _p(d_out) if i == 0 else _NULL, _p(dzn), _NULL, n, h, w, 64, 64, 1.0, 0, planes, 0, 0, 0, _stream())
             dz = dzn
         dx = dz if ctx.needs_input_grad[0] else None
         return (dx, None, None, None, None, None, None, None) + tuple(grads) + tuple(fgrads)
