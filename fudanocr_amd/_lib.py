@@ -126,6 +126,10 @@ def load():
         raise RuntimeError(
             "fudanocr_amd: %s is missing -- build it with `python __graft_entry__.py` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    # torch first: it ships its own libamdhip64 and the library must bind to THAT runtime (the one that owns torch's
+    # streams and allocations).  Loading libfocr_hip.so before torch pulls /opt/rocm's copy in beside it and every
+    # launch then fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
