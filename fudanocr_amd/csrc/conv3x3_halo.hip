@@ -189,6 +189,14 @@ struct H3Geom {
   int ksteps_total;                // 9 * Cin / 16
 };
 
+#ifdef H3_TRACE
+// tools/ubench/conv_ubench.cpp trace: per block [t_start, t_staged, t_contracted, t_end] (100 MHz wall clock), HW_ID, XCC_ID
+__device__ unsigned long long* h3_trace_buf;
+#define H3_STAMP(k) do { if (h3_trace_buf && threadIdx.x == 0) h3_trace_buf[(size_t)blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define H3_STAMP(k)
+#endif
+
 template <int PLANES>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_kernel(const float* __restrict__ X, const __bf16* __restrict__ Wf,
                                                               const float* __restrict__ bias,
@@ -203,6 +211,20 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  H3_STAMP(0);
+#ifdef H3_TRACE
+  if (h3_trace_buf && threadIdx.x == 0) {
+    h3_trace_buf[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    h3_trace_buf[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+  }
+#endif
+#ifdef H3_STAGGER
+  // experiment (tools/gpu/r03_call19.sh): delay the second resident block of every CU (ids t and t + 32 of an XCD share a
+  // CU, see the trace) so that its staging overlaps the first one's contraction.  No gain at any delay: flat up to
+  // 3.4 us, then slower by the delay.
+  if (((blockIdx.x >> 3) >> 5) & 1)
+    for (int i = 0; i < H3_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);
+#endif
   // tile decode: the tiles of one image share halo rows/columns -> keep them on one XCD (block id % 8)
   const int tpi = g.tiles_x * g.tiles_y;
   int img, tile;
@@ -281,6 +303,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   };
   auto stage_halo = [&](int s) {
     constexpr int NPASS = (H3_HR * H3_HP * 16 + 255) / 256;     // 13
+    // two batches (7 + 6 loads per thread): one batch of 13 is SLOWER (staging phase 6.8 -> 7.4 us in the block trace,
+    // launch 40.8 -> 42.0 us, 31 spilled VGPRs in the split-product variant) -- the phase is bandwidth-, not
+    // round-trip-bound
     stage_batch(s, std::integral_constant<int, 0>{}, std::integral_constant<int, 7>{});
     stage_batch(s, std::integral_constant<int, 7>{}, std::integral_constant<int, NPASS>{});
   };
@@ -318,6 +343,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                              // halo + first chunk of the slice visible
+      H3_STAMP(1);
       if (s == nslices - 1 && g.cg_loop == 1) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -352,6 +378,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       H3_CHUNK(6) H3_CHUNK(7) H3_CHUNK(8) H3_CHUNK(9) H3_CHUNK(10) H3_CHUNK(11)
       H3_CHUNK(12) H3_CHUNK(13) H3_CHUNK(14) H3_CHUNK(15) H3_CHUNK(16) H3_CHUNK(17)
 #undef H3_CHUNK
+      H3_STAMP(2);
     }
     // ---- epilogue of this 64-channel output group
 #ifdef H3_ABL_EPI
@@ -435,6 +462,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       }
     }
   }
+  H3_STAMP(3);
 }
 
 // ------------------------------------------------------------------------------------------------------------

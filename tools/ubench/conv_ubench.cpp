@@ -146,6 +146,35 @@ int main(int argc, char** argv) {
     auto h2s = [&]() { focr_conv3x3_halo(x, wf, bias, res, y1, stats, s.N, s.H, s.W, s.Cin, s.Cout, s.Cin, s.Cout, s.Cout, 1.f, 0, 2, 0); };
     auto h1 = [&]() { focr_conv3x3_halo(x, wf, bias, res, y2, nullptr, s.N, s.H, s.W, s.Cin, s.Cout, s.Cin, s.Cout, s.Cout, 1.f, 0, 1, 0); };
     auto prep = [&]() { focr_weight_prep_frag_launch(ddesc, 1, (long)s.Cout * 9 * s.Cin / 8, 0); };
+#ifdef H3_TRACE
+    if (getenv("H3_TRACE_RUN")) {
+      // block timeline of ONE launch (or of the 2nd of 3 back-to-back launches with H3_TRACE_RUN=3)
+      unsigned long long* tb; CK(hipMalloc(&tb, (size_t)tiles * 64));
+      for (int planes = 2; planes >= 1; --planes) {
+        auto fn = [&]() { if (planes == 2) h2(); else h1(); };
+        fn(); fn(); CK(hipDeviceSynchronize());
+        const bool chain = atoi(getenv("H3_TRACE_RUN")) == 3;
+        unsigned long long* nul = nullptr;
+        if (chain) fn();
+        CK(hipMemcpyToSymbolAsync(HIP_SYMBOL(h3_trace_buf), &tb, sizeof(tb), 0, hipMemcpyHostToDevice, 0));
+        fn();
+        CK(hipMemcpyToSymbolAsync(HIP_SYMBOL(h3_trace_buf), &nul, sizeof(nul), 0, hipMemcpyHostToDevice, 0));
+        if (chain) fn();
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> h((size_t)tiles * 8);
+        CK(hipMemcpy(h.data(), tb, h.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull, t3 = 0;
+        for (int i = 0; i < tiles; ++i) { t0 = std::min(t0, h[i * 8]); t3 = std::max(t3, h[i * 8 + 3]); }
+        printf("TRACE planes %d tiles %d span %.2f us\n", planes, tiles, (t3 - t0) * 0.01);
+        for (int i = 0; i < tiles; ++i) {
+          const unsigned hw = (unsigned)h[i * 8 + 4], xcc = (unsigned)h[i * 8 + 5] & 15;
+          printf("B %d xcc %u se %u cu %u simd %u wave %u  %.2f %.2f %.2f %.2f\n", i, xcc, (hw >> 13) & 7, (hw >> 8) & 15, (hw >> 4) & 3,
+                 hw & 15, (h[i * 8] - t0) * 0.01, (h[i * 8 + 1] - t0) * 0.01, (h[i * 8 + 2] - t0) * 0.01, (h[i * 8 + 3] - t0) * 0.01);
+        }
+      }
+      return 0;
+    }
+#endif
     float t_old = timeit(old_k), t_h2 = timeit(h2), t_h1 = timeit(h1), t_h2s = timeit(h2s), t_prep = timeit(prep);
     CK(hipDeviceSynchronize());
     std::vector<float> r(ny), a(ny), b(ny), c(ny);
