@@ -30,16 +30,13 @@ __device__ __forceinline__ void split1(float x, __bf16& hi, __bf16& lo) {
   hi = (__bf16)x;
   lo = (__bf16)(x - (float)hi);
 }
-// split 8 consecutive accumulator registers into MFMA operand fragments
+// split 8 consecutive accumulator registers into MFMA operand fragments (pairwise: focr_common.h focr_split2)
 __device__ __forceinline__ void split_regs(const f32x16& s, int m, bf16x8& hi, bf16x8& lo) {
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    __bf16 h, l;
-    split1(s[8 * m + e], h, l);
-    hi[e] = h;
-    lo[e] = l;
-  }
+  const float v[8] = {s[8 * m], s[8 * m + 1], s[8 * m + 2], s[8 * m + 3], s[8 * m + 4], s[8 * m + 5], s[8 * m + 6],
+                      s[8 * m + 7]};
+  focr_split8(v, hi, lo);
 }
+__device__ __forceinline__ void split4(float4 v, bf16x4& hi, bf16x4& lo) { focr_split4(v, hi, lo); }
 __device__ __forceinline__ bf16x8 cat44(bf16x4 a, bf16x4 b) {
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
@@ -53,13 +50,8 @@ __device__ __forceinline__ bf16x8 cat44(bf16x4 a, bf16x4 b) {
 // row-major staging of 2 rows x 4 columns held by one thread (rows 2*rp, 2*rp+1; cols c0..c0+3)
 __device__ __forceinline__ void put_rows(__bf16* Th, __bf16* Tl, int rp, int c0, float4 r0, float4 r1) {
   bf16x4 h0, l0, h1, l1;
-  const float a[4] = {r0.x, r0.y, r0.z, r0.w}, b[4] = {r1.x, r1.y, r1.z, r1.w};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    __bf16 h, l;
-    split1(a[e], h, l); h0[e] = h; l0[e] = l;
-    split1(b[e], h, l); h1[e] = h; l1[e] = l;
-  }
+  split4(r0, h0, l0);
+  split4(r1, h1, l1);
   *reinterpret_cast<bf16x4*>(&Th[(2 * rp) * RP + c0]) = h0;
   *reinterpret_cast<bf16x4*>(&Tl[(2 * rp) * RP + c0]) = l0;
   *reinterpret_cast<bf16x4*>(&Th[(2 * rp + 1) * RP + c0]) = h1;
@@ -71,9 +63,7 @@ __device__ __forceinline__ void put_cols(__bf16* Th, __bf16* Tl, int rp, int c0,
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     bf16x2 h, l;
-    __bf16 x, y;
-    split1(a[e], x, y); h[0] = x; l[0] = y;
-    split1(b[e], x, y); h[1] = x; l[1] = y;
+    focr_split2(f32x2{a[e], b[e]}, h, l);
     *reinterpret_cast<bf16x2*>(&Th[(c0 + e) * TP + 2 * rp]) = h;
     *reinterpret_cast<bf16x2*>(&Tl[(c0 + e) * TP + 2 * rp]) = l;
   }
@@ -83,14 +73,11 @@ __device__ __forceinline__ float4 scale4(float4 v, float s) { return make_float4
 // fragment of 8 consecutive columns of one global row, scaled, as hi/lo
 __device__ __forceinline__ void row_frag(const float* p, float sc, bf16x8& hi, bf16x8& lo) {
   float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-  const float v[8] = {a.x * sc, a.y * sc, a.z * sc, a.w * sc, b.x * sc, b.y * sc, b.z * sc, b.w * sc};
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    __bf16 h, l;
-    split1(v[e], h, l);
-    hi[e] = h;
-    lo[e] = l;
-  }
+  bf16x4 h0, l0, h1, l1;
+  split4(scale4(a, sc), h0, l0);
+  split4(scale4(b, sc), h1, l1);
+  hi = cat44(h0, h1);
+  lo = cat44(l0, l1);
 }
 
 // ---- pre-split operand planes ("PL" kernel variants) -----------------------------------------------------------
@@ -652,16 +639,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_bx3_kernel(const float* __re
 // hi parts only (bf16 gradient accumulation, precision mode 2)
 __device__ __forceinline__ void hi_regs(const f32x16& s, int m, bf16x8& hi) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) hi[e] = (__bf16)s[8 * m + e];
+  for (int e = 0; e < 8; e += 2) {
+    const bf16x2 h = __builtin_convertvector(f32x2{s[8 * m + e], s[8 * m + e + 1]}, bf16x2);
+    hi[e] = h[0];
+    hi[e + 1] = h[1];
+  }
 }
 // transposed staging of the hi plane only
 __device__ __forceinline__ void put_cols_hi(__bf16* Th, int rp, int c0, float4 r0, float4 r1) {
   const float a[4] = {r0.x, r0.y, r0.z, r0.w}, b[4] = {r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    bf16x2 h;
-    h[0] = (__bf16)a[e];
-    h[1] = (__bf16)b[e];
+    const bf16x2 h = __builtin_convertvector(f32x2{a[e], b[e]}, bf16x2);
     *reinterpret_cast<bf16x2*>(&Th[(c0 + e) * TP + 2 * rp]) = h;
   }
 }
@@ -751,6 +740,12 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
   } while (0)
   if (PL) PL_LOAD_QG(0);
   else LOAD_QG(0);
+  int boff[16];                                    // keep-bit offsets of the 16 accumulator registers, opaque SGPRs (below)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    boff[r] = (r & 3) + 8 * (r >> 2);
+    asm volatile("" : "+s"(boff[r]));
+  }
   for (int qt = 0; qt < ntiles; ++qt) {
     const uint32_t mcur0 = mreg0 >> (4 * lh), mcur1 = mreg1 >> (4 * lh);
     if (PL) {
@@ -799,12 +794,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bx3_kernel(
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        int qlq = sub * 32 + key_of_b(r, lh);
+        const int qlq = sub * 32 + key_of_b(r, lh);
         // dS = P (M dP' - D) = (M P) dP' - P D with M the keep mask: one AND instead of two, the rest an fma
         const float p = __builtin_amdgcn_exp2f(s[r]);
         float pd = p;
         if (DROPOUT) {
-          const int mk = bit_sext(sub ? mcur1 : mcur0, (r & 3) + 8 * (r >> 2));   // query bit of this lane's key word
+          // query bit of this lane's key word.  The bit offset comes from an SGPR the compiler cannot see through:
+          // with a literal offset it rewrites sbfe + and as and + cmp + cndmask (3 VALU operations instead of 2)
+          const int mk = bit_sext(sub ? mcur1 : mcur0, boff[r]);
           pd = __int_as_float(__float_as_int(p) & mk);              // 1/(1-p) folded into the dV store
         }
         s[r] = pd;
@@ -1043,11 +1040,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_bx3_kernel(
         }
         __builtin_amdgcn_sched_barrier(0);       // keep the requests up here (the scheduler sinks them to their uses)
       }
+      // the score accumulators START at -LSE of the lane's query: the MFMAs deliver s - lse for free.  (Starting dP at -D
+      // as well and selecting -D for dropped scores saves the subtraction below but costs 80 spilled VGPRs: 615 -> 667 us
+      // for the backward pair, tools/gpu/r03_call27.sh.)
       f32x16 s[2], dp[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[t][r] = 0.f; dp[t][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { s[t][r] = FAST ? -lse[t] : 0.f; dp[t][r] = 0.f; }   // (FAST only: registers)
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         const int off = (sub * 32 + li) * RP + 16 * m + 8 * lh;
@@ -1062,7 +1062,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_bx3_kernel(
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(s[t][r] - lse[t]);
+          const float p = __builtin_amdgcn_exp2f(FAST ? s[t][r] : s[t][r] - lse[t]);
           float dpe = dp[t][r];
           if (DROPOUT) dpe = keep_lanes(dpe, mk[t][r]);
           s[t][r] = p * (dpe - dd[t]);
@@ -1179,13 +1179,7 @@ __global__ __launch_bounds__(256) void attn_make_planes_kernel(const float* __re
   const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
   const float a[4] = {v.x * mul, v.y * mul, v.z * mul, v.w * mul};
   bf16x4 h, l;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    __bf16 hh, ll;
-    split1(a[e], hh, ll);
-    h[e] = hh;
-    l[e] = ll;
-  }
+  split4(make_float4(a[0], a[1], a[2], a[3]), h, l);
   *reinterpret_cast<bf16x8*>(out + r * 256 + 2 * c) = cat44(h, l);
 }
 int focr_attn_make_planes(const float* x, void* planes, long rows, int ld, float mul, hipStream_t stream) {

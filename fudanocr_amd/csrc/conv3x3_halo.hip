@@ -107,15 +107,7 @@ __global__ __launch_bounds__(256) void weight_prep_frag_kernel(const WPrepDesc* 
 }
 __global__ __launch_bounds__(256) void weight_prep_frag_one_kernel(WPrepDesc d) { weight_prep_frag_body(d); }
 
-__device__ __forceinline__ void h3_split4(float4 v, hbf16x4& hi, hbf16x4& lo) {
-  const float a[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const __bf16 h = (__bf16)a[e];
-    hi[e] = h;
-    lo[e] = (__bf16)(a[e] - (float)h);
-  }
-}
+__device__ __forceinline__ void h3_split4(float4 v, hbf16x4& hi, hbf16x4& lo) { focr_split4(v, hi, lo); }
 
 // ---- main-loop fragment traffic: hand-ordered ds_read_b128 + counted waits -----------------------------------
 // hipcc's own schedule of this loop serialises: it re-uses two or three fragment registers and waits lgkmcnt(0) in

@@ -27,18 +27,13 @@ __device__ __forceinline__ void pack_quad(const float4 (&r)[4], int e, uint32_t&
                       e == 0 ? r[1].x : e == 1 ? r[1].y : e == 2 ? r[1].z : r[1].w,
                       e == 0 ? r[2].x : e == 1 ? r[2].y : e == 2 ? r[2].z : r[2].w,
                       e == 0 ? r[3].x : e == 1 ? r[3].y : e == 2 ? r[3].z : r[3].w};
-  uint32_t hb[4], lb[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    __bf16 h = (__bf16)v[j];
-    __bf16 l = (__bf16)(v[j] - (float)h);
-    hb[j] = (uint32_t)__builtin_bit_cast(unsigned short, h);
-    lb[j] = (uint32_t)__builtin_bit_cast(unsigned short, l);
-  }
-  h0 = hb[0] | (hb[1] << 16);
-  h1 = hb[2] | (hb[3] << 16);
-  l0 = lb[0] | (lb[1] << 16);
-  l1 = lb[2] | (lb[3] << 16);
+  focr_bf16x2 ha, la, hb, lb;
+  focr_split2(f32x2{v[0], v[1]}, ha, la);
+  focr_split2(f32x2{v[2], v[3]}, hb, lb);
+  h0 = __builtin_bit_cast(uint32_t, ha);
+  h1 = __builtin_bit_cast(uint32_t, hb);
+  l0 = __builtin_bit_cast(uint32_t, la);
+  l1 = __builtin_bit_cast(uint32_t, lb);
 }
 __device__ __forceinline__ void st2(__bf16* p, uint32_t a, uint32_t b) {
   *reinterpret_cast<uint2*>(p) = make_uint2(a, b);

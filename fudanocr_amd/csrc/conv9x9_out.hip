@@ -192,12 +192,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 obf16x4;
 
 __device__ __forceinline__ void split8(const float4 a, const float4 b, obf16x8& hi, obf16x8& lo) {
   const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    __bf16 h = (__bf16)v[e];
-    hi[e] = h;
-    lo[e] = (__bf16)(v[e] - (float)h);
-  }
+  focr_split8(v, hi, lo);
 }
 
 #define C9_LOAD_ROW(IY)                                                                                   \

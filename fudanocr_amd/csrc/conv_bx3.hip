@@ -17,15 +17,7 @@ struct ConvGeomX {
   int N, H, W, Cin, OH, OW, Cout, KH, KW, padH, padW, Ktot, M, ldy, ldr, ldx;
 };
 
-__device__ __forceinline__ void split4(float4 v, bf16x4& hi, bf16x4& lo) {
-  const float a[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    __bf16 h = (__bf16)a[e];
-    hi[e] = h;
-    lo[e] = (__bf16)(a[e] - (float)h);
-  }
-}
+__device__ __forceinline__ void split4(float4 v, bf16x4& hi, bf16x4& lo) { focr_split4(v, hi, lo); }
 
 template <int NT>
 __global__ __launch_bounds__(256) void conv_fwd_bx3_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
@@ -253,12 +245,7 @@ __device__ __forceinline__ void put_quad(__bf16* Th, __bf16* Tl, int c0, int px0
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     bf16x4 h, l;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      __bf16 x = (__bf16)v[j][e];
-      h[j] = x;
-      l[j] = (__bf16)(v[j][e] - (float)x);
-    }
+    focr_split4(v[0][e], v[1][e], v[2][e], v[3][e], h, l);
     *reinterpret_cast<bf16x4*>(&Th[(c0 + e) * WTP + px0]) = h;
     *reinterpret_cast<bf16x4*>(&Tl[(c0 + e) * WTP + px0]) = l;
   }

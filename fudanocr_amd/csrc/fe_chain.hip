@@ -54,14 +54,8 @@ __device__ __forceinline__ void fc_stage_w(const float* __restrict__ Wg, int N, 
   for (int i = threadIdx.x; i < N * Q; i += FC_THREADS) {
     const int n = i / Q, c = 4 * (i - n * Q);
     const float4 v = *reinterpret_cast<const float4*>(Wg + (size_t)n * K + c);
-    const float a[4] = {v.x, v.y, v.z, v.w};
     fc_bf16x4 h, l;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const __bf16 t = (__bf16)a[e];
-      h[e] = t;
-      l[e] = (__bf16)(a[e] - (float)t);
-    }
+    focr_split4(v, h, l);
     const int kk = fc_perm(c);
     *reinterpret_cast<fc_bf16x4*>(&Wh[n * KP + kk]) = h;
     *reinterpret_cast<fc_bf16x4*>(&Wl[n * KP + kk]) = l;
@@ -76,13 +70,13 @@ __device__ __forceinline__ void fc_stage_wt(const float* __restrict__ Wg, int ld
   for (int i = threadIdx.x; i < N * Q; i += FC_THREADS) {
     const int n = i / Q, c = 4 * (i - n * Q);
     const float4 v = *reinterpret_cast<const float4*>(Wg + (size_t)n * ldw + c);
-    const float a[4] = {v.x, v.y, v.z, v.w};
     const int kk = fc_perm(n);
+    fc_bf16x4 h, l;
+    focr_split4(v, h, l);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const __bf16 t = (__bf16)a[e];
-      Wh[(c + e) * KP + kk] = t;
-      Wl[(c + e) * KP + kk] = (__bf16)(a[e] - (float)t);
+      Wh[(c + e) * KP + kk] = h[e];
+      Wl[(c + e) * KP + kk] = l[e];
     }
   }
 }
@@ -119,13 +113,7 @@ __device__ __forceinline__ void fc_store_planes(__bf16* __restrict__ p, int lh, 
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       fc_bf16x4 h, l;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float x = v[j][4 * g + e] * mul;
-        const __bf16 t = (__bf16)x;
-        h[e] = t;
-        l[e] = (__bf16)(x - (float)t);
-      }
+      focr_split4(v[j][4 * g] * mul, v[j][4 * g + 1] * mul, v[j][4 * g + 2] * mul, v[j][4 * g + 3] * mul, h, l);
       *reinterpret_cast<fc_bf16x8*>(p + 2 * (32 * j + 8 * g + 4 * lh)) = __builtin_shufflevector(h, l, 0, 1, 2, 3, 4, 5, 6, 7);
     }
 }
@@ -146,14 +134,11 @@ __device__ __forceinline__ void fc_frags(const f32x16 (&v)[NT], fc_bf16x8 (&h)[2
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float x = v[j][8 * m + e];
-        const __bf16 t = (__bf16)x;
-        h[2 * j + m][e] = t;
-        l[2 * j + m][e] = (__bf16)(x - (float)t);
-      }
+    for (int m = 0; m < 2; ++m) {
+      const float x[8] = {v[j][8 * m],     v[j][8 * m + 1], v[j][8 * m + 2], v[j][8 * m + 3],
+                          v[j][8 * m + 4], v[j][8 * m + 5], v[j][8 * m + 6], v[j][8 * m + 7]};
+      focr_split8(x, h[2 * j + m], l[2 * j + m]);
+    }
 }
 // acc[j] += W[32 j + i][:] . x   (NTO output tiles, KS k-steps; W from LDS at pitch KP, first k position koff)
 template <int NTO, int KS, int KP>
@@ -523,14 +508,8 @@ __global__ __launch_bounds__(256, 2) void fe_qkv_fwd_kernel(const float* __restr
     for (int i = threadIdx.x; i < FC_D * Q; i += 256) {
       const int n = i / Q, c = 4 * (i - n * Q);
       const float4 v = *reinterpret_cast<const float4*>(Wg + (size_t)n * FC_D + c);
-      const float a[4] = {v.x, v.y, v.z, v.w};
       fc_bf16x4 h, l;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const __bf16 t = (__bf16)a[e];
-        h[e] = t;
-        l[e] = (__bf16)(a[e] - (float)t);
-      }
+      focr_split4(v, h, l);
       const int kk = fc_perm(c);
       *reinterpret_cast<fc_bf16x4*>(&Wh[n * KP + kk]) = h;
       *reinterpret_cast<fc_bf16x4*>(&Wl[n * KP + kk]) = l;

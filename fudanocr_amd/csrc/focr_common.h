@@ -40,6 +40,48 @@ extern "C" int focr_get_tuning(int key);
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 focr_bf16x2;
+typedef __attribute__((ext_vector_type(4))) __bf16 focr_bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 focr_bf16x8;
+
+// x = hi + lo split of TWO floats at once: 6 VALU instructions per pair (v_cvt_pk_bf16_f32, shift, and, 2 x v_sub_f32,
+// v_cvt_pk_bf16_f32).  Written on pairs because hipcc otherwise converts the hi part twice (once alone to form x - hi,
+// once as a pair for packing): 8 instructions per pair.  The two subtractions stay scalar on purpose: beside MFMAs a
+// v_pk_add_f32 costs more than the two v_sub_f32 it replaces (MI355X_MICROARCH.md, "price of one filler"; measured here:
+// tools/gpu/r03_call22.sh vs r03_call23.sh).  Same values as the scalar form (round-to-nearest-even conversion, exact
+// widening, exact subtraction).
+__device__ __forceinline__ void focr_split2(f32x2 x, focr_bf16x2& hi, focr_bf16x2& lo) {
+  // no fma contraction across the subtraction: when x is a product (x = v * scale), lo must come from the ROUNDED product
+  // that hi was taken from, so that every producer of split operands (kernels splitting on the fly, attn_make_planes,
+  // fe_qkv_fwd writing planes) yields the same bits
+#pragma clang fp contract(off)
+  hi = __builtin_convertvector(x, focr_bf16x2);
+  const unsigned w = __builtin_bit_cast(unsigned, hi);
+  float dx = x.x - __uint_as_float(w << 16);
+  float dy = x.y - __uint_as_float(w & 0xffff0000u);
+#ifndef FOCR_SPLIT_PK
+  asm volatile("" : "+v"(dx));          // keeps the SLP vectoriser from fusing the pair into v_pk_add_f32
+#endif
+  lo = __builtin_convertvector(f32x2{dx, dy}, focr_bf16x2);
+}
+__device__ __forceinline__ void focr_split4(float a, float b, float c, float d, focr_bf16x4& hi, focr_bf16x4& lo) {
+  focr_bf16x2 h0, l0, h1, l1;
+  focr_split2(f32x2{a, b}, h0, l0);
+  focr_split2(f32x2{c, d}, h1, l1);
+  hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3);
+  lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3);
+}
+__device__ __forceinline__ void focr_split4(float4 v, focr_bf16x4& hi, focr_bf16x4& lo) {
+  focr_split4(v.x, v.y, v.z, v.w, hi, lo);
+}
+__device__ __forceinline__ void focr_split8(const float (&v)[8], focr_bf16x8& hi, focr_bf16x8& lo) {
+  focr_bf16x4 h0, l0, h1, l1;
+  focr_split4(v[0], v[1], v[2], v[3], h0, l0);
+  focr_split4(v[4], v[5], v[6], v[7], h1, l1);
+  hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+  lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

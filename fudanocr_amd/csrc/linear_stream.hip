@@ -16,24 +16,11 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 lbf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 lbf16x4;
 
-__device__ __forceinline__ void lsplit4(float4 v, lbf16x4& hi, lbf16x4& lo) {
-  const float a[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    __bf16 h = (__bf16)a[e];
-    hi[e] = h;
-    lo[e] = (__bf16)(a[e] - (float)h);
-  }
-}
+__device__ __forceinline__ void lsplit4(float4 v, lbf16x4& hi, lbf16x4& lo) { focr_split4(v, hi, lo); }
 
 __device__ __forceinline__ void lsplit8(const float4 a, const float4 b, lbf16x8& hi, lbf16x8& lo) {
   const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    __bf16 h = (__bf16)v[e];
-    hi[e] = h;
-    lo[e] = (__bf16)(v[e] - (float)h);
-  }
+  focr_split8(v, hi, lo);
 }
 
 template <int K, int NT, bool HAS_RES, bool HAS_DROP>

@@ -49,13 +49,8 @@ __device__ __forceinline__ void lw_wait(LwRaw& r) {
 }
 // eight fp32 rows of one column -> bf16 hi / lo fragments
 __device__ __forceinline__ void lw_split(const lw_f32x2 (&v)[8], int t, lw_bf16x8& hi, lw_bf16x8& lo) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float x = v[j][t];
-    const __bf16 h = (__bf16)x;
-    hi[j] = h;
-    lo[j] = (__bf16)(x - (float)h);
-  }
+  const float x[8] = {v[0][t], v[1][t], v[2][t], v[3][t], v[4][t], v[5][t], v[6][t], v[7][t]};
+  focr_split8(x, hi, lo);
 }
 
 // grid (K / 128, Cout / 128, splits), 256 threads.  PART: [splits][Cout * K + Cout] floats.

@@ -387,12 +387,8 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 gbf16x8;
 __device__ __forceinline__ void g_split8(const float* v, gbf16x8& hi, gbf16x8& lo) {
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const __bf16 h = (__bf16)v[e];
-    hi[e] = h;
-    lo[e] = (__bf16)(v[e] - (float)h);
-  }
+  const float x[8] = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+  focr_split8(x, hi, lo);
 }
 #define G_MFMA3(acc, ah, al, bh, bl)                                        \
   do {                                                                      \

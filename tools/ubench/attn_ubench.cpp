@@ -1,5 +1,5 @@
 // Standalone micro-benchmark of the attention kernels (no torch): variant A/B in one process, outputs compared.
-//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/attn_ubench.cpp -o build/attn_ubench
+//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize tools/ubench/attn_ubench.cpp -o build/attn_ubench
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>

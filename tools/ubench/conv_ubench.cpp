@@ -1,5 +1,5 @@
 // Standalone micro-benchmark + correctness check of the convolution kernels (no torch: runs in seconds on the GPU box).
-//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/conv_ubench.cpp -o build/conv_ubench
+//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize tools/ubench/conv_ubench.cpp -o build/conv_ubench
 // For every shape: naive fp32 reference (GPU), generic bf16x3 kernel (conv_bx3.hip), halo kernel (planes 2 and 1).
 #include <hip/hip_runtime.h>
 #include <stdarg.h>

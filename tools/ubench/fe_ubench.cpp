@@ -1,5 +1,5 @@
 // Standalone correctness check + micro-benchmark of the fused FeatureEnhancer row chains (csrc/fe_chain.hip); no torch.
-//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/fe_ubench.cpp -o build/fe_ubench
+//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize tools/ubench/fe_ubench.cpp -o build/fe_ubench
 //   run:   build/fe_ubench [batch=128]
 // Every kernel is compared with a one-thread-per-row fp64 evaluation of the same chain (reference tbsrn.py:76-92).
 #include <hip/hip_runtime.h>

@@ -1,5 +1,5 @@
 // Standalone micro-benchmark + correctness check of the linear weight-gradient kernels.
-//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-pass-failed tools/ubench/lwgrad_ubench.cpp -o build/lwgrad_ubench
+//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -Wno-pass-failed tools/ubench/lwgrad_ubench.cpp -o build/lwgrad_ubench
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
