@@ -2,6 +2,7 @@
 """Headline benchmark: training images/sec of the FudanOCR hot path on synthetic crops, one process per GPU.
 
   python bench.py [--config c3] --gpus 1 --steps K --warmup W
+  python bench.py --gpus N ...          (N > 1 without a launcher environment: re-launches itself as below)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -170,6 +171,23 @@ def _gemm_rows(calls, kind):
     return fl, by, ms, n
 
 
+def _self_launch(n):
+    """Re-run this command line as `n` ranks of one node: python -m torch.distributed.run --nnodes=1 --nproc-per-node n
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>.  Returns the launcher's exit code; the ranks
+    inherit stdout, so rank 0's JSON line is this process's output."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     if "--cpu-baseline-only" in sys.argv:
         i = sys.argv.index("--cpu-baseline-only")
@@ -193,6 +211,10 @@ def main():
     ap.add_argument("--all-configs", action="store_true",
                     help="single GPU only: also run c1, c2 and c5 (one subprocess each, 40 timed steps, no CPU baseline) and "
                          "print their JSON lines BEFORE this configuration's line (which stays the last line)")
+    ap.add_argument("--check-launch", action="store_true",
+                    help="launcher / rendezvous check only (no GPU work, runs on a CPU-only host): every rank joins the "
+                         "process group (gloo), one all-reduce, rank 0 prints a JSON line with n_gpus and "
+                         "collective_backend and value null")
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE",
                     help="A/B kernel-selection switch (focr_set_tuning, include/focr.h); reported in config.tuning")
     args = ap.parse_args()
@@ -205,8 +227,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: become the launcher (one rank per GPU under torch.distributed.run, the
+        # command line the driver uses for N > 1) and pass rank 0's JSON line through
+        sys.exit(_self_launch(args.gpus))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    if args.check_launch:
+        if world > 1:
+            dist.init_process_group("gloo")
+            t = torch.tensor([float(rank + 1)])
+            dist.all_reduce(t)
+            assert t.item() == world * (world + 1) / 2, "all-reduce over the launched ranks returned %r" % t.item()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "launch check", "value": None, "n_gpus": world, "steps": 0, "warmup": 0,
+                              "config": {"name": cfg, "collective_backend": "gloo" if world > 1 else None,
+                                         "parallelism": "dp%d" % world}}))
+        return
     # FOCR_BENCH_BACKEND=gloo lets several ranks share one GPU (functional check of the multi-process path
     # on a 1-GPU box; RCCL refuses two ranks on one device).  The measured configuration is always nccl = RCCL.
     backend = os.environ.get("FOCR_BENCH_BACKEND", "nccl")

@@ -716,13 +716,13 @@ extern "C" int focr_fe_post_fwd(const float* ctx, const float* tok, const float*
     *keep_scale = 65536.f / (float)kq;
     if (kq >= 65536u) kq = 0u;
   }
-  static bool attr = false;
-  if (!attr) {
+  static focr_dev_flags attr;
+  if (focr_dev_first(attr)) {
     if (!fc_set_lds(fe_fwd_a_kernel, FC_LDS_FWD_A) || !fc_set_lds(fe_fwd_b_kernel, FC_LDS_FWD_B)) {
       focr_set_error("focr_fe_post_fwd: cannot reserve %zu bytes of LDS", FC_LDS_FWD_A);
       return FOCR_EHIP;
     }
-    attr = true;
+    focr_dev_mark(attr);
   }
   const int ntiles = (int)(rows / 32), nb = fc_blocks(ntiles);
   hipLaunchKernelGGL(fe_fwd_a_kernel, dim3(nb), FC_THREADS, FC_LDS_FWD_A, stream, ctx, tok, wo, bo, a1, b1, w1, bb1,
@@ -743,13 +743,13 @@ extern "C" int focr_fe_post_bwd(const float* d_out, const float* wl, const float
                  "null pointer");
   FOCR_CHECK_ARG(focr_fe_chain_supported(rows, FC_D), "rows must be a positive multiple of 32 (precision mode != 0)");
   FOCR_CHECK_ARG(!dwork || (ctx && ntok > 0 && rows % ntok == 0), "dwork needs ctx and the tokens per image");
-  static bool attr = false;
-  if (!attr) {
+  static focr_dev_flags attr;
+  if (focr_dev_first(attr)) {
     if (!fc_set_lds(fe_bwd_a_kernel, FC_LDS_BWD_A) || !fc_set_lds(fe_bwd_b_kernel, FC_LDS_BWD_B)) {
       focr_set_error("focr_fe_post_bwd: cannot reserve %zu bytes of LDS", FC_LDS_BWD_B);
       return FOCR_EHIP;
     }
-    attr = true;
+    focr_dev_mark(attr);
   }
   const int ntiles = (int)(rows / 32), nb = fc_blocks(ntiles);
   hipLaunchKernelGGL(fe_bwd_a_kernel, dim3(nb), FC_THREADS, FC_LDS_BWD_A, stream, d_out, wl, xhat2, rinv2, a3, w2, h,
@@ -766,13 +766,13 @@ extern "C" int focr_fe_qkv_fwd(const float* feat, const float* pe, const float* 
                                float* qkv, long rows, int ntok, void* planes, float q_mul, hipStream_t stream) {
   FOCR_CHECK_ARG(feat && pe && wqkv && tok && (qkv || planes) && ntok > 0, "bad argument");
   FOCR_CHECK_ARG(focr_fe_chain_supported(rows, FC_D), "rows must be a positive multiple of 32 (precision mode != 0)");
-  static bool attr = false;
-  if (!attr) {
+  static focr_dev_flags attr;
+  if (focr_dev_first(attr)) {
     if (!fc_set_lds(fe_qkv_fwd_kernel, FC_LDS_QKV_FWD)) {
       focr_set_error("focr_fe_qkv_fwd: cannot reserve %zu bytes of LDS", FC_LDS_QKV_FWD);
       return FOCR_EHIP;
     }
-    attr = true;
+    focr_dev_mark(attr);
   }
   const int ntiles = (int)(rows / 32);
   int nb = (ntiles + 3) / 4;
@@ -787,13 +787,13 @@ extern "C" int focr_fe_qkv_dgrad(const float* dqkv, const float* wqkv, const flo
                                  hipStream_t stream) {
   FOCR_CHECK_ARG(dqkv && wqkv && d_feat, "null pointer");
   FOCR_CHECK_ARG(focr_fe_chain_supported(rows, FC_D), "rows must be a positive multiple of 32 (precision mode != 0)");
-  static bool attr = false;
-  if (!attr) {
+  static focr_dev_flags attr;
+  if (focr_dev_first(attr)) {
     if (!fc_set_lds(fe_bwd_qkv_kernel, FC_LDS_BWD_QKV)) {
       focr_set_error("focr_fe_qkv_dgrad: cannot reserve %zu bytes of LDS", FC_LDS_BWD_QKV);
       return FOCR_EHIP;
     }
-    attr = true;
+    focr_dev_mark(attr);
   }
   const int ntiles = (int)(rows / 32), nb = fc_blocks(ntiles);
   hipLaunchKernelGGL(fe_bwd_qkv_kernel, dim3(nb), FC_THREADS, FC_LDS_BWD_QKV, stream, dqkv, wqkv, d_s1, d_feat, ntiles,

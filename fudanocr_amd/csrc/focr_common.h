@@ -86,6 +86,14 @@ __device__ __forceinline__ void focr_split8(const float (&v)[8], focr_bf16x8& hi
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// "done once" flags that are PER DEVICE: function attributes (hipFuncAttributeMaxDynamicSharedMemorySize) and occupancy
+// answers belong to a device, and a process may touch several (tests that switch device, DataParallel-style hosts).
+#include <atomic>
+struct focr_dev_flags { std::atomic<unsigned long long> bits{0ull}; };
+static inline int focr_cur_device() { int d = 0; (void)hipGetDevice(&d); return d & 63; }
+static inline bool focr_dev_first(const focr_dev_flags& f) { return !(f.bits.load(std::memory_order_acquire) >> focr_cur_device() & 1ull); }
+static inline void focr_dev_mark(focr_dev_flags& f) { f.bits.fetch_or(1ull << focr_cur_device(), std::memory_order_release); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

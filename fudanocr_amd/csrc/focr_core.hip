@@ -1,6 +1,7 @@
 // library-wide state of the C ABI: thread-local error string, version.
 #include "focr_common.h"
 #include <stdarg.h>
+#include <atomic>
 
 static thread_local char g_err[512] = "";
 
@@ -24,16 +25,18 @@ extern "C" int focr_version(void) { return 100; }
 //       product (activations' gradients and weights rounded to bf16, fp32 accumulate) -- the arithmetic of every
 //       bf16 mixed-precision training stack.  Forward results are identical to 1 and 2; the host selects the plane
 //       count per call (focr_conv3x3_frag_fwd), this flag only tells it what the library-wide choice is.
-static int g_precision = 2;
+// (atomics: both words are read from PyTorch autograd worker threads while the main thread may set them -- SURVEY 8(b):
+// no unguarded global state.  Relaxed order is enough, a mode switch is only meaningful between steps.)
+static std::atomic<int> g_precision{2};
 extern "C" int focr_set_precision(int mode) {
   if (mode < 0 || mode > 3) {
     focr_set_error("focr_set_precision: mode must be 0 (fp32), 1 (bf16x3), 2 (bf16x3, bf16 gradient accumulation) or 3 (2 + bf16 data gradients)");
     return FOCR_EINVAL;
   }
-  g_precision = mode;
+  g_precision.store(mode, std::memory_order_relaxed);
   return FOCR_OK;
 }
-extern "C" int focr_get_precision(void) { return g_precision; }
+extern "C" int focr_get_precision(void) { return g_precision.load(std::memory_order_relaxed); }
 
 // Kernel-selection switches for A/B measurements (tools/dev, tools/ubench): every switch has ONE production value (the
 // default); results are the same either way, only the kernel that computes them changes.
@@ -41,14 +44,16 @@ extern "C" int focr_get_precision(void) { return g_precision; }
 //   1 "attn_fwd_variant"     1: 256-query attention forward blocks    0: 128-query blocks    2: scores one key
 //                            group ahead + thresholded rescale (measured: no gain in the step)
 //   2 "lstm_persistent"      1: one launch per BiLSTM layer and direction pair (rnn.hip)  0: one launch per time step
-//   3 "attn_bwd_dq_variant"  1: dQ pass with 256-query blocks (two tiles per wave)        0: 128-query blocks
-int g_tuning[FOCR_TUNING_COUNT] = {1, 1, 1, 1};
+//   3 "attn_bwd_dq_variant"  2: single-pass backward (dQ, dK, dV from one S / dP evaluation, attention_bwd1_bx3.h; precision
+//                            modes 2 / 3, Ntok % 256 == 0, else as 1)   1: two passes, dQ pass with 256-query blocks (two
+//                            tiles per wave)   0: two passes, 128-query blocks
+static std::atomic<int> g_tuning[FOCR_TUNING_COUNT] = {{1}, {1}, {1}, {1}};
 extern "C" int focr_set_tuning(int key, int value) {
   if (key < 0 || key >= FOCR_TUNING_COUNT) {
     focr_set_error("focr_set_tuning: unknown key %d", key);
     return FOCR_EINVAL;
   }
-  g_tuning[key] = value;
+  g_tuning[key].store(value, std::memory_order_relaxed);
   return FOCR_OK;
 }
-extern "C" int focr_get_tuning(int key) { return (key >= 0 && key < FOCR_TUNING_COUNT) ? g_tuning[key] : -1; }
+extern "C" int focr_get_tuning(int key) { return (key >= 0 && key < FOCR_TUNING_COUNT) ? g_tuning[key].load(std::memory_order_relaxed) : -1; }

@@ -1103,11 +1103,14 @@ static bool lp_usable(int B, int H) {
   if (!(H == 256 && 8 * cdiv(B, 32) * 2 <= 256 && focr_get_tuning(FOCR_TUNE_LSTM_PERSISTENT) != 0 &&
         cdiv(B, 32) * 2 + 1 <= LP_FLAG_BYTES / 4))
     return false;
-  static int resident = -1;                 // min over the two kernels, queried once per process (one device per process)
+  static std::atomic<int> resident_dev[64];          // min over the two kernels + 1 (0 = not asked yet), per device
+  std::atomic<int>& slot = resident_dev[focr_cur_device()];
+  int resident = slot.load(std::memory_order_relaxed) - 1;
   if (resident < 0) {
     const int f = lp_resident_blocks((const void*)lstm_fwd_persist_bx3_kernel, LP_FWD_LDS);
     const int b = lp_resident_blocks((const void*)lstm_bwd_persist_bx3_kernel, LP_BWD_LDS);
     resident = f < b ? f : b;
+    slot.store(resident + 1, std::memory_order_relaxed);
   }
   return 8 * cdiv(B, 32) * 2 <= resident;
 }
@@ -1127,11 +1130,11 @@ int focr_lstm_fwd_bx3(const float* gx, const float* whh, const float* bhh, float
   __bf16* hseq2 = whh2 + 2 * nw;
   hipLaunchKernelGGL(split_bf16_kernel, dim3(512), 256, 0, stream, whh, whh2, nw, 1, 1, 0);
   if (lp_usable(B, H)) {
-    static bool attr = false;
-    if (!attr) {
+    static focr_dev_flags attr;
+    if (focr_dev_first(attr)) {
       (void)hipFuncSetAttribute((const void*)lstm_fwd_persist_bx3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LP_FWD_LDS);
-      attr = true;
+      focr_dev_mark(attr);
     }
     unsigned* flags = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + focr_lstm_ws_bytes(T, B, H, 0) -
                                                   LP_FLAG_BYTES);
@@ -1156,11 +1159,11 @@ int focr_lstm_bwd_bx3(const float* dhseq, const float* whh, const float* gates, 
   // whh [2][4H][H] -> whhT [2][H][4H] (hi plane then lo plane)
   hipLaunchKernelGGL(split_bf16_kernel, dim3(512), 256, 0, stream, whh, whhT2, nw, 4 * H, H, 1);
   if (lp_usable(B, H)) {
-    static bool attr = false;
-    if (!attr) {
+    static focr_dev_flags attr;
+    if (focr_dev_first(attr)) {
       (void)hipFuncSetAttribute((const void*)lstm_bwd_persist_bx3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LP_BWD_LDS);
-      attr = true;
+      focr_dev_mark(attr);
     }
     unsigned* flags = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + focr_lstm_ws_bytes(T, B, H, 1) -
                                                   LP_FLAG_BYTES);

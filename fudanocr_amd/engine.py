@@ -277,6 +277,10 @@ class TrainStep:
         self._sent.append(rng)
         view = self.flat.flat_grad[lo:hi]
         if self.comm_stream is not None:
+            # parked weight-gradient closures (FOCR_DEFER_SIDE=1) record their inputs-ready event on the CURRENT stream:
+            # issue them here, on the compute stream, not inside the comm-stream context below (where they would order
+            # themselves behind in-flight all-reduces)
+            self.ctx.flush_side()
             ev = torch.cuda.Event()
             ev.record()                                    # gradients of this range are complete here ...
             with torch.cuda.stream(self.comm_stream):

@@ -152,13 +152,26 @@ class TextBase(object):
             # text-gestalt's criterion (text-gestalt/interfaces/base.py:162): MSE + stroke_lambda * L1 on the attention
             # maps of the stroke-level recognizer.  `--text_focus` switches its focus term on, as in the reference.
             from ..loss.stroke_focus_loss import StrokeFocusLoss
-            return {"model": model, "crit": StrokeFocusLoss(a, device=self.device), "recognizer": rec}
+            crit = StrokeFocusLoss(a, device=self.device)
+            self._note_standins(crit)
+            return {"model": model, "crit": crit, "recognizer": rec}
         if getattr(a, "text_focus", False):
             # the reference's criterion for tbsrn / tsrn (interfaces/base.py:143-150): MSE + text-focus terms.  The
             # CRNN stays the eval-time recognizer only, exactly as in the reference.
             from ..loss.text_focus_loss import TextFocusLoss
-            return {"model": model, "crit": TextFocusLoss(a, device=self.device), "recognizer": rec}
+            crit = TextFocusLoss(a, device=self.device)
+            if getattr(a, "text_focus", False):
+                crit.weight_table()                          # resolve confuse.pkl now: a missing file fails at start-up
+            self._note_standins(crit)
+            return {"model": model, "crit": crit, "recognizer": rec}
         return {"model": model, "crit": CTCFocusLoss(rec), "recognizer": rec}
+
+    def _note_standins(self, crit):
+        """stand-in assets (explicit --standin_assets runs only) go into the run's config and log, not just a warning"""
+        used = list(getattr(crit, "standin_assets", []))
+        self.config["standin_assets"] = used
+        if used:
+            self.logging.info("STAND-IN ASSETS in use (benchmark / test run, not a training run): %s" % ", ".join(used))
 
     def optimizer_init(self, model, crit):
         from ..engine import TrainStep

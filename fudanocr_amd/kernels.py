@@ -992,8 +992,11 @@ def attention(q, k, v, heads=4, p_drop=0.0):
 # library call on the weight-gradient side stream.  5 + 5 library calls instead of ~10 + ~25 autograd nodes, and the
 # intermediates between the row-local layers never touch HBM.
 # ----------------------------------------------------------------------------------------
-def fe_chain_supported(feat):
-    return bool(feat.is_cuda and feat.dtype == torch.float32 and feat.dim() == 3 and feat.shape[-1] == 64
+def fe_chain_supported(feat, heads=4, d_model=128):
+    """The fused chains (csrc/fe_chain.hip) are written for 4 heads of 32 over d_model = 128 (fe_bwd_b's accumulator
+    tile j IS head j of D = rowsum(dO * O)); any other geometry takes the per-layer path."""
+    return bool(int(heads) == 4 and int(d_model) == 128
+                and feat.is_cuda and feat.dtype == torch.float32 and feat.dim() == 3 and feat.shape[-1] == 64
                 and _lib.load().focr_fe_chain_supported(feat.shape[0] * feat.shape[1], 128))
 
 
@@ -1181,6 +1184,9 @@ class _FeatureEnhancerFused(torch.autograd.Function):
 
 def feature_enhancer_fused(feat, xres, pe, params, heads=4, p_attn=0.0, p_ffn=0.0, eps=1e-6, defer_residual=False):
     """params: (wqkv [384,128], bqkv, wo, bo, a1, b1, w1, bb1, w2, bb2, a3, b3, wl [64,128], bl) -- tbsrn.py:76-92"""
+    if int(heads) != 4 or tuple(params[0].shape) != (384, 128):
+        raise RuntimeError("feature_enhancer_fused: the fused chains are built for 4 heads of 32 (d_model 128); "
+                           "got heads=%r, wqkv %r -- use the per-layer path (fe_chain_supported)" % (heads, tuple(params[0].shape)))
     return _FeatureEnhancerFused.apply(feat, xres, pe, int(heads), float(p_attn), float(p_ffn), float(eps),
                                        bool(defer_residual), *params)
 
@@ -1200,8 +1206,12 @@ def srb_fused_supported(x, conv1, conv2, bn1, bn2):
     for cv in (conv1, conv2):
         if tuple(cv.weight.shape) != (64, 64, 3, 3) or tuple(cv.padding) != (1, 1) or cv.bias is None:
             return False
+        if _ohwi(cv.weight).data_ptr() != cv.weight.data_ptr():
+            return False          # weights re-laid-out by the caller (not channels_last): the per-layer path copies them
     if not all((bn.training or not bn.track_running_stats) and bn.track_running_stats for bn in (bn1, bn2)):
         return False
+    if any(bn.momentum is None for bn in (bn1, bn2)):
+        return False              # cumulative-average running statistics: per-layer path
     return bool(_halo_ok(h, w, 64, 64, 3, 3, 1, 1) and _lib.load().focr_fe_chain_supported(n * h * w, 128))
 
 

@@ -9,9 +9,13 @@ into the SR network).  Returns the reference's 4-tuple (loss, mse_loss, attentio
 `-1` sentinels for both terms when `args.text_focus` is off.
 
 Neither ./dataset/mydata/english_decomposition.txt nor pretrain_transformer_stroke_decomposition.pth ships with the
-reference.  When the files are absent the decomposition is a seeded stand-in table (`standin_decomposition`: same
-format, every alphanumeric character -> 1-4 strokes) and the recognizer gets the name-keyed deterministic weights: the
-maths, shapes and cost of the step are the reference's, only the learned content is missing -- and that is logged."""
+reference.  As in the reference (stroke_focus_loss.py:31,45) a missing file raises FileNotFoundError: training the SR
+network towards the attention maps of an untrained recognizer over a made-up stroke table is not a run anybody wants
+by accident.  Benchmarks and tests opt in explicitly (`allow_standin=True`, `--standin_assets`, or
+FOCR_ALLOW_STANDIN_ASSETS=1): the decomposition is then a seeded stand-in table (`standin_decomposition`: same format,
+every alphanumeric character -> 1-4 strokes) and the recognizer gets the name-keyed deterministic weights -- the maths,
+shapes and cost of the step are the reference's, only the learned content is missing; `standin_assets` lists what was
+substituted and the harness writes it into the run's log / config."""
 import logging
 import os
 
@@ -33,9 +37,24 @@ def standin_decomposition(seed=2021):
     return {c: "".join(str(int(d)) for d in rs.randint(1, 10, size=int(rs.randint(1, 5)))) for c in chars}
 
 
-def load_decomposition(path="./dataset/mydata/english_decomposition.txt"):
+def standin_allowed(flag=None):
+    """explicit opt-in for stand-in assets: constructor argument, else FOCR_ALLOW_STANDIN_ASSETS=1"""
+    return bool(flag) if flag is not None else os.environ.get("FOCR_ALLOW_STANDIN_ASSETS", "0") == "1"
+
+
+def missing_asset(path, what):
+    return FileNotFoundError("%s not found (%s). The reference needs this file too; pass --standin_assets (or "
+                             "allow_standin=True / FOCR_ALLOW_STANDIN_ASSETS=1) to run on %s instead" % (
+                                 os.path.basename(path), path, what))
+
+
+def load_decomposition(path="./dataset/mydata/english_decomposition.txt", allow_standin=None, used=None):
     if not os.path.isfile(path):
+        if not standin_allowed(allow_standin):
+            raise missing_asset(path, "a seeded stand-in stroke table")
         logging.getLogger(__name__).warning("english_decomposition.txt not found (%s): seeded stand-in stroke table", path)
+        if used is not None:
+            used.append("english_decomposition.txt")
         return standin_decomposition()
     dic = {}
     for line in open(path, "r").readlines():
@@ -47,12 +66,16 @@ def load_decomposition(path="./dataset/mydata/english_decomposition.txt"):
 class StrokeFocusLoss(nn.Module):
     correct_flag = False               # reference :99: the "select correct" branch is switched off
 
-    def __init__(self, args, transformer=None, decomposition=None, device="cuda"):
+    def __init__(self, args, transformer=None, decomposition=None, device="cuda", allow_standin=None):
         super().__init__()
         self.args = args
+        self.allow_standin = allow_standin if allow_standin is not None else (
+            True if getattr(args, "standin_assets", False) else None)
+        self.standin_assets = []                          # names of the assets replaced by stand-ins (run config / log)
         self.english_stroke_alphabet = "0123456789"
         self.english_stroke_dict = {c: i for i, c in enumerate(self.english_stroke_alphabet)}
-        self.dic = dict(decomposition) if decomposition is not None else load_decomposition()
+        self.dic = dict(decomposition) if decomposition is not None else load_decomposition(
+            allow_standin=self.allow_standin, used=self.standin_assets)
         self.device = torch.device(device)
         self._transformer = [transformer]                 # not registered: stays out of state_dict / parameters()
         if getattr(args, "text_focus", False) and transformer is None:
@@ -68,8 +91,11 @@ class StrokeFocusLoss(nn.Module):
             sd = torch.load(path, map_location="cpu")
             t.load_state_dict({k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()})
         else:
+            if not standin_allowed(self.allow_standin):
+                raise missing_asset(path, "name-keyed deterministic recognizer weights")
             logging.getLogger(__name__).warning("pretrain_transformer_stroke_decomposition.pth not found (%s): "
                                                 "name-keyed weights", path)
+            self.standin_assets.append(os.path.basename(path))
             fill_module_(t)
         t = t.to(self.device).eval()
         for p in t.parameters():

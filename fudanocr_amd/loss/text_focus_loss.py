@@ -36,10 +36,17 @@ def str_filt(str_, voc_type):
     return _str_filt(str_, voc_type).lower()          # text_focus_loss.py:25-38 lower-cases once more at the end
 
 
-def load_confuse_matrix(path="./dataset/mydata/confuse.pkl"):
-    """weight table of loss/weight_ce_loss.py:10-33 ([37, 37]; inverse confusion counts, lower/upper case merged)"""
+def load_confuse_matrix(path="./dataset/mydata/confuse.pkl", allow_standin=None, used=None):
+    """weight table of loss/weight_ce_loss.py:10-33 ([37, 37]; inverse confusion counts, lower/upper case merged).
+    A missing file raises (the reference opens it at import, weight_ce_loss.py:35) unless stand-ins are allowed
+    explicitly (stroke_focus_loss.standin_allowed)."""
+    from .stroke_focus_loss import missing_asset, standin_allowed
     if not os.path.isfile(path):
+        if not standin_allowed(allow_standin):
+            raise missing_asset(path, "unit cross-entropy weights")
         logging.getLogger(__name__).warning("confuse.pkl not found (%s): weight_cross_entropy uses unit weights", path)
+        if used is not None:
+            used.append("confuse.pkl")
         return torch.ones(37, 37)
     data = pickle.load(open(path, "rb"))
     number, upper, lower = data[:10], data[10:36], data[36:]
@@ -58,9 +65,12 @@ def load_confuse_matrix(path="./dataset/mydata/confuse.pkl"):
 
 
 class TextFocusLoss(nn.Module):
-    def __init__(self, args, transformer=None, weight_table=None, device="cuda"):
+    def __init__(self, args, transformer=None, weight_table=None, device="cuda", allow_standin=None):
         super().__init__()
         self.args = args
+        self.allow_standin = allow_standin if allow_standin is not None else (
+            True if getattr(args, "standin_assets", False) else None)
+        self.standin_assets = []                          # names of the assets replaced by stand-ins (run config / log)
         self.english_alphabet = standard_alphebet
         self.english_dict = {c: i for i, c in enumerate(self.english_alphabet)}
         self.device = torch.device(device)
@@ -79,7 +89,11 @@ class TextFocusLoss(nn.Module):
             sd = torch.load(path, map_location="cpu")
             t.load_state_dict({k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()})
         else:
+            from .stroke_focus_loss import missing_asset, standin_allowed
+            if not standin_allowed(self.allow_standin):
+                raise missing_asset(path, "name-keyed deterministic recognizer weights")
             logging.getLogger(__name__).warning("pretrain_transformer.pth not found (%s): name-keyed weights", path)
+            self.standin_assets.append(os.path.basename(path))
             fill_module_(t)
         t = t.to(self.device).eval()
         for p in t.parameters():
@@ -88,7 +102,7 @@ class TextFocusLoss(nn.Module):
 
     def weight_table(self):
         if self._table is None:
-            self._table = load_confuse_matrix()
+            self._table = load_confuse_matrix(allow_standin=self.allow_standin, used=self.standin_assets)
         if self._table.device != self.device:
             self._table = self._table.to(self.device).contiguous()
         return self._table

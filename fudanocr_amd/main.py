@@ -28,6 +28,11 @@ def parse(argv=None):
     p.add_argument("--text_focus", action="store_true", help="train with the text-focus loss (loss/text_focus_loss.py) instead of MSE + CRNN-CTC")
     p.add_argument("--stroke_focus", action="store_true", help="text-gestalt's criterion (loss/stroke_focus_loss.py): MSE + stroke_lambda * L1 of the stroke-level recognizer's attention maps when --text_focus is given")
     p.add_argument("--stroke_lambda", type=float, default=50)
+    p.add_argument("--standin_assets", action="store_true",
+                   help="allow --text_focus / --stroke_focus to run WITHOUT the pretrained recognizer, confuse.pkl or "
+                        "english_decomposition.txt (none ships with the reference) on name-keyed weights / unit weights / a "
+                        "seeded stroke table: benchmarking and tests only; without the flag a missing file raises "
+                        "FileNotFoundError as in the reference")
     p.add_argument("--exp_name", required=True, help="Type your experiment name")
     p.add_argument("--test", action="store_true", default=False)
     p.add_argument("--test_data_dir", type=str, default="")

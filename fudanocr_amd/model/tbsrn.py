@@ -135,7 +135,7 @@ class FeatureEnhancer(nn.Module):
         # gradient (defer) and the GEMM's data-gradient kernel adds it in its epilogue (take_deferred) -- see
         # kernels.py "Deferred residual gradients"; three 67 MB gradient-add passes per block disappear.
         g = torch.is_grad_enabled() and conv_feature.requires_grad
-        if _FE_FUSED and K.fe_chain_supported(conv_feature):
+        if _FE_FUSED and K.fe_chain_supported(conv_feature, self.multihead.h, self.multihead.h * self.multihead.d_k):
             # one autograd node for the whole block: the row-local layers run as fused chains (csrc/fe_chain.hip)
             p_attn, p_ffn = self._fused_dropout()
             return K.feature_enhancer_fused(
@@ -189,7 +189,9 @@ class RecurrentResidualBlock(nn.Module):
 
     def forward(self, x):
         g = torch.is_grad_enabled() and x.requires_grad
-        if _SRB_FUSED and _FE_FUSED and K.srb_fused_supported(x, self.conv1, self.conv2, self.bn1, self.bn2):
+        mh = self.feature_enhancer.multihead
+        if (_SRB_FUSED and _FE_FUSED and mh.h == 4 and mh.h * mh.d_k == 128
+                and K.srb_fused_supported(x, self.conv1, self.conv2, self.bn1, self.bn2)):
             # training mode: the whole block is one autograd node (kernels._SRBFused), same library calls
             fe = self.feature_enhancer
             p_attn, p_ffn = fe._fused_dropout()

@@ -113,6 +113,22 @@ def test_bench_multiprocess_path(tmp_path):
     assert res["scaling"] == "weak" and "cpu_baseline" not in res
 
 
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no launcher environment (the shape of the driver's N > 1 bench command when it is
+    not wrapped in torch.distributed.run): bench.py re-launches itself as two ranks and prints ONE JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR",
+                                                              "MASTER_PORT")}
+    env["FOCR_BENCH_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "8"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, p.stdout[-2000:]
+    res = json.loads(line[0])
+    assert res["n_gpus"] == 2 and res["config"]["collective_backend"] == "gloo" and res["value"] > 0
+    assert res["config"]["global_batch"] == 16
+
+
 MAIN_WORKER = r"""
 import os, sys, yaml, torch, torch.distributed as dist
 sys.path.insert(0, %r)

@@ -296,3 +296,22 @@ def test_row_pitch_helper():
     assert K._row_pitch(t[:, :500, :64]) == 0                     # batch stride != rows x pitch: does not collapse
     assert K._row_pitch(t.transpose(1, 2)) == 0                   # last dim not dense
     assert K._row_pitch(torch.zeros(8, 130)[:, :64]) == 0         # pitch not a multiple of 4 floats
+
+
+def test_bench_self_launch_plumbing():
+    """bench.py --gpus 2 without WORLD_SIZE re-launches itself under torch.distributed.run (127.0.0.1 rendezvous);
+    --check-launch keeps the ranks off the GPU: join (gloo), one all-reduce, ONE JSON line from rank 0."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR",
+                                                              "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--check-launch"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["collective_backend"] == "gloo"
+    # a mismatching launcher environment is refused, not silently run at the wrong size
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--check-launch"],
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=2" in (p.stdout + p.stderr)

@@ -167,8 +167,13 @@ def test_harness_trains_with_text_focus(tmp_path, monkeypatch):
     cfg = AttrDict(yaml.load(open(os.path.join(os.path.dirname(M.__file__), "config", "super_resolution.yaml")),
                              Loader=yaml.Loader))
     cfg.TRAIN.iters_per_epoch, cfg.TRAIN.displayInterval, cfg.TRAIN.saveInterval = 2, 1, 100
-    res = M.main(cfg, M.parse(["--arch", "tbsrn", "--STN", "--exp_name", "tf", "--batch_size", "4", "--text_focus"]))
+    res = M.main(cfg, M.parse(["--arch", "tbsrn", "--STN", "--exp_name", "tf", "--batch_size", "4", "--text_focus",
+                              "--standin_assets"]))
     assert res["images_per_sec"] > 0
+    assert set(cfg["standin_assets"]) == {"pretrain_transformer.pth", "confuse.pkl"}
+    # without the explicit opt-in the missing assets are an error, as in the reference (text_focus_loss.py:56-58)
+    with pytest.raises(FileNotFoundError):
+        M.main(cfg, M.parse(["--arch", "tbsrn", "--STN", "--exp_name", "tf2", "--batch_size", "4", "--text_focus"]))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -205,6 +210,34 @@ def test_stroke_oracle_matches_reference_fixture(golden_dir):
         assert _rel(pred4, g["pred4"]) < 1e-4
         _, _, c_mixed = O.stroke_recognizer(P, O.to_gray(sr.detach()), length, torch.tensor(sc["text_input_mixed"]))
     assert c_mixed == sc["correct_mixed"] and any(c_mixed) and not all(c_mixed)
+
+
+def test_missing_focus_assets_raise_unless_opted_in(tmp_path, monkeypatch):
+    """reference stroke_focus_loss.py:31,45 / text_focus_loss.py:56-58 / weight_ce_loss.py:35: a missing decomposition
+    table, recognizer checkpoint or confusion matrix is an error; the stand-ins need an explicit opt-in and are recorded"""
+    import types
+    from fudanocr_amd.loss import stroke_focus_loss as S
+    from fudanocr_amd.loss import text_focus_loss as T
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.delenv("FOCR_ALLOW_STANDIN_ASSETS", raising=False)
+    with pytest.raises(FileNotFoundError, match="english_decomposition.txt"):
+        S.load_decomposition()
+    with pytest.raises(FileNotFoundError, match="confuse.pkl"):
+        T.load_confuse_matrix()
+    with pytest.raises(FileNotFoundError):
+        S.StrokeFocusLoss(types.SimpleNamespace(text_focus=False), device="cpu")
+    used = []
+    assert len(S.load_decomposition(allow_standin=True, used=used)) == 62 and used == ["english_decomposition.txt"]
+    assert T.load_confuse_matrix(allow_standin=True, used=used).shape == (37, 37) and used[-1] == "confuse.pkl"
+    monkeypatch.setenv("FOCR_ALLOW_STANDIN_ASSETS", "1")
+    crit = S.StrokeFocusLoss(types.SimpleNamespace(text_focus=False), device="cpu")
+    assert crit.standin_assets == ["english_decomposition.txt"]
+    # a real table on disk is used as it is and nothing is recorded
+    os.makedirs(tmp_path / "dataset" / "mydata")
+    (tmp_path / "dataset" / "mydata" / "english_decomposition.txt").write_text("a 12\nb 3\n")
+    monkeypatch.delenv("FOCR_ALLOW_STANDIN_ASSETS")
+    crit = S.StrokeFocusLoss(types.SimpleNamespace(text_focus=False), device="cpu")
+    assert crit.dic == {"a": "12", "b": "3"} and crit.standin_assets == []
 
 
 def test_stroke_standin_table_and_encoder_host_logic():

@@ -55,8 +55,16 @@ int main(int argc, char** argv) {
   uint32_t* mask; CK(hipMalloc(&mask, (size_t)B * H * N * (N / 32) * 4));
   const float scale = 1.f / sqrtf(32.f);
   const double fl = 4.0 * B * H * (double)N * N * 32;
+  const bool only_b1 = argc > 4 && !strcmp(argv[4], "b1");      // single-pass backward section only
   for (float p : {0.1f, 0.0f}) {
     float t0 = 1e9f, t1 = 1e9f;
+    if (only_b1) {
+      g_tune[FOCR_TUNE_ATTN_FWD_VARIANT] = 1;
+      focr_attention_fwd(q, k, v, o0, lse0, mask, B, H, N, D, D, scale, p, 1234, 0);
+      g_tune[FOCR_TUNE_ATTN_BWD_DQ_VARIANT] = 1;
+      focr_attention_bwd(q, k, v, o0, dO, lse0, mask, dq1, dk1, dv1, work, B, H, N, D, D, scale, p, 0);
+    }
+    if (!only_b1) {
     for (int rep = 0; rep < 3; ++rep) {                 // A B A B A B: best of three each (box clocks drift)
       g_tune[FOCR_TUNE_ATTN_FWD_VARIANT] = V0;
       focr_attention_fwd(q, k, v, o0, lse0, mask, B, H, N, D, D, scale, p, 1234, 0);
@@ -82,6 +90,29 @@ int main(int argc, char** argv) {
     double eq = maxdiff(dq0, dq1, n, &m1), ek = maxdiff(dk0, dk1, n, &m2), ev = maxdiff(dv0, dv1, n, &m3);
     printf("bwd p=%.1f: variant0 %7.1f us  variant1 %7.1f us  max diff dq %.2e/%.2e dk %.2e/%.2e dv %.2e/%.2e\n", p, b0, b1, eq, m1, ek, m2, ev, m3);
     fflush(stdout);
+    }
+    {   // single-pass backward (variant 2) against the two-pass result of variant 1 (dq0 / dk0 / dv0 hold variant 0, dq1.. variant 1)
+      float *dq2 = dalloc(n, 0, 0), *dk2 = dalloc(n, 0, 0), *dv2 = dalloc(n, 0, 0);
+      CK(hipMemset(dq2, 0xff, n * 4)); CK(hipMemset(dk2, 0xff, n * 4)); CK(hipMemset(dv2, 0xff, n * 4));
+      g_tune[FOCR_TUNE_ATTN_BWD_DQ_VARIANT] = 2;
+      int rc2 = focr_attention_bwd(q, k, v, nullptr, dO, lse0, mask, dq2, dk2, dv2, work, B, H, N, D, D, scale, p, 0);
+      CK(hipDeviceSynchronize());
+      if (rc2) { printf("single-pass bwd failed %d\n", rc2); return 1; }
+      float t2 = 1e9f, t1b = 1e9f;
+      for (int rep = 0; rep < 3; ++rep) {
+        g_tune[FOCR_TUNE_ATTN_BWD_DQ_VARIANT] = 1;
+        t1b = std::min(t1b, timeit([&]() { focr_attention_bwd(q, k, v, nullptr, dO, lse0, mask, dq1, dk1, dv1, work, B, H, N, D, D, scale, p, 0); }, 6));
+        g_tune[FOCR_TUNE_ATTN_BWD_DQ_VARIANT] = 2;
+        t2 = std::min(t2, timeit([&]() { focr_attention_bwd(q, k, v, nullptr, dO, lse0, mask, dq2, dk2, dv2, work, B, H, N, D, D, scale, p, 0); }, 6));
+      }
+      CK(hipDeviceSynchronize());
+      double n1, n2, n3;
+      double fq = maxdiff(dq1, dq2, n, &n1), fk = maxdiff(dk1, dk2, n, &n2), fv = maxdiff(dv1, dv2, n, &n3);
+      printf("bwd1 p=%.1f: two-pass (no prep) %7.1f us  single-pass %7.1f us  max diff dq %.2e/%.2e dk %.2e/%.2e dv %.2e/%.2e\n", p, t1b, t2, fq, n1, fk, n2, fv, n3);
+      fflush(stdout);
+      CK(hipFree(dq2)); CK(hipFree(dk2)); CK(hipFree(dv2));
+    }
+    if (only_b1) continue;
     // ---- pre-split operand planes (PL kernel variants) against the fp32-input kernels above (variant 1 / dq2)
     {
       const long rows = (long)B * N;
