@@ -114,67 +114,106 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_bx3_kernel(
   float* const lsds = reinterpret_cast<float*>(b1_smem + B1_OFF_LS);
 
   // ---- dQ^T[d][q] += K^T[d][key] dS^T[key][q] over the chunk's 256 keys for the tile of iteration `jt` (T buffer jt & 1):
-  // 8 x v_mfma_f32_16x16x32_bf16 per wave, two accumulator chains.  `prev` = the float4 this lane wrote one chunk earlier.
-  auto dq_phase = [&](int jt, float4 prev, bool have_prev) {
-#ifndef B1_ABL_DQ
+  // 8 x v_mfma_f32_16x16x32_bf16 per wave, two accumulator chains.  Split in request / product halves so that the tile
+  // code below can place them where the LDS latency and the matrix-pipe time are covered.
+  struct DqFrag { bf16x8 a[4], b[4]; };
+  using I0 = std::integral_constant<int, 0>; using I8 = std::integral_constant<int, 8>; using I16 = std::integral_constant<int, 16>;
+  using I12 = std::integral_constant<int, 12>;
+  auto dq_request = [&](int jt, int half, DqFrag& f) {
     const unsigned char* Tr = b1_smem + B1_OFF_T + (jt & 1) * B1_T_BYTES;
     const unsigned char* Kt = b1_smem + B1_OFF_KT + ktoff;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s8 = 0; s8 < 8; s8 += 2) {
-      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(Kt + 16 * s8);
-      const bf16x8 b0 = cat44(b1_tr_read(Tr + toff0 + 4096 * s8), b1_tr_read(Tr + toff1 + 4096 * s8));
-      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(Kt + 16 * (s8 + 1));
-      const bf16x8 b1 = cat44(b1_tr_read(Tr + toff0 + 4096 * (s8 + 1)), b1_tr_read(Tr + toff1 + 4096 * (s8 + 1)));
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc1, 0, 0, 0);
+    for (int j = 0; j < 4; ++j) {
+      const int s8 = 4 * half + j;
+      f.a[j] = *reinterpret_cast<const bf16x8*>(Kt + 16 * s8);
+      f.b[j] = cat44(b1_tr_read(Tr + toff0 + 4096 * s8), b1_tr_read(Tr + toff1 + 4096 * s8));
     }
-    const int qj = jt % nq;
-    float* const row = dqp + (size_t)(qj * 64) * ldg;
+  };
+  auto dq_product = [&](const DqFrag& f, f32x4& acc0, f32x4& acc1) {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[0], f.b[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[1], f.b[1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[2], f.b[2], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[3], f.b[3], acc1, 0, 0, 0);
+  };
+  auto dq_store = [&](int jt, const f32x4& acc0, const f32x4& acc1, float4 prev, bool have_prev) {
+    float* const row = dqp + (size_t)((jt % nq) * 64) * ldg;
     if (!have_prev) prev = make_float4(0.f, 0.f, 0.f, 0.f);      // (a select, not a branch)
     *reinterpret_cast<float4*>(row) =
         make_float4(fmaf(acc0[0] + acc1[0], scale, prev.x), fmaf(acc0[1] + acc1[1], scale, prev.y),
                     fmaf(acc0[2] + acc1[2], scale, prev.z), fmaf(acc0[3] + acc1[3], scale, prev.w));
-#endif
+  };
+  auto dq_phase = [&](int jt, float4 prev, bool have_prev) {       // the whole product in one go (chunk boundaries, tail)
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    DqFrag f;
+    dq_request(jt, 0, f);
+    dq_product(f, acc0, acc1);
+    dq_request(jt, 1, f);
+    dq_product(f, acc0, acc1);
+    dq_store(jt, acc0, acc1, prev, have_prev);
   };
 
-  // ---- S, dP, dS, dV, dK of one 32-query sub-tile of the staged tile (buffer p); dS -> T[p]
-  auto sub_tile = [&](int p, int sub, uint32_t mcur) {
-    const __bf16* st = reinterpret_cast<const __bf16*>(b1_smem + p * B1_STAGE);
-    const __bf16 *Qh = st, *Ql = st + 64 * RP, *Gh = st + 2 * 64 * RP, *Gl = st + 3 * 64 * RP;
-    const __bf16 *Qth = st + 4 * 64 * RP, *Gth = Qth + 32 * TP;
+  // ---- pieces of one 32-query sub-tile (S, dP, dS, dV, dK; dS -> T[p]) of the staged tile in buffer p
+  struct RowFrag { bf16x8 qh[2], ql[2], gh[2], gl[2]; };
+  auto st_ptr = [&](int p) { return reinterpret_cast<const __bf16*>(b1_smem + p * B1_STAGE); };
+  // s starts at -LSE of its query row (register r <-> query key_of_b(r, lh)): the MFMAs deliver s - lse for free
+  auto req_lse = [&](int p, int sub, f32x16& s) {
     const float* Ls = lsds + p * 64;
-    const float* Ds = Ls + 128;
-    unsigned char* const Tb = b1_smem + B1_OFF_T + p * B1_T_BYTES;
-    // s starts at -LSE of its query row (register r <-> query key_of_b(r, lh)): the MFMAs deliver s - lse for free
-    f32x16 s, dp;
-    float dd[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const float4 l4 = *reinterpret_cast<const float4*>(&Ls[sub * 32 + 8 * g + 4 * lh]);
-      const float4 d4 = *reinterpret_cast<const float4*>(&Ds[sub * 32 + 8 * g + 4 * lh]);
       s[4 * g] = l4.x; s[4 * g + 1] = l4.y; s[4 * g + 2] = l4.z; s[4 * g + 3] = l4.w;
+    }
+  };
+  auto req_d = [&](int p, int sub, float (&dd)[16]) {
+    const float* Ds = lsds + 128 + p * 64;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 d4 = *reinterpret_cast<const float4*>(&Ds[sub * 32 + 8 * g + 4 * lh]);
       dd[4 * g] = d4.x; dd[4 * g + 1] = d4.y; dd[4 * g + 2] = d4.z; dd[4 * g + 3] = d4.w;
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+  };
+  auto req_rows = [&](int p, int sub, RowFrag& f) {
+    const __bf16* st = st_ptr(p);
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       const int off = (sub * 32 + li) * RP + 16 * m + 8 * lh;
-      bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Qh[off]), al = *reinterpret_cast<const bf16x8*>(&Ql[off]);
-      bf16x8 gh = *reinterpret_cast<const bf16x8*>(&Gh[off]), gl = *reinterpret_cast<const bf16x8*>(&Gl[off]);
-#ifdef B1_ABL_MFMA12
-      s[0] += (float)ah[0] + (float)al[1]; dp[0] += (float)kh[m][0] + (float)kl[m][0];
-      s[1] += (float)gh[0] + (float)gl[1]; dp[1] += (float)vh[m][0] + (float)vl[m][0];
-#else
-      MFMA3(s, ah, al, kh[m], kl[m]);
-      MFMA3(dp, gh, gl, vh[m], vl[m]);
-#endif
+      f.qh[m] = *reinterpret_cast<const bf16x8*>(&st[off]);
+      f.ql[m] = *reinterpret_cast<const bf16x8*>(&st[64 * RP + off]);
+      f.gh[m] = *reinterpret_cast<const bf16x8*>(&st[2 * 64 * RP + off]);
+      f.gl[m] = *reinterpret_cast<const bf16x8*>(&st[3 * 64 * RP + off]);
     }
+  };
+  struct ColFrag { bf16x8 qt[2], gt[2]; };
+  auto req_cols = [&](int p, int sub, ColFrag& f) {
+    const __bf16 *Qth = st_ptr(p) + 4 * 64 * RP, *Gth = Qth + 32 * TP;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int qc = sub * 32 + 16 * m + 4 * lh;
+      f.gt[m] = cat44(*reinterpret_cast<const bf16x4*>(&Gth[li * TP + qc]), *reinterpret_cast<const bf16x4*>(&Gth[li * TP + qc + 8]));
+      f.qt[m] = cat44(*reinterpret_cast<const bf16x4*>(&Qth[li * TP + qc]), *reinterpret_cast<const bf16x4*>(&Qth[li * TP + qc + 8]));
+    }
+  };
+  // the 12 score / dP products, alternating between the two accumulators (consecutive MFMAs are independent: other
+  // instructions may sit between them at no cost)
+#define B1_MFMA_PAIR(s_, dp_, f_, m_, A_, B_)                                                                   \
+  do {                                                                                                          \
+    s_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_ ? f_.ql[m_] : f_.qh[m_], B_ ? kl[m_] : kh[m_], s_, 0, 0, 0);   \
+    dp_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_ ? f_.gl[m_] : f_.gh[m_], B_ ? vl[m_] : vh[m_], dp_, 0, 0, 0); \
+  } while (0)
+  auto scores = [&](f32x16& s, f32x16& dp, const RowFrag& f) {
+#ifndef B1_ABL_MFMA12
+    B1_MFMA_PAIR(s, dp, f, 0, 0, 0); B1_MFMA_PAIR(s, dp, f, 0, 0, 1); B1_MFMA_PAIR(s, dp, f, 0, 1, 0);
+    B1_MFMA_PAIR(s, dp, f, 1, 0, 0); B1_MFMA_PAIR(s, dp, f, 1, 0, 1); B1_MFMA_PAIR(s, dp, f, 1, 1, 0);
+#else
+    s[0] += (float)f.qh[0][0] + (float)f.ql[1][1]; dp[0] += (float)f.gh[0][0] + (float)f.gl[1][0];
+#endif
+  };
+  // dS = P (M dP' - D) = (M P) dP' - P D with M the keep mask: one AND instead of two, the rest an fma.  On return s
+  // holds M P (the dV operand), dp holds dS.  Registers [lo, hi).
+  auto softmax_grad = [&](f32x16& s, f32x16& dp, const float (&dd)[16], uint32_t mcur, auto lo, auto hi) {
 #ifndef B1_ABL_VALU
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      // dS = P (M dP' - D) = (M P) dP' - P D with M the keep mask: one AND instead of two, the rest an fma
+    for (int r = decltype(lo)::value; r < decltype(hi)::value; ++r) {
       const float pr = __builtin_amdgcn_exp2f(s[r]);
       float pd = pr;
       if (DROPOUT) {
@@ -185,20 +224,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_bx3_kernel(
       dp[r] = fmaf(pd, dp[r], -pr * dd[r]);
     }
 #else
-    dp[0] += dd[0] + dd[5] + dd[10] + dd[15];
+    if (decltype(lo)::value == 0) dp[0] += dd[0] + dd[5] + dd[10] + dd[15];
 #endif
+  };
+  auto grads = [&](int p, int sub, const f32x16& s, const f32x16& dp, const ColFrag& f) {
+    unsigned char* const Tb = b1_smem + B1_OFF_T + p * B1_T_BYTES;
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      const int qc = sub * 32 + 16 * m + 4 * lh;
-      const bf16x8 gth = cat44(*reinterpret_cast<const bf16x4*>(&Gth[li * TP + qc]),
-                               *reinterpret_cast<const bf16x4*>(&Gth[li * TP + qc + 8]));
-      const bf16x8 qth = cat44(*reinterpret_cast<const bf16x4*>(&Qth[li * TP + qc]),
-                               *reinterpret_cast<const bf16x4*>(&Qth[li * TP + qc + 8]));
       bf16x8 ph, sh;
       hi_regs(s, m, ph);
       hi_regs(dp, m, sh);
-      MFMA1(dvacc, gth, ph);
-      MFMA1(dkacc, qth, sh);
+      MFMA1(dvacc, f.gt[m], ph);
+      MFMA1(dkacc, f.qt[m], sh);
       // registers 8 m .. 8 m + 3 / + 4 .. + 7 = queries 8 g + 4 lh + (0 .. 3) of the sub-tile, g = 2 m / 2 m + 1
       const uint4 w = __builtin_bit_cast(uint4, sh);
 #ifndef B1_ABL_T
@@ -208,6 +245,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_bx3_kernel(
     }
   };
 
+#ifdef B1_PRIO
+  if (__builtin_amdgcn_readfirstlane(ten) != 0) __builtin_amdgcn_s_setprio(1);
+#endif
   B1_LOAD(0);
   B1_STORE(0);
   for (int kc = 0; kc < nkc; ++kc) {
@@ -258,9 +298,78 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_bx3_kernel(
       B1_LOAD(nxt);
 #endif
       __builtin_amdgcn_sched_barrier(0);         // keep the requests up here (the scheduler sinks them to their uses)
-      if constexpr (decltype(with_dq)::value) dq_phase(it - 1, prev, kc > 0);
-      sub_tile(p, 0, mcur0);
-      sub_tile(p, 1, mcur1);
+      constexpr bool WDQ = decltype(with_dq)::value;
+      // ---- a hand-ordered software pipeline (sched_barrier between the stages keeps hipcc from re-serialising it):
+      // every LDS request is issued a stage before its consumer, and the VALU work of sub-tile 0 (exp2, keep bit, dS)
+      // sits between the score MFMAs of sub-tile 1
+      f32x16 s0, dp0, s1, dp1;
+      float dd0[16], dd1[16];
+      RowFrag rf;
+      ColFrag cf;
+      DqFrag qf;
+      f32x4 qa0, qa1;
+      // stage A: requests of sub-tile 0
+      req_lse(p, 0, s0);
+      req_rows(p, 0, rf);
+      req_d(p, 0, dd0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp0[r] = 0.f;
+      __builtin_amdgcn_sched_barrier(0);
+      // stage B: scores of sub-tile 0; requests: sub-tile 1's rows
+      scores(s0, dp0, rf);
+      req_lse(p, 1, s1);
+      req_rows(p, 1, rf);
+      __builtin_amdgcn_sched_barrier(0);
+      // stage C: VALU of sub-tile 0 between the score MFMAs of sub-tile 1
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp1[r] = 0.f;
+      scores(s1, dp1, rf);
+      softmax_grad(s0, dp0, dd0, mcur0, I0{}, I12{});
+#if !defined(B1_ABL_VALU) && !defined(B1_ABL_MFMA12) && !defined(B1_NO_GROUPS)
+      // MFMA = 0x8, VALU = 0x2, TRANS = 0x400: one matrix instruction, then one score register's VALU work (12 of 16 registers here)
+#define B1_GROUP                                                   \
+  __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                 \
+  __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);               \
+  __builtin_amdgcn_sched_group_barrier(0x2, DROPOUT ? 4 : 2, 0);
+      B1_GROUP B1_GROUP B1_GROUP B1_GROUP B1_GROUP B1_GROUP B1_GROUP B1_GROUP B1_GROUP B1_GROUP B1_GROUP B1_GROUP
+#undef B1_GROUP
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      // (the column fragments are requested only now -- sub-tile 1's row fragments have just died -- and the last quarter
+      // of the VALU work covers their latency)
+      req_cols(p, 0, cf);
+      req_d(p, 1, dd1);
+      __builtin_amdgcn_sched_barrier(0);
+      softmax_grad(s0, dp0, dd0, mcur0, I12{}, I16{});
+      __builtin_amdgcn_sched_barrier(0);
+      // stage D: dV / dK of sub-tile 0, dS -> T; requests: sub-tile 1's columns, first half of the pending dQ product
+      grads(p, 0, s0, dp0, cf);
+      req_cols(p, 1, cf);
+#ifndef B1_ABL_DQ
+      if constexpr (WDQ) dq_request(it - 1, 0, qf);
+#endif
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { qa0[r] = 0.f; qa1[r] = 0.f; }
+      __builtin_amdgcn_sched_barrier(0);
+      // stage E: VALU of sub-tile 1 -- the one stretch without score MFMAs of its own -- around the pending dQ product of
+      // the PREVIOUS tile (its T buffer is complete since the last barrier)
+      softmax_grad(s1, dp1, dd1, mcur1, I0{}, I8{});
+#ifndef B1_ABL_DQ
+      if constexpr (WDQ) {
+        dq_product(qf, qa0, qa1);
+        __builtin_amdgcn_sched_barrier(0);
+        dq_request(it - 1, 1, qf);
+      }
+#endif
+      softmax_grad(s1, dp1, dd1, mcur1, I8{}, I16{});
+#ifndef B1_ABL_DQ
+      if constexpr (WDQ) {
+        dq_product(qf, qa0, qa1);
+        dq_store(it - 1, qa0, qa1, prev, kc > 0);
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      grads(p, 1, s1, dp1, cf);
 #ifndef B1_ABL_STAGE
       B1_STORE(p ^ 1);
 #endif
