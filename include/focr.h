@@ -47,7 +47,9 @@ int focr_set_precision(int mode);
  * kernels).  key 0: transformer-linear weight gradients on the streaming kernel (1, default) or the generic split
  * kernel (0); key 1: attention forward with 256-query (1, default) / 128-query (0) blocks / look-ahead scores (2);
  * key 2: persistent LSTM scan, one launch per layer (1, default) or one launch per time step (0);
- * key 3: attention dQ pass with 256-query (1, default) or 128-query (0) blocks. */
+ * key 3: attention backward: 2 (default) = single pass, dQ / dK / dV from one S / dP evaluation (precision modes 2 / 3
+ * and Ntok % 256 == 0, otherwise as 1); 1 = two passes (dK/dV, then dQ with 256-query blocks); 0 = two passes,
+ * 128-query dQ blocks. */
 int focr_set_tuning(int key, int value);
 int focr_get_tuning(int key);
 int focr_get_precision(void);

@@ -378,6 +378,57 @@ def test_attention_dropout_exact_against_extracted_mask(precision):
     close(vd.grad, v.grad, gtol(precision), what="attn dropout dv")
 
 
+@pytest.mark.parametrize("p", [0.0, 0.1])
+@pytest.mark.parametrize("t", [256, 1024])
+def test_attention_backward_single_pass(p, t):
+    """csrc/attention_bwd1_bx3.h (tuning key 3 = 2, the default in precision modes 2 / 3): dQ, dK, dV from ONE S / dP
+    evaluation.  Against an fp64 reference that uses the very keep bits the forward wrote (t = 1024: four 256-key chunks,
+    dQ accumulated across them in its output rows; packed [B, T, 384] operands as in the training step), and against the
+    two-pass kernels on the same inputs: dK / dV bit-identical (same arithmetic in the same order), dQ within bf16
+    rounding of the summands (the two-pass dQ kernel forms dS in the transposed orientation)."""
+    from fudanocr_amd import _lib
+    from fudanocr_amd.kernels import _AttentionPacked
+    _lib.set_precision(2)
+    b = 2
+    try:
+        qkv = rnd(b, t, 384, seed=11, scale=1.5).requires_grad_(True)
+        go = rnd(b, t, 128, seed=4)
+        res = {}
+        for variant in (2, 1):
+            _lib.call("focr_set_tuning", 3, variant)
+            x = dev(qkv).requires_grad_(True)
+            od = _AttentionPacked.apply(x, 4, p, 4242)
+            words = od.grad_fn.saved_tensors[3] if p > 0 else None
+            od.backward(dev(go))
+            res[variant] = (od.detach().cpu(), x.grad.detach().cpu())
+        assert _lib.load().focr_get_tuning(3) == 1
+        q, k, v = qkv[..., :128], qkv[..., 128:256], qkv[..., 256:]
+        heads = lambda z: z.reshape(b, t, 4, 32).transpose(1, 2)
+        pr = torch.softmax(heads(q) @ heads(k).transpose(-1, -2) / math.sqrt(32), -1)
+        if p > 0:
+            ng = t // 32
+            w = words.cpu().to(torch.int64) & 0xFFFFFFFF
+            slot = torch.arange(32)
+            key_of_slot = ((slot >> 1) & 3) + 8 * (slot >> 3) + 4 * (slot & 1)
+            bits = (w.unsqueeze(-1) >> torch.arange(32)) & 1
+            dense = torch.zeros(b, 4, ng, ng, 32, 32, dtype=torch.int64)
+            dense[:, :, :, :, key_of_slot, :] = bits
+            keep = dense.permute(0, 1, 2, 5, 3, 4).reshape(b, 4, t, t).double()
+            pr = pr * keep / (1 - round(p * 4096) * 16 / 65536)
+        o = (pr @ heads(v)).transpose(1, 2).reshape(b, t, 128)
+        o.backward(go)
+        o1, g1 = res[2]
+        o2, g2 = res[1]
+        assert torch.equal(o1, o2)
+        close(o1, o, ptol(2), what="single-pass: forward")
+        close(g1, qkv.grad, gtol(2), what="single-pass: d qkv vs fp64")
+        assert torch.equal(g1[..., 128:], g2[..., 128:]), "dK / dV of the single-pass and two-pass kernels differ"
+        close(g1[..., :128], g2[..., :128], 4e-3, what="single-pass dQ vs two-pass dQ")
+    finally:
+        _lib.call("focr_set_tuning", 3, 2)
+        _lib.set_precision(2)
+
+
 @pytest.mark.parametrize("act", [0, 1, 4])
 @pytest.mark.parametrize("training", [True, False])
 def test_batchnorm(act, training):
