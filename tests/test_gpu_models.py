@@ -387,7 +387,27 @@ def test_train_gradients_elementwise_vs_oracle(with_ctc, prec_mode):
     oloss, _, _, _ = O.step_loss(P, "tbsrn", lr, hr, C, tgt, tlen, True, 0.0, 5, True)
     (oloss * 100).backward()
     assert abs(loss.item() - oloss.item()) < 1e-3 * abs(oloss.item())
+    # the same oracle in float64 = the arbitration: the fp32 oracle is itself one fp32 implementation of a B = 4
+    # BatchNorm chain that amplifies rounding, so "HIP vs fp32 oracle" mixes two errors.  Per parameter:
+    #   err(HIP, fp64) <= 2 x err(fp32 oracle, fp64) + allowance(mode)
+    # Measured (gpurun_out/test_margins.txt): in modes 1 / 2 the worst HIP gradient is EXACTLY as far from the fp64 truth
+    # as the fp32 oracle is (block6 pff.w_1.weight: 8.12e-3 vs 8.10e-3; pff.w_1.bias 6.6e-3 vs 8.3e-3) -- the 6-8e-3 that
+    # does not move between the arithmetic modes is fp32-vs-fp32 noise of the B = 4 BatchNorm chain, not kernel error;
+    # allowance 2e-3 (a floor for parameters on which the fp32 oracle happens to be exact).  Mode 3 rounds the operands
+    # of the 3x3 data-gradient convolutions to bf16 (up to ten of them in a chain above block2): 4e-3 .. 7.4e-3 on
+    # block2's parameters where the fp32 oracle is at 9e-4 -- allowance 7e-3, the price of that mode, stated here.
+    P64 = {k: (v.detach().double().requires_grad_(v.requires_grad) if v.is_floating_point() else v) for k, v in P.items()}
+    C64 = None if C is None else {k: (v.double() if v.is_floating_point() else v) for k, v in C.items()}
+    pe0 = O.positional_encoding_2d
+    O.positional_encoding_2d = lambda *a: pe0(*a).double()
+    try:
+        l64, _, _, _ = O.step_loss(P64, "tbsrn", lr.double(), hr.double(), C64, tgt, tlen, True, 0.0, 5, True)
+        (l64 * 100).backward()
+    finally:
+        O.positional_encoding_2d = pe0
+    assert abs(loss.item() - l64.item()) < 1e-3 * abs(l64.item())
     checked, bad, errs = 0, [], []
+    bad64, pairs = [], []
     for name, p in net.named_parameters():
         if not (name.startswith("block") and ".gru" not in name and any(name.endswith(sfx) for sfx in SMOOTH_PARAMS)):
             continue
@@ -402,10 +422,18 @@ def test_train_gradients_elementwise_vs_oracle(with_ctc, prec_mode):
         # rounding of zero differs between any two fp32 implementations -> that one parameter kind gets 1.5e-2
         if not e <= (1.5e-2 if name.endswith(".pff.w_1.bias") else 1e-2):
             bad.append((name, e))
-    _note("gradients_elementwise ctc=%s mode %d: %d parameters, worst %s" % (
-        with_ctc, prec_mode, checked, sorted(errs, key=lambda t: -t[1])[:3]))
+        truth = P64[name].grad
+        e_hip, e_o32 = rel_to_max(p.grad, truth), rel_to_max(ref, truth)
+        pairs.append((name, e_hip, e_o32))
+        if not e_hip <= 2.0 * e_o32 + (7e-3 if prec_mode == 3 else 2e-3):
+            bad64.append((name, e_hip, e_o32))
+    worst = sorted(pairs, key=lambda t: -t[1])[:3]
+    _note("gradients_elementwise ctc=%s mode %d: %d parameters, worst vs fp32 oracle %s; vs fp64 oracle (HIP, fp32 oracle) %s"
+          % (with_ctc, prec_mode, checked, sorted(errs, key=lambda t: -t[1])[:3],
+             [(n, "%.2e" % a, "%.2e" % b) for n, a, b in worst]))
     assert checked >= 60, checked
     assert not bad, bad[:10]
+    assert not bad64, ("HIP gradient further from the fp64 oracle than 2 x the fp32 oracle + allowance", bad64[:10])
 
 
 def test_traj_fixed_batch_vs_oracle(prec_mode):
