@@ -36,7 +36,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak; the bf16x3 split issue
 # algorithmic fwd+bwd flops per image
 FLOP_PER_IMG = {"c3": 18.131e9, "c1": 5.366e9 + 2.820e9, "c2": 15.311e9, "c5": 94.667e9}
 DEFAULT_BATCH = {"c3": 128, "c1": 128, "c2": 64, "c5": 32}
-PMC_ARTEFACT = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+PMC_ARTEFACT = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
 
 
 def _cpu_model():
@@ -400,8 +400,12 @@ def main():
                     fa * len(fwd), 0.0, sum(fwd), len(fwd), 3 if bx3 else 1)
             r["launches_per_step"] = len(fwd) // args.steps
             also.append(r)
-            r = row("attention backward (dK/dV + dQ launches; 2.5x the forward flops)", 2.5 * fa * len(bwd), 0.0,
-                    sum(bwd), len(bwd), 3 if bx3 else 1)
+            single = mode >= 2 and _lib.load().focr_get_tuning(3) == 2
+            r = row("attn_bwd1_bx3_kernel (single pass: dQ, dK, dV from ONE S / dP evaluation; 2.5x the forward flops)"
+                    if single else "attention backward (dK/dV + dQ launches; 2.5x the forward flops)",
+                    2.5 * fa * len(bwd), 0.0, sum(bwd), len(bwd),
+                    # executed MFMA flops per algorithmic flop: S and dP split (3 products), dV / dK / dQ single bf16
+                    (6 + 6 + 2 + 2 + 2) / 10.0 if single else (3 if bx3 else 1))
             r["launches_per_step"] = len(bwd) // args.steps
             also.append(r)
         # fused FeatureEnhancer row chains (csrc/fe_chain.hip): HBM-bound; algorithmic bytes = the [rows, 128] fp32

@@ -1111,14 +1111,23 @@ def test_feature_enhancer_fused_dropout_statistics():
 
 
 def test_attention_planes_c_abi(precision):
-    """focr_attention_make_planes + focr_attention_planes_fwd / _bwd against the fp32-input entry points on the same
-    keep bits: forward and dQ identical (the split is the same arithmetic), dK / dV equal up to where the dropout scale
-    is applied (bf16-level in modes 2 / 3)"""
+    """focr_attention_make_planes + focr_attention_planes_fwd / _bwd.  (1) Oracle leg: against a float64 reference that uses
+    the very keep bits the forward wrote (forward and all three gradients).  (2) Against the fp32-input TWO-PASS entry
+    points on the same keep bits (tuning key 3 = 1): forward and dQ identical (the split is the same arithmetic), dK / dV
+    equal up to where the dropout scale is applied (bf16-level in modes 2 / 3)."""
     import ctypes
     from fudanocr_amd import _lib
     if precision == 0:
         pytest.skip("the PL kernel variants are bf16x3 kernels")
     lib = _lib.load()
+    _lib.call("focr_set_tuning", 3, 1)
+    try:
+        _attention_planes_body(precision, lib, _lib, ctypes)
+    finally:
+        _lib.call("focr_set_tuning", 3, 2)
+
+
+def _attention_planes_body(precision, lib, _lib, ctypes):
     b, h, t, d = 2, 4, 1024, 128
     rows = b * t
     assert lib.focr_attention_planes_supported(h, t, d) == 1 and lib.focr_attention_planes_supported(h, 1000, d) == 0
@@ -1151,3 +1160,21 @@ def test_attention_planes_c_abi(precision):
     close(g1[0], g0[0], 1e-6, "planes dq")
     close(g1[1], g0[1], gtol(precision), "planes dk")
     close(g1[2], g0[2], 5e-3 if precision >= 2 else 1e-4, "planes dv")
+    # oracle leg: float64 attention with the keep bits the forward wrote
+    ng = t // 32
+    w = mask.cpu().to(torch.int64) & 0xFFFFFFFF
+    slot = torch.arange(32)
+    key_of_slot = ((slot >> 1) & 3) + 8 * (slot >> 3) + 4 * (slot & 1)
+    bits = (w.unsqueeze(-1) >> torch.arange(32)) & 1
+    dense = torch.zeros(b, h, ng, ng, 32, 32, dtype=torch.int64)
+    dense[:, :, :, :, key_of_slot, :] = bits
+    keep = dense.permute(0, 1, 2, 5, 3, 4).reshape(b, h, t, t).double()
+    q64, k64, v64 = (z.detach().cpu().double().requires_grad_(True) for z in (q, kk, v))
+    heads = lambda z: z.view(b, t, h, 32).transpose(1, 2)
+    pr = torch.softmax(heads(q64) @ heads(k64).transpose(-1, -2) / math.sqrt(32), -1) * keep * ik
+    oref = (pr @ heads(v64)).transpose(1, 2).reshape(b, t, d)
+    oref.backward(do.cpu().double())
+    close(o1, oref, ptol(precision), "planes forward vs fp64")
+    close(g1[0], q64.grad, gtol(precision), "planes dq vs fp64")
+    close(g1[1], k64.grad, gtol(precision), "planes dk vs fp64")
+    close(g1[2], v64.grad, gtol(precision), "planes dv vs fp64")
