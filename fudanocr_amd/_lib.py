@@ -79,6 +79,8 @@ SIGNATURES = {
     "focr_gru_bidir_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     "focr_conv9x9_small_cout_fwd": [P, P, P, P, I, I, I, I, I, P],
     "focr_conv9x9_small_cout_wgrad": [P, P, P, P, I, I, I, I, I, I, P],
+    "focr_conv9x9_small_cout_wgrad_ws": [P, P, P, P, P, L, I, I, I, I, I, P],
+    "focr_conv9x9_small_cout_wgrad_ws_floats": [I, I, I, I],
     "focr_ctc_fwd": [P, P, P, P, P, P, P, I, I, I, P],
     "focr_scale_dev": [P, P, P, L, P],
     "focr_grad_sumsq": [P, P, L, F, P],
@@ -144,6 +146,7 @@ def load():
     lib.focr_lstm_ws_bytes.restype = ctypes.c_long
     lib.focr_grad_sumsq_ws_floats.restype = ctypes.c_long
     lib.focr_conv2d_wgrad_ws_floats.restype = ctypes.c_long
+    lib.focr_conv9x9_small_cout_wgrad_ws_floats.restype = ctypes.c_long
     lib.focr_conv2d_fwd_ws_floats.restype = ctypes.c_long
     lib.focr_weight_frag_bytes.restype = ctypes.c_long
     lib.focr_psnr_ssim_ws_floats.restype = ctypes.c_long

@@ -365,3 +365,194 @@ extern "C" int focr_conv9x9_small_cout_wgrad(const float* x, const float* dy, fl
   if (dbias) return focr_colsum(dy, dbias, (long)N * H * W, Cout, Cout, stream);
   return FOCR_OK;
 }
+
+// =======================================================================================
+// bf16x3 weight gradient of the 9x9 output layer (round 4).  The fp32-MFMA kernel above re-reads every input row three
+// times (one block per group of three tap rows) and runs at 1/16 of the bf16 matrix rate: 428 us on the weight-gradient
+// stream at B = 128 -- the longest single launch of the step -- plus a 130 us column-sum launch for three bias values.
+//   * a block walks over a range of INPUT rows; the row is split to bf16 hi / lo ONCE while it is staged, transposed
+//     ([ci][pixel], two pixels per 32-bit store), so that a B fragment (8 consecutive pixels of one channel) is one
+//     ds_read_b128 per plane, shared by the nine tap rows and the three waves;
+//   * wave w owns tap rows kh = 3 w .. 3 w + 2: input row iy meets output row oy = iy - kh + 4; the nine dY rows (tiny:
+//     W x Cout floats) are staged as fp32 with a 4-pixel zero halo, and the A fragment of lane j = co * 9 + kw is eight
+//     pixels of channel co shifted by kw - 4 (stride-3 ds_read_b32, split on the fly);
+//   * dW^T tile C[(co, kw)][ci] per (kh, 32-channel half): 6 accumulator tiles per wave, K = every pixel of the rows;
+//   * the bias gradient falls out of the centre tap's A fragments (kw = 4 of kh = 4 sees every dY pixel exactly once);
+//   * per-block partial slots + a fixed-order fold (no atomics: deterministic).
+// =======================================================================================
+#define W9_MAXW 128
+#define W9_XTP (W9_MAXW + 8)                 // bf16 pitch of a transposed channel row: 272 B, conflict-free ds_read_b128
+#define W9_GLEN ((W9_MAXW + 8) * 3 + 4)      // floats of one staged dY row (4-pixel halo each side, Cout <= 3)
+#define W9_THREADS 192
+
+__global__ __launch_bounds__(W9_THREADS) void conv9x9_out_wgrad_bx3_kernel(const float* __restrict__ X,
+                                                                           const float* __restrict__ dY,
+                                                                           float* __restrict__ PART, int N, int H, int W,
+                                                                           int Cout, int rows_per_block, long slot_floats) {
+  __shared__ __attribute__((aligned(16))) __bf16 Xth[C9 * W9_XTP], Xtl[C9 * W9_XTP];
+  __shared__ float Gs[9][W9_GLEN];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int row0 = blockIdx.x * rows_per_block, row1 = min(N * H, row0 + rows_per_block);
+  const int jco = li / 9, jkw = li - jco * 9;
+  const bool jok = li < Cout * 9;
+  const int glen = (W + 8) * Cout;
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
+  float bsum = 0.f;
+  // A-fragment base: pixel (16 s + 8 lh + e) - kw + 4 of the halo-padded row, channel co; lanes j >= 27 read the zero halo
+  const int abase = jok ? (8 * lh - jkw + 8) * Cout + jco : 0;
+  const int astep = jok ? Cout : 0, asstep = jok ? 16 * Cout : 0;
+
+  for (int row = row0; row < row1; ++row) {
+    const int n = row / H, iy = row - n * H;
+    // ---- stage the input row transposed + split: item = (pixel pair, 4 channels)
+    const float* xrow = X + (size_t)row * W * C9;
+    for (int i = tid; i < (W / 2) * 16; i += W9_THREADS) {
+      const int pp = i >> 4, c4 = (i & 15) * 4;
+      const float4 u0 = *reinterpret_cast<const float4*>(xrow + (size_t)(2 * pp) * C9 + c4);
+      const float4 u1 = *reinterpret_cast<const float4*>(xrow + (size_t)(2 * pp + 1) * C9 + c4);
+      const float a0[4] = {u0.x, u0.y, u0.z, u0.w}, a1[4] = {u1.x, u1.y, u1.z, u1.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        focr_bf16x2 hh, ll;
+        focr_split2(f32x2{a0[e], a1[e]}, hh, ll);
+        *reinterpret_cast<focr_bf16x2*>(&Xth[(c4 + e) * W9_XTP + 2 * pp]) = hh;
+        *reinterpret_cast<focr_bf16x2*>(&Xtl[(c4 + e) * W9_XTP + 2 * pp]) = ll;
+      }
+    }
+    // ---- the nine dY rows this input row meets (zero outside the image), 4-pixel zero halo on both sides
+    for (int i = tid; i < 9 * glen; i += W9_THREADS) {
+      const int kh = i / glen, g = i - kh * glen;
+      const int oy = iy - kh + 4, px = g / Cout - 4;
+      const bool ok = (unsigned)oy < (unsigned)H && (unsigned)px < (unsigned)W;
+      Gs[kh][g] = ok ? dY[(((size_t)n * H + oy) * W) * Cout + (g - 4 * Cout)] : 0.f;
+    }
+    __syncthreads();
+    for (int s = 0; s < W / 16; ++s) {
+      obf16x8 bh[2], bl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        bh[t] = *reinterpret_cast<const obf16x8*>(&Xth[(li + 32 * t) * W9_XTP + 16 * s + 8 * lh]);
+        bl[t] = *reinterpret_cast<const obf16x8*>(&Xtl[(li + 32 * t) * W9_XTP + 16 * s + 8 * lh]);
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float* g = &Gs[3 * wave + a][abase + s * asstep];
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = g[e * astep];
+        if (!jok) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        }
+        if (wave == 1 && a == 1 && jkw == 4) {          // centre tap of kh = 4: every dY pixel of row iy exactly once
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bsum += v[e];
+        }
+        obf16x8 ah, al;
+        focr_split8(v, ah, al);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[t], acc[a][t], 0, 0, 0);
+          acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[t], acc[a][t], 0, 0, 0);
+          acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[t], acc[a][t], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- this block's partial: slot [Cout][9][9][64] (+ Cout bias sums), plain stores
+  float* slot = PART + (size_t)blockIdx.x * slot_floats;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int kh = 3 * wave + a;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (j < Cout * 9) {
+          const int co = (j * 57) >> 9, kw = j - 9 * co;       // j / 9 for j < 32
+          slot[(((size_t)co * 9 + kh) * 9 + kw) * C9 + li + 32 * t] = acc[a][t][r];
+        }
+      }
+  }
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (wave == 1 && lh == 0 && jok && jkw == 4) slot[(size_t)Cout * 81 * C9 + jco] = bsum;
+}
+
+// dst = sum over the slots in slot order (fixed order: deterministic); block = 8 float4 elements x 32 slot groups
+__global__ __launch_bounds__(256) void conv9x9_out_wgrad_fold_kernel(const float* __restrict__ PART, float* __restrict__ dw,
+                                                                     float* __restrict__ dbias, long n_dw4,
+                                                                     long slot_floats, int nslots, int Cout) {
+  __shared__ float4 red[32][8];
+  const int e = threadIdx.x & 7, g = threadIdx.x >> 3;
+  const long i = (long)blockIdx.x * 8 + e;
+  float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int per = (nslots + 31) / 32, s0 = g * per, s1 = min(nslots, s0 + per);
+  if (i < n_dw4) {
+    for (int b = s0; b < s1; ++b) {
+      const float4 v = reinterpret_cast<const float4*>(PART + (size_t)b * slot_floats)[i];
+      sacc.x += v.x; sacc.y += v.y; sacc.z += v.z; sacc.w += v.w;
+    }
+  } else if (i == n_dw4 && dbias) {                      // the bias sums: element i == n_dw4 of every slot (Cout floats)
+    for (int b = s0; b < s1; ++b) {
+      const float* v = PART + (size_t)b * slot_floats + n_dw4 * 4;
+      sacc.x += v[0];
+      if (Cout > 1) sacc.y += v[1];
+      if (Cout > 2) sacc.z += v[2];
+    }
+  }
+  red[g][e] = sacc;
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    float4 t = red[0][e];
+#pragma unroll
+    for (int q = 1; q < 32; ++q) { t.x += red[q][e].x; t.y += red[q][e].y; t.z += red[q][e].z; t.w += red[q][e].w; }
+    if (i < n_dw4) {
+      reinterpret_cast<float4*>(dw)[i] = t;
+    } else if (i == n_dw4 && dbias) {
+      dbias[0] = t.x;
+      if (Cout > 1) dbias[1] = t.y;
+      if (Cout > 2) dbias[2] = t.z;
+    }
+  }
+}
+
+static void w9_plan(int N, int H, int& nb, int& rpb) {
+  const int rows = N * H;
+  nb = rows < 256 ? rows : 256;
+  rpb = cdiv(rows, nb);
+  nb = cdiv(rows, rpb);
+}
+extern "C" long focr_conv9x9_small_cout_wgrad_ws_floats(int N, int H, int W, int Cout) {
+  int nb, rpb;
+  w9_plan(N, H, nb, rpb);
+  return (long)nb * ((long)Cout * 81 * C9 + 4);
+}
+// as focr_conv9x9_small_cout_wgrad, on the bf16 matrix pipe with split operands (precision modes 1-3) and with the bias
+// gradient from the same pass.  dw / dbias are OVERWRITTEN.  ws: focr_conv9x9_small_cout_wgrad_ws_floats() floats.
+extern "C" int focr_conv9x9_small_cout_wgrad_ws(const float* x, const float* dy, float* dw, float* dbias, float* ws,
+                                                long ws_floats, int N, int H, int W, int Cin, int Cout,
+                                                hipStream_t stream) {
+  FOCR_CHECK_ARG(x && dy && dw && ws, "null pointer");
+  if (Cin != C9 || Cout < 1 || Cout > 3 || W > W9_MAXW || W % 16 || focr_get_precision() == 0) {
+    focr_set_error("focr_conv9x9_small_cout_wgrad_ws: needs Cin == 64, Cout <= 3, W %% 16 == 0, W <= 128, precision != 0");
+    return FOCR_EUNSUPPORTED;
+  }
+  int nb, rpb;
+  w9_plan(N, H, nb, rpb);
+  const long slot = (long)Cout * 81 * C9 + 4;
+  FOCR_CHECK_ARG(ws_floats >= (long)nb * slot, "workspace too small");
+  hipLaunchKernelGGL(conv9x9_out_wgrad_bx3_kernel, dim3(nb), W9_THREADS, 0, stream, x, dy, ws, N, H, W, Cout, rpb, slot);
+  const long n_dw4 = (long)Cout * 81 * C9 / 4;
+  hipLaunchKernelGGL(conv9x9_out_wgrad_fold_kernel, dim3((int)((n_dw4 + 1 + 7) / 8)), 256, 0, stream, (const float*)ws, dw,
+                     dbias, n_dw4, slot, nb, Cout);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}

@@ -541,8 +541,15 @@ class _Conv2d(torch.autograd.Function):
                 dy4.record_stream(side)
             with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
                 if _is_out_layer(cin, cout, kh, kw, ph, pw, w, None, alpha, relu) and not has_res:
-                    _lib.call("focr_conv9x9_small_cout_wgrad", _p(x4), _p(dy4), _p(dw), _p(db), n, h, w, cin,
-                              cout, pz, _stream())
+                    if _lib.get_precision() != 0 and w % 16 == 0 and _C9_WGRAD_BX3:
+                        # split-bf16 kernel, bias gradient from the same pass (428 + 130 us -> one ~60 us launch + fold)
+                        nws = _lib.load().focr_conv9x9_small_cout_wgrad_ws_floats(n, h, w, cout)
+                        ws = torch.empty(nws, device=dy.device, dtype=torch.float32)
+                        _lib.call("focr_conv9x9_small_cout_wgrad_ws", _p(x4), _p(dy4), _p(dw), _p(db), _p(ws), nws, n, h,
+                                  w, cin, cout, _stream())
+                    else:
+                        _lib.call("focr_conv9x9_small_cout_wgrad", _p(x4), _p(dy4), _p(dw), _p(db), n, h, w, cin,
+                                  cout, pz, _stream())
                 else:
                     nws = _lib.load().focr_conv2d_wgrad_ws_floats(n, h, w, cin, cout, kh, kw, ph, pw)
                     ws = torch.empty(nws, device=dy.device, dtype=torch.float32) if nws > 0 else None
@@ -1006,6 +1013,8 @@ def fe_chain_supported(feat, heads=4, d_model=128):
 # step the forward is bound by the latency of its keep-bit scalar loads, which the longer fp32 staging phase happens to
 # cover: split forward +25 us, backward -12 us per block, step +0.1 ms.  Off by default, kept tested behind the switch.
 _ATTN_PLANES = os.environ.get("FOCR_ATTN_PLANES", "0") == "1"
+# FOCR_C9_WGRAD_BX3=0: weight gradient of the 9x9 output layer on the round-1 fp32-MFMA kernel (A/B switch)
+_C9_WGRAD_BX3 = os.environ.get("FOCR_C9_WGRAD_BX3", "1") != "0"
 _LOG2E = 1.4426950408889634
 # FOCR_DGRAD_FIRST=0: enqueue a convolution's weight gradient (side stream) before its data gradient (main stream)
 _DGRAD_FIRST = os.environ.get("FOCR_DGRAD_FIRST", "1") != "0"

@@ -136,6 +136,12 @@ int focr_conv9x9_small_cout_fwd(const float* x, const float* w, const float* bia
                                 int W, int Cin, int Cout, focr_stream_t stream);
 int focr_conv9x9_small_cout_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N, int H,
                                   int W, int Cin, int Cout, int prezeroed, focr_stream_t stream);
+/* the same gradient on the bf16 matrix pipe with split operands (precision modes 1-3), bias gradient from the same pass;
+ * dw / dbias are overwritten; ws: focr_conv9x9_small_cout_wgrad_ws_floats(N, H, W, Cout) floats (per-block partial tiles,
+ * folded in a fixed order: no atomics).  model/tsrn.py:43 / tbsrn.py:197 backward. */
+long focr_conv9x9_small_cout_wgrad_ws_floats(int N, int H, int W, int Cout);
+int focr_conv9x9_small_cout_wgrad_ws(const float* x, const float* dy, float* dw, float* dbias, float* ws, long ws_floats,
+                                     int N, int H, int W, int Cin, int Cout, focr_stream_t stream);
 
 /* ---- fused attention: model/tbsrn.py:132-150 (+ the head split/merge of :116-126) -----------
  * q,k,v (and dq,dk,dv): row pitch ld; o, d_o: row pitch ldo (0 = ld) -- q,k,v may be column slices of one packed
