@@ -382,7 +382,7 @@ extern "C" int focr_conv9x9_small_cout_wgrad(const float* x, const float* dy, fl
 // =======================================================================================
 #define W9_MAXW 128
 #define W9_XTP (W9_MAXW + 8)                 // bf16 pitch of a transposed channel row: 272 B, conflict-free ds_read_b128
-#define W9_GLEN ((W9_MAXW + 8) * 3 + 4)      // floats of one staged dY row (4-pixel halo each side, Cout <= 3)
+#define W9_GLEN ((W9_MAXW + 8) * 3 + 4)      // floats of one staged dY row (4-pixel halo each side, Cout <= 3); % 4 == 0
 #define W9_THREADS 192
 
 __global__ __launch_bounds__(W9_THREADS) void conv9x9_out_wgrad_bx3_kernel(const float* __restrict__ X,
@@ -390,7 +390,10 @@ __global__ __launch_bounds__(W9_THREADS) void conv9x9_out_wgrad_bx3_kernel(const
                                                                            float* __restrict__ PART, int N, int H, int W,
                                                                            int Cout, int rows_per_block, long slot_floats) {
   __shared__ __attribute__((aligned(16))) __bf16 Xth[C9 * W9_XTP], Xtl[C9 * W9_XTP];
-  __shared__ float Gs[9][W9_GLEN];
+  // the nine dY rows, split ONCE while staged: one 32-bit word per value = bf16 hi | bf16 lo << 16 (a lane's A fragment is eight
+  // words at a 3-word stride; separating the planes costs one v_perm per word pair instead of a 24-instruction split per
+  // fragment -- the fragment splits were what bounded the first version of this kernel: 1 700 VALU per wave and row)
+  __shared__ __attribute__((aligned(16))) uint32_t Gs[9][W9_GLEN];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int row0 = blockIdx.x * rows_per_block, row1 = min(N * H, row0 + rows_per_block);
   const int jco = li / 9, jkw = li - jco * 9;
@@ -403,36 +406,102 @@ __global__ __launch_bounds__(W9_THREADS) void conv9x9_out_wgrad_bx3_kernel(const
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
-  float bsum = 0.f;
-  // A-fragment base: pixel (16 s + 8 lh + e) - kw + 4 of the halo-padded row, channel co; lanes j >= 27 read the zero halo
-  const int abase = jok ? (8 * lh - jkw + 8) * Cout + jco : 0;
-  const int astep = jok ? Cout : 0, asstep = jok ? 16 * Cout : 0;
-
-  for (int row = row0; row < row1; ++row) {
-    const int n = row / H, iy = row - n * H;
-    // ---- stage the input row transposed + split: item = (pixel pair, 4 channels)
-    const float* xrow = X + (size_t)row * W * C9;
-    for (int i = tid; i < (W / 2) * 16; i += W9_THREADS) {
-      const int pp = i >> 4, c4 = (i & 15) * 4;
-      const float4 u0 = *reinterpret_cast<const float4*>(xrow + (size_t)(2 * pp) * C9 + c4);
-      const float4 u1 = *reinterpret_cast<const float4*>(xrow + (size_t)(2 * pp + 1) * C9 + c4);
-      const float a0[4] = {u0.x, u0.y, u0.z, u0.w}, a1[4] = {u1.x, u1.y, u1.z, u1.w};
+  // A-fragment base: pixel (16 s + 8 lh + e) - kw + 4 of the halo-padded row, channel co
+  // (lanes j >= Cout * 9 feed output rows that are never stored: they read what lane (co 0, kw 0) reads -- a broadcast, no
+  // extra bank -- instead of a zero word of their own)
+  const int abase = jok ? (8 * lh - jkw + 8) * Cout + jco : (8 * lh + 8) * Cout;
+  const int astep = Cout, asstep = 16 * Cout;
+  // the halo cells (4 pixels left / right of every staged dY row) are zero for the whole launch
+  for (int i = tid; i < 9 * 8 * Cout; i += W9_THREADS) {
+    const int kh = i / (8 * Cout), g = i - kh * 8 * Cout;
+    Gs[kh][g < 4 * Cout ? g : (W + 4) * Cout + (g - 4 * Cout)] = 0u;
+  }
+  // ---- this thread's staging items are the same for every row: up to 6 (pixel pair, 4 channels) patches of the input row
+  // and up to 5 float4 of the nine dY rows (a dY row is W * Cout contiguous floats)
+  const int nxi = (W / 2) * 16, qpr = W * Cout / 4, ndi = 9 * qpr;
+  int dkh[5], dq[5];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        focr_bf16x2 hh, ll;
-        focr_split2(f32x2{a0[e], a1[e]}, hh, ll);
-        *reinterpret_cast<focr_bf16x2*>(&Xth[(c4 + e) * W9_XTP + 2 * pp]) = hh;
-        *reinterpret_cast<focr_bf16x2*>(&Xtl[(c4 + e) * W9_XTP + 2 * pp]) = ll;
+  for (int u = 0; u < 5; ++u) {
+    const int i = tid + u * W9_THREADS;
+    dkh[u] = i < ndi ? i / qpr : -1;
+    dq[u] = i < ndi ? i - dkh[u] * qpr : 0;
+  }
+  float4 xa[6], xb[6], dv[5];
+  // bias gradient: channel of element 4 q of a dY row is (4 q) % Cout; the per-thread sums are kept per channel SLOT
+  // (slot c = channel c for Cout == 3; for Cout < 3 the unused slots stay zero) and folded at the end
+  float bs[3] = {0.f, 0.f, 0.f};
+  int bch[5];
+#pragma unroll
+  for (int u = 0; u < 5; ++u) bch[u] = (4 * dq[u]) % Cout;
+  auto load_row = [&](int row) {
+    const int n = row / H, iy = row - n * H;
+    const float* xrow = X + (size_t)row * W * C9;
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int i = tid + u * W9_THREADS;
+      if (i < nxi) {
+        // 16 adjacent lanes = 16 pixel pairs of one channel quad: their 32-bit LDS stores are consecutive words (lanes that
+        // differ in the channel quad sit 4 x 68 words apart = the same bank: the first mapping -- 16 lanes over the 16
+        // quads -- was an 8-way store conflict)
+        const int pp = (i >> 8) * 16 + (i & 15), c4 = ((i >> 4) & 15) * 4;
+        xa[u] = *reinterpret_cast<const float4*>(xrow + (size_t)(2 * pp) * C9 + c4);
+        xb[u] = *reinterpret_cast<const float4*>(xrow + (size_t)(2 * pp + 1) * C9 + c4);
       }
     }
-    // ---- the nine dY rows this input row meets (zero outside the image), 4-pixel zero halo on both sides
-    for (int i = tid; i < 9 * glen; i += W9_THREADS) {
-      const int kh = i / glen, g = i - kh * glen;
-      const int oy = iy - kh + 4, px = g / Cout - 4;
-      const bool ok = (unsigned)oy < (unsigned)H && (unsigned)px < (unsigned)W;
-      Gs[kh][g] = ok ? dY[(((size_t)n * H + oy) * W) * Cout + (g - 4 * Cout)] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int oy = iy - dkh[u] + 4;
+      const bool ok = dkh[u] >= 0 && (unsigned)oy < (unsigned)H;
+      dv[u] = ok ? *reinterpret_cast<const float4*>(dY + ((size_t)n * H + oy) * W * Cout + 4 * dq[u])
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+  };
+  auto store_row = [&]() {
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int i = tid + u * W9_THREADS;
+      if (i < nxi) {
+        const int pp = (i >> 8) * 16 + (i & 15), c4 = ((i >> 4) & 15) * 4;
+        const float a0[4] = {xa[u].x, xa[u].y, xa[u].z, xa[u].w}, a1[4] = {xb[u].x, xb[u].y, xb[u].z, xb[u].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          focr_bf16x2 hh, ll;
+          focr_split2(f32x2{a0[e], a1[e]}, hh, ll);
+          *reinterpret_cast<focr_bf16x2*>(&Xth[(c4 + e) * W9_XTP + 2 * pp]) = hh;
+          *reinterpret_cast<focr_bf16x2*>(&Xtl[(c4 + e) * W9_XTP + 2 * pp]) = ll;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+      if (dkh[u] >= 0) {
+        focr_bf16x2 h0, l0, h1, l1;
+        focr_split2(f32x2{dv[u].x, dv[u].y}, h0, l0);
+        focr_split2(f32x2{dv[u].z, dv[u].w}, h1, l1);
+        const uint32_t ha = __builtin_bit_cast(uint32_t, h0), la = __builtin_bit_cast(uint32_t, l0);
+        const uint32_t hb = __builtin_bit_cast(uint32_t, h1), lb = __builtin_bit_cast(uint32_t, l1);
+        *reinterpret_cast<uint4*>(&Gs[dkh[u]][4 * Cout + 4 * dq[u]]) =
+            make_uint4(__builtin_amdgcn_perm(la, ha, 0x05040100u), __builtin_amdgcn_perm(la, ha, 0x07060302u),
+                       __builtin_amdgcn_perm(lb, hb, 0x05040100u), __builtin_amdgcn_perm(lb, hb, 0x07060302u));
+        if (dkh[u] == 4) {                                // tap row kh = 4 is dY row iy itself: every pixel exactly once
+          const float ev[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
+          int c = bch[u];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            bs[0] += c == 0 ? ev[e] : 0.f;
+            bs[1] += c == 1 ? ev[e] : 0.f;
+            bs[2] += c == 2 ? ev[e] : 0.f;
+            c = c + 1 == Cout ? 0 : c + 1;
+          }
+        }
+      }
+  };
+
+  if (row0 < row1) load_row(row0);
+  for (int row = row0; row < row1; ++row) {
+    store_row();                                        // this row (requested during the previous row's products)
     __syncthreads();
+    if (row + 1 < row1) load_row(row + 1);
     for (int s = 0; s < W / 16; ++s) {
       obf16x8 bh[2], bl[2];
 #pragma unroll
@@ -442,20 +511,16 @@ __global__ __launch_bounds__(W9_THREADS) void conv9x9_out_wgrad_bx3_kernel(const
       }
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        const float* g = &Gs[3 * wave + a][abase + s * asstep];
-        float v[8];
+        const uint32_t* g = &Gs[3 * wave + a][abase + s * asstep];     // 8 words at a Cout-word stride
+        uint32_t w[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = g[e * astep];
-        if (!jok) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = 0.f;
-        }
-        if (wave == 1 && a == 1 && jkw == 4) {          // centre tap of kh = 4: every dY pixel of row iy exactly once
-#pragma unroll
-          for (int e = 0; e < 8; ++e) bsum += v[e];
-        }
-        obf16x8 ah, al;
-        focr_split8(v, ah, al);
+        for (int e = 0; e < 8; ++e) w[e] = g[e * astep];
+        typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+        const u32x4 hw = {__builtin_amdgcn_perm(w[1], w[0], 0x05040100u), __builtin_amdgcn_perm(w[3], w[2], 0x05040100u),
+                          __builtin_amdgcn_perm(w[5], w[4], 0x05040100u), __builtin_amdgcn_perm(w[7], w[6], 0x05040100u)};
+        const u32x4 lw = {__builtin_amdgcn_perm(w[1], w[0], 0x07060302u), __builtin_amdgcn_perm(w[3], w[2], 0x07060302u),
+                          __builtin_amdgcn_perm(w[5], w[4], 0x07060302u), __builtin_amdgcn_perm(w[7], w[6], 0x07060302u)};
+        const obf16x8 ah = __builtin_bit_cast(obf16x8, hw), al = __builtin_bit_cast(obf16x8, lw);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[t], acc[a][t], 0, 0, 0);
@@ -482,8 +547,19 @@ __global__ __launch_bounds__(W9_THREADS) void conv9x9_out_wgrad_bx3_kernel(const
         }
       }
   }
-  bsum += __shfl_xor(bsum, 32, 64);
-  if (wave == 1 && lh == 0 && jok && jkw == 4) slot[(size_t)Cout * 81 * C9 + jco] = bsum;
+  // bias sums: per-thread channel sums -> block (Xth is free now)
+  {
+    float* red = reinterpret_cast<float*>(Xth);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; ++c) red[c * W9_THREADS + tid] = bs[c];
+    __syncthreads();
+    if (tid < Cout) {
+      float t = 0.f;
+      for (int i = 0; i < W9_THREADS; ++i) t += red[tid * W9_THREADS + i];
+      slot[(size_t)Cout * 81 * C9 + tid] = t;
+    }
+  }
 }
 
 // dst = sum over the slots in slot order (fixed order: deterministic); block = 8 float4 elements x 32 slot groups
@@ -526,7 +602,7 @@ __global__ __launch_bounds__(256) void conv9x9_out_wgrad_fold_kernel(const float
 
 static void w9_plan(int N, int H, int& nb, int& rpb) {
   const int rows = N * H;
-  nb = rows < 256 ? rows : 256;
+  nb = rows < 512 ? rows : 512;           // two 3-wave blocks per CU: one block alone leaves a SIMD idle and nothing to cover its LDS gathers
   rpb = cdiv(rows, nb);
   nb = cdiv(rows, rpb);
 }
@@ -541,8 +617,8 @@ extern "C" int focr_conv9x9_small_cout_wgrad_ws(const float* x, const float* dy,
                                                 long ws_floats, int N, int H, int W, int Cin, int Cout,
                                                 hipStream_t stream) {
   FOCR_CHECK_ARG(x && dy && dw && ws, "null pointer");
-  if (Cin != C9 || Cout < 1 || Cout > 3 || W > W9_MAXW || W % 16 || focr_get_precision() == 0) {
-    focr_set_error("focr_conv9x9_small_cout_wgrad_ws: needs Cin == 64, Cout <= 3, W %% 16 == 0, W <= 128, precision != 0");
+  if (Cin != C9 || Cout < 1 || Cout > 3 || W > W9_MAXW || W % 32 || focr_get_precision() == 0) {
+    focr_set_error("focr_conv9x9_small_cout_wgrad_ws: needs Cin == 64, Cout <= 3, W %% 32 == 0, W <= 128, precision != 0");
     return FOCR_EUNSUPPORTED;
   }
   int nb, rpb;

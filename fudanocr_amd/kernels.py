@@ -541,7 +541,7 @@ class _Conv2d(torch.autograd.Function):
                 dy4.record_stream(side)
             with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
                 if _is_out_layer(cin, cout, kh, kw, ph, pw, w, None, alpha, relu) and not has_res:
-                    if _lib.get_precision() != 0 and w % 16 == 0 and _C9_WGRAD_BX3:
+                    if _lib.get_precision() != 0 and w % 32 == 0 and _C9_WGRAD_BX3:
                         # split-bf16 kernel, bias gradient from the same pass (428 + 130 us -> one ~60 us launch + fold)
                         nws = _lib.load().focr_conv9x9_small_cout_wgrad_ws_floats(n, h, w, cout)
                         ws = torch.empty(nws, device=dy.device, dtype=torch.float32)
