@@ -826,6 +826,23 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_bx3_kernel(
 // `bad` (LDS, zeroed by the kernel): set when the wait timed out, i.e. a partner block was never scheduled.  The kernels
 // then write NaN into every later output of this block, so a scan that could not synchronise can never pass for a
 // result (the error word `err` additionally tells the host why; kernels._lstm_check reads it under FOCR_LSTM_CHECK=1).
+// Exchange protocol (round 4 re-measured both forms of cdna_hip_programming.md Guideline 16 on this scan):
+//   LSTM_XCHG == 0 (default): payload = plain stores (they stay in the XCD's L2, where the 8 partners -- same id mod 8 =
+//     same XCD under round-robin dispatch -- read them back), ONE lane bumps the group's step counter with RELEASE order
+//     (agent scope: correct on any placement), the consumer polls the word RELAXED and issues ONE agent-scope acquire after
+//     the match (round 3 polled with ACQUIRE loads: an L1 invalidate per poll), then plain 16-byte loads.
+//   LSTM_XCHG == 1: the fence-free form -- 8-byte agent-scope atomic stores (write-through) and loads (past the L1) on
+//     both sides, relaxed counter.  Correct (bit-identical scan), but SLOWER here: 250 / 265 us per layer against 207 / 213:
+//     write-through stores drop the line from the L2 the partners would have hit, and 8-byte accesses run at 0.5-0.7x the
+//     16-byte rate (MI355X_MICROARCH.md, visibility table).
+//   Also tried: plain stores + drained RELAXED counter + L1-bypassing loads and no fence at all (sound only if the partners
+//   share an L2): the scan goes STALE (test_lstm / decoded strings fail) and is slower still (280 / 316 us) -- dropped.
+// In both forms the payload is staged in LDS and leaves as 8-byte stores (round 3: 2-byte stores, 16 per thread in the
+// backward scan).  Net effect of the round-4 form: 207 / 213 -> 202 / 216 us per layer, i.e. none: the 8 us per step are not
+// in the polls or the store width.
+#ifndef LSTM_XCHG
+#define LSTM_XCHG 0
+#endif
 __device__ __forceinline__ void lp_wait(unsigned* flag, unsigned target, unsigned* err, unsigned* bad) {
 #ifdef LSTM_ABL_NOSYNC
   __syncthreads();
@@ -833,13 +850,16 @@ __device__ __forceinline__ void lp_wait(unsigned* flag, unsigned target, unsigne
 #endif
   if (threadIdx.x == 0) {
     int spins = 0;
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       if (++spins > LSTM_SPIN_LIMIT) {
         __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *bad = 1u;
         break;
       }
     }
+#if LSTM_XCHG == 0
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // ONE invalidate of this CU's L1, after the match
+#endif
   }
   __syncthreads();
 }
@@ -848,8 +868,33 @@ __device__ __forceinline__ void lp_arrive(unsigned* flag) {
   __syncthreads();
   return;
 #endif
+#if LSTM_XCHG == 1
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave: its write-through payload stores are acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
   __syncthreads();                      // every thread's rows of this step are written (and acknowledged by L2)
   if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+// 8 bf16 (16 bytes) of a partner's payload row
+__device__ __forceinline__ rbf16x8 lp_load8(const __bf16* p) {
+#if LSTM_XCHG == 1
+  typedef __attribute__((ext_vector_type(2))) unsigned long long u64x2;
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(const_cast<__bf16*>(p));
+  const u64x2 v = {__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                   __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
+  return __builtin_bit_cast(rbf16x8, v);
+#else
+  return *reinterpret_cast<const rbf16x8*>(p);
+#endif
+}
+__device__ __forceinline__ void lp_store4(__bf16* p, unsigned long long v) {
+#if LSTM_XCHG == 1
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  *reinterpret_cast<unsigned long long*>(p) = v;
+#endif
 }
 
 __global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
@@ -905,8 +950,8 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
       rbf16x8 ah[8], al[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        ah[i] = *reinterpret_cast<const rbf16x8*>(arow + 16 * i);
-        al[i] = *reinterpret_cast<const rbf16x8*>(arow + nh + 16 * i);
+        ah[i] = lp_load8(arow + 16 * i);
+        al[i] = lp_load8(arow + nh + 16 * i);
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -944,12 +989,24 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
       o_h[e] = o_og[e] * tanhf(o_c[e]);
       if (lp_bad) o_h[e] = __int_as_float(0x7fc00000);     // a wait timed out: poison, never a silently stale scan
       cprev[e] = o_c[e];
-      if (eb < B) {
-        const size_t ho = ((size_t)t * B + eb) * 2 * H + dir * H + j0 + eu;
-        const __bf16 hh = (__bf16)o_h[e];
-        hseq2[ho] = hh;
-        hseq2[nh + ho] = (__bf16)(o_h[e] - (float)hh);
-      }
+    }
+    // payload: h as bf16 hi / lo, [plane][sequence][unit], staged in the (now idle) partial-sum tile and sent as one
+    // 8-byte write-through store per thread
+    __bf16* pay = reinterpret_cast<__bf16*>(&part[0][0][0]);
+    __syncthreads();                               // every thread has read its partial sums
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int ebl = (tid >> 5) + 16 * e;
+      const __bf16 hh = (__bf16)o_h[e];
+      pay[ebl * 32 + eu] = hh;
+      pay[1024 + ebl * 32 + eu] = (__bf16)(o_h[e] - (float)hh);
+    }
+    __syncthreads();
+    {
+      const int pl = tid >> 8, sq = (tid >> 3) & 31, ch = tid & 7;
+      if (b0 + sq < B)
+        lp_store4(hseq2 + (size_t)pl * nh + ((size_t)t * B + b0 + sq) * 2 * H + dir * H + j0 + 4 * ch,
+                  *reinterpret_cast<const unsigned long long*>(&pay[pl * 1024 + sq * 32 + 4 * ch]));
     }
     if (step + 1 < T) lp_arrive(flag);          // (the barrier inside also protects `part` for the next step)
 #pragma unroll
@@ -1022,8 +1079,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_bx3_kernel(
       rbf16x8 ah[8], al[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        ah[i] = *reinterpret_cast<const rbf16x8*>(arow + 16 * i);
-        al[i] = *reinterpret_cast<const rbf16x8*>(arow + ndg + 16 * i);
+        ah[i] = lp_load8(arow + 16 * i);
+        al[i] = lp_load8(arow + ndg + 16 * i);
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -1061,15 +1118,29 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_bx3_kernel(
       d4[e][2] = dc * ig[e] * (1.f - gg[e] * gg[e]);
       d4[e][3] = dh * tc * og[e] * (1.f - og[e]);
       if (lp_bad) d4[e][0] = d4[e][1] = d4[e][2] = d4[e][3] = __int_as_float(0x7fc00000);
-      if (eb < B) {
-        const size_t ob = ((size_t)t * st_t + (size_t)eb * st_b) * 8 * H + dir * 4 * H + j0 + eu;
+    }
+    // payload: the gate gradients as bf16 hi / lo, [plane][sequence][gate][unit] (16 KB), staged in the partial-sum
+    // tile and sent as four 8-byte write-through stores per thread
+    __bf16* pay = reinterpret_cast<__bf16*>(&part[0][0][0]);
+    __syncthreads();                               // every thread has read its partial sums
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const __bf16 hh = (__bf16)d4[e][q];
-          dgx2[ob + q * H] = hh;
-          dgx2[ndg + ob + q * H] = (__bf16)(d4[e][q] - (float)hh);
-        }
+    for (int e = 0; e < 2; ++e) {
+      const int ebl = (tid >> 5) + 16 * e;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const __bf16 hh = (__bf16)d4[e][q];
+        pay[(ebl * 4 + q) * 32 + eu] = hh;
+        pay[4096 + (ebl * 4 + q) * 32 + eu] = (__bf16)(d4[e][q] - (float)hh);
       }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = tid + 512 * k, pl = c >> 10, sq = (c >> 5) & 31, q = (c >> 3) & 3, ch = c & 7;
+      if (b0 + sq < B)
+        lp_store4(dgx2 + (size_t)pl * ndg + ((size_t)t * st_t + (size_t)(b0 + sq) * st_b) * 8 * H + dir * 4 * H + q * H + j0 +
+                      4 * ch,
+                  *reinterpret_cast<const unsigned long long*>(&pay[pl * 4096 + (sq * 4 + q) * 32 + 4 * ch]));
     }
     if (step + 1 < T) lp_arrive(flag);          // partners read the bf16 copies only; the fp32 result follows
 #pragma unroll
