@@ -87,6 +87,23 @@ __device__ __forceinline__ void fc_stage_vec(const float* __restrict__ g, float*
 // ---- rows in the lane layout ------------------------------------------------------------------------------------
 template <int NT>
 __device__ __forceinline__ void fc_load_row(const float* __restrict__ p, int lh, f32x16 (&v)[NT]) {
+#ifdef FC_TLAYOUT_PROBE      // timing probe only (wrong data): 128-column rows addressed as [tile][16-byte chunk][row], i.e.
+                             // every wave access two 512-byte runs.  Upper bound of what a tile-transposed layout of the chain-
+                             // internal tensors could buy (r04: fwd_a 68 -> 61, fwd_b 67 -> 65, bwd_a 80 -> 72, bwd_b 104 -> 99 us,
+                             // the two QKV kernels slower): ~0.1 ms per step at best -- not pursued
+  if (NT == 4) {
+    const int li_ = threadIdx.x & 31;
+    const float* tb = p - li_ * FC_D;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 t = *reinterpret_cast<const float4*>(tb + (8 * j + 2 * g + lh) * 128 + li_ * 4);
+        v[j][4 * g] = t.x; v[j][4 * g + 1] = t.y; v[j][4 * g + 2] = t.z; v[j][4 * g + 3] = t.w;
+      }
+    return;
+  }
+#endif
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -97,6 +114,19 @@ __device__ __forceinline__ void fc_load_row(const float* __restrict__ p, int lh,
 }
 template <int NT>
 __device__ __forceinline__ void fc_store_row(float* __restrict__ p, int lh, const f32x16 (&v)[NT]) {
+#ifdef FC_TLAYOUT_PROBE
+  if (NT == 4) {
+    const int li_ = threadIdx.x & 31;
+    float* tb = p - li_ * FC_D;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(tb + (8 * j + 2 * g + lh) * 128 + li_ * 4) =
+            make_float4(v[j][4 * g], v[j][4 * g + 1], v[j][4 * g + 2], v[j][4 * g + 3]);
+    return;
+  }
+#endif
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
