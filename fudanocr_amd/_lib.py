@@ -68,6 +68,7 @@ SIGNATURES = {
     "focr_linear_relu_dropout_fwd": [P, P, P, P, L, I, I, F, F, U, P, P],
     "focr_maxpool_fwd": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "focr_maxpool_bwd": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "focr_maxpool_relu_bwd": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "focr_tps_fwd": [P, P, P, P, P, P, I, I, I, I, I, P],
     "focr_tps_bwd": [P, P, P, P, P, P, I, I, I, I, I, P],
     "focr_tps_bwd_img": [P, P, P, I, I, I, I, P],

@@ -67,8 +67,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
   }
 }
 // one thread = 4 consecutive channels of one input pixel (C % 4 == 0: float4 / uchar4 accesses, 32-bit index math)
+// ypool != nullptr: the pooled tensor was max(relu(.)): a window whose maximum is 0 passes no gradient (relu'(y <= 0) = 0),
+// every other window's arg-max element has relu' = 1 -- the relu backward of the producing layer is applied HERE and its
+// own pass over the (2-4x larger) un-pooled gradient disappears
 __global__ __launch_bounds__(256) void maxpool_bwd_vec4_kernel(const float* __restrict__ dy,
                                                                const uint8_t* __restrict__ idx,
+                                                               const float* __restrict__ ypool,
                                                                float* __restrict__ dx, long total4, int H, int W,
                                                                int C, int OH, int OW, int kh, int kw, int sh,
                                                                int sw, int ph, int pw) {
@@ -93,7 +97,11 @@ __global__ __launch_bounds__(256) void maxpool_bwd_vec4_kernel(const float* __re
         if (ox >= OW) continue;
         const size_t o = (((size_t)n * OH + oy) * OW + ox) * C4 + c4;
         const uchar4 k = reinterpret_cast<const uchar4*>(idx)[o];
-        const float4 g = reinterpret_cast<const float4*>(dy)[o];
+        float4 g = reinterpret_cast<const float4*>(dy)[o];
+        if (ypool) {
+          const float4 yp = reinterpret_cast<const float4*>(ypool)[o];
+          g.x = yp.x > 0.f ? g.x : 0.f; g.y = yp.y > 0.f ? g.y : 0.f; g.z = yp.z > 0.f ? g.z : 0.f; g.w = yp.w > 0.f ? g.w : 0.f;
+        }
         const int tap = a * kw + b;
         acc.x += k.x == tap ? g.x : 0.f;
         acc.y += k.y == tap ? g.y : 0.f;
@@ -319,14 +327,27 @@ extern "C" int focr_maxpool_fwd(const float* x, float* y, uint8_t* idx, int N, i
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }
+static int maxpool_bwd_impl(const float* dy, const uint8_t* idx, const float* ypool, float* dx, int N, int H, int W, int C,
+                            int kh, int kw, int sh, int sw, int ph, int pw, hipStream_t stream);
 extern "C" int focr_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int N, int H, int W, int C,
                                 int kh, int kw, int sh, int sw, int ph, int pw, hipStream_t stream) {
+  return maxpool_bwd_impl(dy, idx, nullptr, dx, N, H, W, C, kh, kw, sh, sw, ph, pw, stream);
+}
+// maxpool backward fused with the backward of the relu that produced the pooled input (crnn.py:52-63: conv -> relu -> pool):
+// ypool = the pooling layer's forward output; C % 4 == 0
+extern "C" int focr_maxpool_relu_bwd(const float* dy, const uint8_t* idx, const float* ypool, float* dx, int N, int H,
+                                     int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, hipStream_t stream) {
+  FOCR_CHECK_ARG(ypool && C % 4 == 0, "needs the pooled forward output and C % 4 == 0");
+  return maxpool_bwd_impl(dy, idx, ypool, dx, N, H, W, C, kh, kw, sh, sw, ph, pw, stream);
+}
+static int maxpool_bwd_impl(const float* dy, const uint8_t* idx, const float* ypool, float* dx, int N, int H, int W, int C,
+                            int kh, int kw, int sh, int sw, int ph, int pw, hipStream_t stream) {
   FOCR_CHECK_ARG(dy && dx && idx, "null pointer");
   int OH = (H + 2 * ph - kh) / sh + 1, OW = (W + 2 * pw - kw) / sw + 1;
   FOCR_CHECK_ARG(OH > 0 && OW > 0, "bad geometry");
   long total = (long)N * H * W * C;
   if (C % 4 == 0)
-    hipLaunchKernelGGL(maxpool_bwd_vec4_kernel, dim3(ew_grid(total / 4)), 256, 0, stream, dy, idx, dx, total / 4, H, W, C,
+    hipLaunchKernelGGL(maxpool_bwd_vec4_kernel, dim3(ew_grid(total / 4)), 256, 0, stream, dy, idx, ypool, dx, total / 4, H, W, C,
                        OH, OW, kh, kw, sh, sw, ph, pw);
   else
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total)), 256, 0, stream, dy, idx, dx, total, H, W, C, OH, OW,

@@ -1446,8 +1446,12 @@ def ctc_loss(logits, targets, lengths):
 # pooling / resampling
 # ----------------------------------------------------------------------------------------
 class _MaxPool(torch.autograd.Function):
+    """relu_input: x is the output of a conv + relu layer (CRNN conv0 / 1 / 3 / 5).  The backward then applies that relu's
+    backward itself (a window whose maximum is 0 passes no gradient) and registers its result in StepContext.premasked,
+    where the convolution's backward finds it and skips its own relu pass over the un-pooled gradient."""
+
     @staticmethod
-    def forward(ctx, x, kernel, stride, pad):
+    def forward(ctx, x, kernel, stride, pad, relu_input):
         n, h, w, c = x.shape
         _chk(x)
         kh, kw = kernel
@@ -1459,22 +1463,32 @@ class _MaxPool(torch.autograd.Function):
         _lib.call("focr_maxpool_fwd", _p(x), _p(y), ctypes.c_void_p(idx.data_ptr()), n, h, w, c, kh, kw, sh, sw,
                   ph, pw, _stream())
         ctx.cfg = (n, h, w, c, kh, kw, sh, sw, ph, pw)
-        ctx.save_for_backward(idx)
+        ctx.relu_input = bool(relu_input) and c % 4 == 0
+        ctx.step = current_context()
+        if ctx.relu_input:
+            ctx.save_for_backward(idx, y)
+        else:
+            ctx.save_for_backward(idx)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (idx,) = ctx.saved_tensors
+        idx = ctx.saved_tensors[0]
         n, h, w, c, kh, kw, sh, sw, ph, pw = ctx.cfg
         dy = dy.contiguous()
         dx = torch.empty((n, h, w, c), device=dy.device)
-        _lib.call("focr_maxpool_bwd", _p(dy), ctypes.c_void_p(idx.data_ptr()), _p(dx), n, h, w, c, kh, kw, sh,
-                  sw, ph, pw, _stream())
-        return dx, None, None, None
+        if ctx.relu_input:
+            _lib.call("focr_maxpool_relu_bwd", _p(dy), ctypes.c_void_p(idx.data_ptr()), _p(ctx.saved_tensors[1]), _p(dx), n,
+                      h, w, c, kh, kw, sh, sw, ph, pw, _stream())
+            ctx.step.premasked[dx.data_ptr()] = True
+        else:
+            _lib.call("focr_maxpool_bwd", _p(dy), ctypes.c_void_p(idx.data_ptr()), _p(dx), n, h, w, c, kh, kw, sh,
+                      sw, ph, pw, _stream())
+        return dx, None, None, None, None
 
 
-def maxpool(x, kernel, stride=None, pad=(0, 0)):
-    return _MaxPool.apply(x, tuple(kernel), tuple(stride or kernel), tuple(pad))
+def maxpool(x, kernel, stride=None, pad=(0, 0), relu_input=False):
+    return _MaxPool.apply(x, tuple(kernel), tuple(stride or kernel), tuple(pad), relu_input)
 
 
 class _TPSWarp(torch.autograd.Function):

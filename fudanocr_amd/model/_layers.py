@@ -65,8 +65,8 @@ class ReLUTag(nn.ReLU):
 
 
 class MaxPool2d(nn.MaxPool2d):
-    def forward(self, x):
+    def forward(self, x, relu_input=False):
         k = self.kernel_size if isinstance(self.kernel_size, tuple) else (self.kernel_size,) * 2
         s = self.stride if isinstance(self.stride, tuple) else (self.stride,) * 2
         p = self.padding if isinstance(self.padding, tuple) else (self.padding,) * 2
-        return K.maxpool(x, k, s, p)
+        return K.maxpool(x, k, s, p, relu_input=relu_input)

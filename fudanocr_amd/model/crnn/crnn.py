@@ -80,6 +80,7 @@ class CRNN(nn.Module):
                                                                        input.shape[3], 1)
         mods = list(self.cnn.named_children())
         i = 0
+        after_conv_relu = False
         while i < len(mods):
             name, m = mods[i]
             if name.startswith("conv"):
@@ -87,11 +88,15 @@ class CRNN(nn.Module):
                 if bn is None:
                     x = m(x, relu=True)
                     i += 2                      # conv, relu
+                    after_conv_relu = True
                 else:
                     x = bn(m(x), act=K.ACT_RELU)
                     i += 3                      # conv, batchnorm, relu
+                    after_conv_relu = False
             else:
-                x = m(x)
+                # pooling right behind conv + relu: its backward also applies that relu's backward (kernels._MaxPool)
+                x = m(x, relu_input=after_conv_relu) if name.startswith("pooling") else m(x)
+                after_conv_relu = False
                 i += 1
         b, h, w, c = x.shape
         assert h == 1, "the height of conv must be 1"

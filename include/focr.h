@@ -296,6 +296,10 @@ int focr_maxpool_fwd(const float* x, float* y, uint8_t* idx, int N, int H, int W
                      int sh, int sw, int ph, int pw, focr_stream_t stream);
 int focr_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int N, int H, int W, int C, int kh,
                      int kw, int sh, int sw, int ph, int pw, focr_stream_t stream);
+/* the same, fused with the backward of the relu in front of the pooling layer (model/crnn/crnn.py:52-63 conv -> relu -> pool):
+ * ypool = the pooling forward output; gradients of windows whose maximum is 0 are dropped (relu'(y <= 0) = 0) */
+int focr_maxpool_relu_bwd(const float* dy, const uint8_t* idx, const float* ypool, float* dx, int N, int H, int W, int C,
+                          int kh, int kw, int sh, int sw, int ph, int pw, focr_stream_t stream);
 /* TPS grid + F.grid_sample: model/tps_spatial_transformer.py:97-111,10-18 ; src: [B,H*W,2] */
 int focr_tps_fwd(const float* img, const float* ctrl, const float* inv_kernel, const float* coord_repr,
                  float* out, float* src, int B, int H, int W, int C, int NC, focr_stream_t stream);

@@ -570,6 +570,39 @@ def test_maxpool(geom):
     close(xd.grad.permute(0, 3, 1, 2), x.grad, what="maxpool bwd")
 
 
+def test_conv_relu_maxpool_fused_relu_backward():
+    """crnn.py:52-63 conv -> relu -> pool: the pooling backward applies the relu backward itself (a window whose maximum is 0
+    passes no gradient) and the convolution's backward skips its own relu pass (StepContext.premasked).  Against
+    F.conv2d + relu + max_pool2d in float64: input, weight and bias gradients; about half of the windows are all-negative
+    (the bias shifts the pre-activations down) so that the dropped-gradient branch is exercised."""
+    from fudanocr_amd.model._layers import Conv2d, MaxPool2d
+    n, cin, cout, h, w = 2, 32, 64, 8, 12
+    x = rnd(n, cin, h, w, seed=1).requires_grad_(True)
+    wt = (rnd(cout, cin, 3, 3, seed=2) * 0.2).requires_grad_(True)
+    b = (rnd(cout, seed=3) * 0.5 - 0.6).requires_grad_(True)
+    for kern, stride, pad in (((2, 2), (2, 2), (0, 0)), ((2, 2), (2, 1), (0, 1))):
+        for t in (x, wt, b):
+            t.grad = None
+        a = F.relu(F.conv2d(x, wt, b, padding=1))
+        y = F.max_pool2d(a, kern, stride, pad)
+        assert 0.1 < (y == 0).double().mean().item() < 0.9
+        gy = rnd(*y.shape, seed=4)
+        y.backward(gy)
+        conv = Conv2d(cin, cout, 3, 1, 1).cuda()
+        with torch.no_grad():
+            conv.weight.copy_(dev(wt))
+            conv.bias.copy_(dev(b))
+        pool = MaxPool2d(kern, stride, pad)
+        xd = dev(x.permute(0, 2, 3, 1)).requires_grad_(True)
+        yd = pool(conv(xd, relu=True), relu_input=True)
+        close(yd.permute(0, 3, 1, 2), y, ptol(2), what="conv-relu-pool fwd")
+        yd.backward(dev(gy.permute(0, 2, 3, 1)))
+        assert not K().current_context().premasked, "the convolution's backward did not consume the pre-masked gradient"
+        close(xd.grad.permute(0, 3, 1, 2), x.grad, ptol(2), what="conv-relu-pool dx")
+        close(conv.weight.grad, wt.grad, ptol(2), what="conv-relu-pool dw")
+        close(conv.bias.grad, b.grad, ptol(2), what="conv-relu-pool db")
+
+
 def test_tps_warp():
     from oracle import sr_oracle as O
     inv, rep, ctrl0 = O.tps_constants()
