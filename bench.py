@@ -215,6 +215,8 @@ def main():
                     help="launcher / rendezvous check only (no GPU work, runs on a CPU-only host): every rank joins the "
                          "process group (gloo), one all-reduce, rank 0 prints a JSON line with n_gpus and "
                          "collective_backend and value null")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default c3 run: do not time c1 / c2 / c5 in short subprocesses for config.other_configs")
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE",
                     help="A/B kernel-selection switch (focr_set_tuning, include/focr.h); reported in config.tuning")
     args = ap.parse_args()
@@ -339,15 +341,32 @@ def main():
         sync()
         mode1_ms = (time.perf_counter() - t1) / 20 * 1e3
         _lib.set_precision(mode)
-    if rank == 0 and world == 1 and args.all_configs:
+    others = {}
+    if rank == 0 and world == 1 and (args.all_configs or (cfg == "c3" and args.steps >= 20 and not args.no_other_configs)):
+        # the other BASELINE configurations (c1 = TSRN variant of configs[2], c2 = configs[1], c5 = configs[4] at its per-GPU
+        # batch), one short subprocess each: --all-configs prints their full JSON lines BEFORE this configuration's line;
+        # the default run only records ms/step and images/s under config.other_configs (bounded: 120 s per configuration)
         import subprocess
         for other in ("c1", "c2", "c5"):
             if other == cfg:
                 continue
-            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", other, "--steps", "40", "--warmup",
-                                "20", "--no-cpu-baseline", "--precision", args.precision], capture_output=True, text=True)
-            lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-            print(lines[-1] if lines else json.dumps({"config": {"name": other}, "error": p.stderr[-400:]}), flush=True)
+            try:
+                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", other, "--steps", "40" if
+                                    args.all_configs else "20", "--warmup", "20" if args.all_configs else "10",
+                                    "--no-cpu-baseline", "--precision", args.precision], capture_output=True, text=True,
+                                   timeout=300 if args.all_configs else 120)
+                lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+                err = p.stderr[-400:]
+            except Exception as e:                             # noqa: BLE001
+                lines, err = [], type(e).__name__
+            if args.all_configs:
+                print(lines[-1] if lines else json.dumps({"config": {"name": other}, "error": err}), flush=True)
+            if lines:
+                d_ = json.loads(lines[-1])
+                others[other] = {"ms_per_step": d_["ms_per_step"], "images_per_sec": d_["value"],
+                                 "per_gpu_batch": d_["config"]["per_gpu_batch"], "steps": d_["steps"]}
+            else:
+                others[other] = {"error": err}
     if rank == 0:
         value = batch * world * args.steps / dt
         bx3 = mode != 0
@@ -452,7 +471,10 @@ def main():
                        "collective_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
                        "arithmetic": arith,
                        # mode 1 = split products at every site of forward AND backward (fp32-equivalent everywhere)
-                       "mode1_ms_per_step": None if mode1_ms is None else round(mode1_ms, 3)},
+                       "mode1_ms_per_step": None if mode1_ms is None else round(mode1_ms, 3),
+                       # c1 / c2 / c5 of BASELINE.json at one GPU (short runs in subprocesses; `--all-configs` prints their
+                       # full lines, `--no-other-configs` skips them)
+                       "other_configs": others or None},
             # the bounding roofline of this path is the dense-contraction (MFMA) one; `achieved` is the
             # ALGORITHMIC flop rate of the dominant kernel's launches, `executed_frac` counts the MFMA flops actually
             # issued (3 per algorithmic flop for split products).  hbm_view: the same launches against HBM.
