@@ -1106,6 +1106,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_bx3_kernel(
 }
 
 #include "attention_bwd1_bx3.h"
+#include "attention_bwd1w_bx3.h"
 
 // launchers used by the dispatching C ABI entry points in attention.hip
 // 0: one query tile per wave (128-query blocks); 1: two tiles per wave (256-query blocks, needs Ntok % 256 == 0)
@@ -1145,6 +1146,19 @@ int focr_attn_bwd_bx3(const float* q, const float* k, const float* v, const floa
                       const float* dwork, const uint32_t* mask, float* dq, float* dk, float* dv, int B, int H,
                       int Ntok, int ld, int ldo, float scale, float p_drop, hipStream_t stream) {
   const bool fast = focr_get_precision() >= 2;
+  if (fast && focr_get_tuning(FOCR_TUNE_ATTN_BWD_DQ_VARIANT) == 3 && Ntok % 256 == 0) {
+    // experiment: the single pass with one wave per SIMD (attention_bwd1w_bx3.h)
+    if (p_drop > 0.f) {
+      (void)hipFuncSetAttribute((const void*)attn_bwd1w_bx3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, B1_LDS_BYTES);
+      hipLaunchKernelGGL((attn_bwd1w_bx3_kernel<true>), dim3(B * H), 256, B1_LDS_BYTES, stream, q, k, v, d_o, lse, dwork, dq,
+                         dk, dv, mask, Ntok, ld, ldo, ld, scale, p_drop, H);
+    } else {
+      (void)hipFuncSetAttribute((const void*)attn_bwd1w_bx3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, B1_LDS_BYTES);
+      hipLaunchKernelGGL((attn_bwd1w_bx3_kernel<false>), dim3(B * H), 256, B1_LDS_BYTES, stream, q, k, v, d_o, lse, dwork, dq,
+                         dk, dv, mask, Ntok, ld, ldo, ld, scale, p_drop, H);
+    }
+    return 0;
+  }
   if (fast && focr_get_tuning(FOCR_TUNE_ATTN_BWD_DQ_VARIANT) == 2 && Ntok % 256 == 0) {
     // single pass: dQ, dK, dV from one S / dP evaluation (attention_bwd1_bx3.h); 138.5 KB of LDS per block.  The
     // attribute is per device: set on every call (a host-side table lookup) rather than cached in a process-wide flag.

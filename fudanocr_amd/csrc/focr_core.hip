@@ -44,7 +44,8 @@ extern "C" int focr_get_precision(void) { return g_precision.load(std::memory_or
 //   1 "attn_fwd_variant"     1: 256-query attention forward blocks    0: 128-query blocks    2: scores one key
 //                            group ahead + thresholded rescale (measured: no gain in the step)
 //   2 "lstm_persistent"      1: one launch per BiLSTM layer and direction pair (rnn.hip)  0: one launch per time step
-//   3 "attn_bwd_dq_variant"  2: single-pass backward (dQ, dK, dV from one S / dP evaluation, attention_bwd1_bx3.h; precision
+//   3 "attn_bwd_dq_variant"  3: single pass with one wave per SIMD (attention_bwd1w_bx3.h; measured slower: A/B only)
+//                            2: single-pass backward (dQ, dK, dV from one S / dP evaluation, attention_bwd1_bx3.h; precision
 //                            modes 2 / 3, Ntok % 256 == 0, else as 1)   1: two passes, dQ pass with 256-query blocks (two
 //                            tiles per wave)   0: two passes, 128-query blocks
 static std::atomic<int> g_tuning[FOCR_TUNING_COUNT] = {{1}, {1}, {1}, {2}};
