@@ -394,7 +394,7 @@ def test_attention_backward_single_pass(p, t):
         qkv = rnd(b, t, 384, seed=11, scale=1.5).requires_grad_(True)
         go = rnd(b, t, 128, seed=4)
         res = {}
-        for variant in (2, 1):
+        for variant in (2, 3, 1):         # 2 = the default single pass, 3 = its one-wave-per-SIMD form (A/B), 1 = two passes
             _lib.call("focr_set_tuning", 3, variant)
             x = dev(qkv).requires_grad_(True)
             od = _AttentionPacked.apply(x, 4, p, 4242)
@@ -417,13 +417,15 @@ def test_attention_backward_single_pass(p, t):
             pr = pr * keep / (1 - round(p * 4096) * 16 / 65536)
         o = (pr @ heads(v)).transpose(1, 2).reshape(b, t, 128)
         o.backward(go)
-        o1, g1 = res[2]
         o2, g2 = res[1]
-        assert torch.equal(o1, o2)
-        close(o1, o, ptol(2), what="single-pass: forward")
-        close(g1, qkv.grad, gtol(2), what="single-pass: d qkv vs fp64")
-        assert torch.equal(g1[..., 128:], g2[..., 128:]), "dK / dV of the single-pass and two-pass kernels differ"
-        close(g1[..., :128], g2[..., :128], 4e-3, what="single-pass dQ vs two-pass dQ")
+        for variant in (2, 3):
+            o1, g1 = res[variant]
+            assert torch.equal(o1, o2)
+            close(o1, o, ptol(2), what="single-pass: forward")
+            close(g1, qkv.grad, gtol(2), what="single-pass (variant %d): d qkv vs fp64" % variant)
+            assert torch.equal(g1[..., 128:], g2[..., 128:]), "dK / dV of the single-pass and two-pass kernels differ"
+            close(g1[..., :128], g2[..., :128], 4e-3, what="single-pass dQ vs two-pass dQ")
+        assert torch.equal(res[2][1], res[3][1]), "the two single-pass forms differ"
     finally:
         _lib.call("focr_set_tuning", 3, 2)
         _lib.set_precision(2)
