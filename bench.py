@@ -422,11 +422,24 @@ def main():
             single = mode >= 2 and _lib.load().focr_get_tuning(3) == 2
             r = row("attn_bwd1_bx3_kernel (single pass: dQ, dK, dV from ONE S / dP evaluation; 2.5x the forward flops)"
                     if single else "attention backward (dK/dV + dQ launches; 2.5x the forward flops)",
-                    2.5 * fa * len(bwd), 0.0, sum(bwd), len(bwd),
+                    2.5 * fa * len(bwd),
+                    # algorithmic bytes: q, k, v, dO read + dq, dk, dv written once (fp32 [B,4,1024,32] each), the keep
+                    # bits (1 bit per score) and the LSE / D row vectors
+                    (7 * batch * 4 * 1024 * 32 * 4.0 + batch * 4 * 1024 * 1024 / 8.0 + 2 * batch * 4 * 1024 * 4.0)
+                    * len(bwd) if single else 0.0, sum(bwd), len(bwd),
                     # executed MFMA flops per algorithmic flop: S and dP split (3 products), dV / dK / dQ single bf16
                     (6 + 6 + 2 + 2 + 2) / 10.0 if single else (3 if bx3 else 1))
             r["launches_per_step"] = len(bwd) // args.steps
-            also.append(r)
+            if single and sum(bwd) > ms:
+                # the single-pass attention backward is now the kernel with the largest share of the step (more than
+                # both conv3x3_halo_kernel instantiations together): it becomes the headline row, the halo kernel
+                # moves to `also`.  PMC traffic from the same artefact (rocprofv3 --pmc passes, tools/pmc_traffic.py).
+                traffic, prov = _pmc("attn_bwd1_bx3_kernel", batch) if cfg == "c3" else (None, None)
+                r.update({"traffic": traffic, "traffic_provenance": prov})
+                roof, r = r, roof
+                also.insert(0, r)
+            else:
+                also.append(r)
         # fused FeatureEnhancer row chains (csrc/fe_chain.hip): HBM-bound; algorithmic bytes = the [rows, 128] fp32
         # matrices each call reads + writes once (forward pair 8, backward pair 9.5, QKV data gradient 4)
         for name, nmat, nlaunch in (("focr_fe_post_fwd", 8.0, 2), ("focr_fe_post_bwd", 9.5, 2), ("focr_fe_qkv_dgrad", 4.0, 1)):

@@ -39,7 +39,8 @@ def main():
     short = {"conv3x3_halo_kernel": "conv3x3_halo_kernel", "conv_fwd_bx3_kernel": "conv_fwd_bx3_kernel",
              "linear_stream_bx3_kernel": "linear_stream_bx3_kernel", "attn_fwd2_bx3_kernel": "attn_fwd2_bx3_kernel",
              "attn_bwd_dkv_bx3_kernel": "attn_bwd_dkv_bx3_kernel", "attn_bwd_dq_bx3_kernel": "attn_bwd_dq_bx3_kernel",
-             "attn_bwd_dq2_bx3_kernel": "attn_bwd_dq2_bx3_kernel", "fe_qkv_fwd_kernel": "fe_qkv_fwd_kernel",
+             "attn_bwd_dq2_bx3_kernel": "attn_bwd_dq2_bx3_kernel", "attn_bwd1_bx3_kernel": "attn_bwd1_bx3_kernel",
+             "fe_qkv_fwd_kernel": "fe_qkv_fwd_kernel",
              "fe_fwd_a_kernel": "fe_fwd_a_kernel", "fe_fwd_b_kernel": "fe_fwd_b_kernel", "fe_bwd_a_kernel": "fe_bwd_a_kernel",
              "fe_bwd_b_kernel": "fe_bwd_b_kernel", "fe_bwd_qkv_kernel": "fe_bwd_qkv_kernel"}
     out["step_total"] = {"fetch_kb": sum(t for _, t in fetch.values()), "write_kb": sum(t for _, t in write.values()),
