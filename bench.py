@@ -428,7 +428,8 @@ def main():
                     (7 * batch * 4 * 1024 * 32 * 4.0 + batch * 4 * 1024 * 1024 / 8.0 + 2 * batch * 4 * 1024 * 4.0)
                     * len(bwd) if single else 0.0, sum(bwd), len(bwd),
                     # executed MFMA flops per algorithmic flop: S and dP split (3 products), dV / dK / dQ single bf16
-                    (6 + 6 + 2 + 2 + 2) / 10.0 if single else (3 if bx3 else 1))
+                    # (mode 3: dP single bf16 as well)
+                    ((6 + (2 if mode >= 3 else 6) + 2 + 2 + 2) / 10.0) if single else (3 if bx3 else 1))
             r["launches_per_step"] = len(bwd) // args.steps
             if single and sum(bwd) > ms:
                 # the single-pass attention backward is now the kernel with the largest share of the step (more than

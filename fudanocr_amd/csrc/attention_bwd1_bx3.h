@@ -38,7 +38,16 @@ __device__ __forceinline__ bf16x4 b1_tr_read(const unsigned char* p) {
 // the 2 x 4 (row parity, chunk group) combinations of the 64-bank read space.
 __device__ __forceinline__ int b1_swz(int row) { return (((row >> 1) & 3) << 2) | (((row >> 3) & 1) << 1) | (row & 1); }
 
-template <bool DROPOUT>
+// hi plane only of two staged rows (DP1: the dO rows)
+__device__ __forceinline__ void b1_put_rows_hi(__bf16* Th, int rp, int c0, float4 r0, float4 r1) {
+  *reinterpret_cast<bf16x4*>(&Th[(2 * rp) * RP + c0]) = __builtin_convertvector(f32x4{r0.x, r0.y, r0.z, r0.w}, bf16x4);
+  *reinterpret_cast<bf16x4*>(&Th[(2 * rp + 1) * RP + c0]) = __builtin_convertvector(f32x4{r1.x, r1.y, r1.z, r1.w}, bf16x4);
+}
+
+// DP1 (precision mode 3, "bf16 data gradients"): dP = dO V^T -- the data gradient of O = P V with respect to P -- as ONE
+// bf16 product (dO, V rounded to bf16) like the convolutions' data gradients in that mode: 14 instead of 18
+// MFMA-equivalents per tile, no lo plane of the staged dO rows.  S is a forward recomputation and stays split.
+template <bool DROPOUT, bool DP1 = false>
 __global__ __launch_bounds__(512, 2) void attn_bwd1_bx3_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ Dv, float* dQ,
@@ -97,7 +106,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_bx3_kernel(
     __bf16* rh_ = st_ + ten * (2 * 64 * RP);                                                       \
     __bf16* th_ = st_ + 4 * 64 * RP + ten * (32 * TP);                                             \
     const float4 a_ = scale4(r0, stg_scale), b_ = scale4(r1, stg_scale);                           \
-    put_rows(rh_, rh_ + 64 * RP, rp, c0, a_, b_);                                                  \
+    if (DP1 && ten) b1_put_rows_hi(rh_, rp, c0, a_, b_);                                           \
+    else put_rows(rh_, rh_ + 64 * RP, rp, c0, a_, b_);                                             \
     put_cols_hi(th_, rp, c0, a_, b_);                                                              \
     float* ls_ = reinterpret_cast<float*>(b1_smem + B1_OFF_LS);                                    \
     if (t8 < 64) ls_[128 * ten + (buf_) * 64 + t8] = ten ? lreg : -lreg * LOG2E;                   \
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_bx3_kernel(
       f.qh[m] = *reinterpret_cast<const bf16x8*>(&st[off]);
       f.ql[m] = *reinterpret_cast<const bf16x8*>(&st[64 * RP + off]);
       f.gh[m] = *reinterpret_cast<const bf16x8*>(&st[2 * 64 * RP + off]);
-      f.gl[m] = *reinterpret_cast<const bf16x8*>(&st[3 * 64 * RP + off]);
+      if constexpr (!DP1) f.gl[m] = *reinterpret_cast<const bf16x8*>(&st[3 * 64 * RP + off]);
     }
   };
   struct ColFrag { bf16x8 qt[2], gt[2]; };
@@ -202,8 +212,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_bx3_kernel(
   } while (0)
   auto scores = [&](f32x16& s, f32x16& dp, const RowFrag& f) {
 #ifndef B1_ABL_MFMA12
-    B1_MFMA_PAIR(s, dp, f, 0, 0, 0); B1_MFMA_PAIR(s, dp, f, 0, 0, 1); B1_MFMA_PAIR(s, dp, f, 0, 1, 0);
-    B1_MFMA_PAIR(s, dp, f, 1, 0, 0); B1_MFMA_PAIR(s, dp, f, 1, 0, 1); B1_MFMA_PAIR(s, dp, f, 1, 1, 0);
+    if constexpr (DP1) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.qh[m], kh[m], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.gh[m], vh[m], dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.qh[m], kl[m], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ql[m], kh[m], s, 0, 0, 0);
+      }
+    } else {
+      B1_MFMA_PAIR(s, dp, f, 0, 0, 0); B1_MFMA_PAIR(s, dp, f, 0, 0, 1); B1_MFMA_PAIR(s, dp, f, 0, 1, 0);
+      B1_MFMA_PAIR(s, dp, f, 1, 0, 0); B1_MFMA_PAIR(s, dp, f, 1, 0, 1); B1_MFMA_PAIR(s, dp, f, 1, 1, 0);
+    }
 #else
     s[0] += (float)f.qh[0][0] + (float)f.ql[1][1]; dp[0] += (float)f.gh[0][0] + (float)f.gl[1][0];
 #endif
@@ -331,7 +351,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_bx3_kernel(
   __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                 \
   __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);               \
   __builtin_amdgcn_sched_group_barrier(0x2, DROPOUT ? 4 : 2, 0);
-      B1_GROUP B1_GROUP B1_GROUP B1_GROUP B1_GROUP B1_GROUP B1_GROUP B1_GROUP B1_GROUP B1_GROUP B1_GROUP B1_GROUP
+#define B1_GROUP_R                                                 \
+  __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);               \
+  __builtin_amdgcn_sched_group_barrier(0x2, DROPOUT ? 4 : 2, 0);
+      if constexpr (DP1) {      // 8 matrix instructions over the same 12 registers' VALU work
+        B1_GROUP B1_GROUP B1_GROUP_R B1_GROUP B1_GROUP B1_GROUP_R B1_GROUP B1_GROUP B1_GROUP_R B1_GROUP B1_GROUP B1_GROUP_R
+      } else {
+        B1_GROUP B1_GROUP B1_GROUP B1_GROUP B1_GROUP B1_GROUP B1_GROUP B1_GROUP B1_GROUP B1_GROUP B1_GROUP B1_GROUP
+      }
+#undef B1_GROUP_R
 #undef B1_GROUP
 #endif
       __builtin_amdgcn_sched_barrier(0);

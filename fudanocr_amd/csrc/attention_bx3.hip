@@ -1162,15 +1162,27 @@ int focr_attn_bwd_bx3(const float* q, const float* k, const float* v, const floa
   if (fast && focr_get_tuning(FOCR_TUNE_ATTN_BWD_DQ_VARIANT) == 2 && Ntok % 256 == 0) {
     // single pass: dQ, dK, dV from one S / dP evaluation (attention_bwd1_bx3.h); 138.5 KB of LDS per block.  The
     // attribute is per device: set on every call (a host-side table lookup) rather than cached in a process-wide flag.
+    // Mode 3 (bf16 data gradients): dP = dO V^T as a single bf16 product (template flag DP1).
+#ifdef B1_NO_DP1                     // A/B builds (tools/gpu): the split dP product in every mode
+    const bool dp1 = false;
+#else
+    const bool dp1 = focr_get_precision() >= 3;
+#endif
+#define LAUNCH_BWD1(DR, D1)                                                                                       \
+  do {                                                                                                            \
+    (void)hipFuncSetAttribute((const void*)attn_bwd1_bx3_kernel<DR, D1>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              B1_LDS_BYTES);                                                                      \
+    hipLaunchKernelGGL((attn_bwd1_bx3_kernel<DR, D1>), dim3(B * H), 512, B1_LDS_BYTES, stream, q, k, v, d_o, lse, dwork, \
+                       dq, dk, dv, mask, Ntok, ld, ldo, ld, scale, p_drop, H);                                    \
+  } while (0)
     if (p_drop > 0.f) {
-      (void)hipFuncSetAttribute((const void*)attn_bwd1_bx3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, B1_LDS_BYTES);
-      hipLaunchKernelGGL((attn_bwd1_bx3_kernel<true>), dim3(B * H), 512, B1_LDS_BYTES, stream, q, k, v, d_o, lse, dwork, dq,
-                         dk, dv, mask, Ntok, ld, ldo, ld, scale, p_drop, H);
+      if (dp1) LAUNCH_BWD1(true, true);
+      else LAUNCH_BWD1(true, false);
     } else {
-      (void)hipFuncSetAttribute((const void*)attn_bwd1_bx3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, B1_LDS_BYTES);
-      hipLaunchKernelGGL((attn_bwd1_bx3_kernel<false>), dim3(B * H), 512, B1_LDS_BYTES, stream, q, k, v, d_o, lse, dwork, dq,
-                         dk, dv, mask, Ntok, ld, ldo, ld, scale, p_drop, H);
+      if (dp1) LAUNCH_BWD1(false, true);
+      else LAUNCH_BWD1(false, false);
     }
+#undef LAUNCH_BWD1
     return 0;
   }
   dim3 grid(B * H * (Ntok / 128));

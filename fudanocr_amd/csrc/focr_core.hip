@@ -25,6 +25,10 @@ extern "C" int focr_version(void) { return 100; }
 //       product (activations' gradients and weights rounded to bf16, fp32 accumulate) -- the arithmetic of every
 //       bf16 mixed-precision training stack.  Forward results are identical to 1 and 2; the host selects the plane
 //       count per call (focr_conv3x3_frag_fwd), this flag only tells it what the library-wide choice is.
+//       Round 4: the same rule for the attention's data gradient dP = dO V^T in the single-pass backward
+//       (attention_bwd1_bx3.h, template flag DP1: dO and V rounded to bf16, one product; the score recomputation stays
+//       split).  Measured against fp64 with the kernel's own keep bits: d qkv error 3.1e-4 .. 5.7e-4 of max (mode 2:
+//       2.4e-4 .. 4.9e-4; gate 3e-3), kernel 444 -> 396 us, step 13.87 -> 13.55 ms.
 // (atomics: both words are read from PyTorch autograd worker threads while the main thread may set them -- SURVEY 8(b):
 // no unguarded global state.  Relaxed order is enough, a mode switch is only meaningful between steps.)
 static std::atomic<int> g_precision{2};

@@ -101,6 +101,7 @@ class StepContext:
         self.mask_prefetch = False       # engine-owned contexts draw the attention keep bits ahead of time
         self._masks = []                 # per attention call of a step: {"key", "mask", "event"}
         self._mask_cursor = 0
+        self._early_done = False
         self._pending_side = []          # weight-gradient launches parked for a better moment (defer_side)
 
     # -- attention dropout keep bits.  They depend on (shape, p, seed) only, so the engine draws the bits of ALL
@@ -125,23 +126,50 @@ class StepContext:
         return mask, False
 
     def prefetch_masks(self):
-        """start of an engine step: redraw every recorded mask on the side stream.  The buffers are the ones the
-        previous step's backward read; that backward is already queued on the current stream, which the side stream
-        waits for first."""
+        """start of an engine step: every recorded mask either was drawn EARLY into its second buffer (see
+        `prefetch_masks_early`: the buffers are swapped) or is redrawn now on the side stream.  The buffers redrawn
+        here are the ones the previous step's backward read; that backward is already queued on the current stream,
+        which the side stream waits for first."""
         self._mask_cursor = 0
+        self._early_done = False
         if not (self.mask_prefetch and self._masks):
             return
+        late = [m for m in self._masks if m.get("alt_event") is None]
+        for m in self._masks:
+            if m.get("alt_event") is not None:
+                m["mask"], m["alt"] = m["alt"], m["mask"]
+                m["event"], m["alt_event"] = m["alt_event"], None
+        if late:
+            self._draw_masks(late, "mask", "event")
+
+    def _draw_masks(self, entries, buf, evt):
         if self.side_stream_obj is None:
             self.side_stream_obj = torch.cuda.Stream()
         s = self.side_stream_obj
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            for m in self._masks:
+            for m in entries:
                 b, heads, t, p, _ = m["key"]
-                _lib.call("focr_attention_dropout_mask", _p(m["mask"]), b, heads, t, p, _new_seed(), _stream())
+                _lib.call("focr_attention_dropout_mask", _p(m[buf]), b, heads, t, p, _new_seed(), _stream())
                 ev = torch.cuda.Event()
                 ev.record(s)
-                m["event"] = ev
+                m[evt] = ev
+
+    def prefetch_masks_early(self):
+        """called in front of the recognizer's LSTM scan (a latency-bound persistent kernel that leaves HBM and most CUs
+        idle for ~0.4 ms): the keep bits of the NEXT step are drawn now, on the side stream, into a second buffer per
+        attention call -- the current step's backward still reads the first one.  The second buffer was last read by
+        the backward of the step before this one, which the current stream (that the side stream waits for) has behind
+        it.  A step without such a call (SR-only configurations) draws at the step start as before."""
+        if not (self.mask_prefetch and _MASK_EARLY and self._masks) or self._early_done:
+            return
+        if self._mask_cursor != len(self._masks):          # not every attention call of this step has happened yet
+            return
+        self._early_done = True
+        for m in self._masks:
+            if m.get("alt") is None:
+                m["alt"] = torch.empty_like(m["mask"])
+        self._draw_masks(self._masks, "alt", "alt_event")
 
     # -- deferred residual gradients
     def defer_grad(self, t, g):
@@ -1022,6 +1050,11 @@ _DGRAD_FIRST = os.environ.get("FOCR_DGRAD_FIRST", "1") != "0"
 # block's attention backward.  Measured (same box, interleaved): 15.32 ms vs 15.13 ms without -- the attention kernels lose
 # more to the extra company than the HBM-bound kernels gain; off by default, kept as an A/B switch.
 _DEFER_SIDE = os.environ.get("FOCR_DEFER_SIDE", "0") == "1"
+# FOCR_MASK_EARLY=1: next step's attention keep bits drawn under the recognizer's LSTM scan (second buffer per attention
+# call) instead of at the step start.  Measured (tools/gpu/r04_call25.sh, interleaved): 13.56 / 13.55 ms with, 13.45 / 13.50
+# ms without -- the 8-block groups of the persistent scan lose more to the company of the mask blocks than the first
+# forward kernels of the step gain; off by default, kept as an A/B switch.
+_MASK_EARLY = os.environ.get("FOCR_MASK_EARLY", "0") == "1"
 # FOCR_FE_WGRAD_EARLY=0: all weight gradients of a FeatureEnhancer after its attention backward (A/B measurements)
 _FE_WGRAD_EARLY = os.environ.get("FOCR_FE_WGRAD_EARLY", "1") != "0"
 FE_PARAM_NAMES = ("wqkv", "bqkv", "wo", "bo", "a1", "b1", "w1", "bb1", "w2", "bb2", "a3", "b3", "wl", "bl")
@@ -1585,6 +1618,8 @@ class _LSTMRecur(torch.autograd.Function):
         gates = torch.empty((t_len, batch, 2, 4 * hid), device=gx.device)
         cseq = torch.empty((t_len, batch, 2, hid), device=gx.device)
         ws = torch.empty(_lib.load().focr_lstm_ws_bytes(t_len, batch, hid, 0), device=gx.device, dtype=torch.uint8)
+        if ctx.needs_input_grad[0]:
+            current_context().prefetch_masks_early()
         _lib.call("focr_lstm_bidir_fwd", _p(gx), _p(whh), _p(bhh), _p(hseq), _p(gates), _p(cseq), _p(ws), t_len,
                   batch, hid, st_t, st_b, _stream())
         _lstm_check(ws, batch)

@@ -40,8 +40,8 @@ int focr_version(void);
 /* contraction precision of the kernels that have both paths (process-wide):
  *   0 = exact fp32 on the f32-input MFMA; 1 = split bf16 "bf16x3" (hi/lo operands, 3 products, fp32 accumulate) on the
  *   bf16 MFMA pipe -- same end-to-end error as fp32 (tools/exp_split_precision.py); 2 (default) = 1 with single-bf16
- *   gradient accumulations in the attention backward; 3 = 2 with single-bf16 data-gradient convolutions on the halo
- *   kernel.  Forward results are identical in modes 1-3 (csrc/focr_core.hip). */
+ *   gradient accumulations in the attention backward; 3 = 2 with single-bf16 data-gradient products: the data-gradient
+ *   convolutions on the halo kernel and dP = dO V^T in the single-pass attention backward (S stays split).  Forward results are identical in modes 1-3 (csrc/focr_core.hip). */
 int focr_set_precision(int mode);
 /* A/B kernel-selection switches for measurements (results do not depend on them; defaults are the production
  * kernels).  key 0: transformer-linear weight gradients on the streaming kernel (1, default) or the generic split

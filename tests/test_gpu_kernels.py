@@ -3,6 +3,7 @@ fudanocr_amd.kernels) against a plain PyTorch CPU float64 reference of the same 
 Tolerance: fp32 kernels, so 2e-5 * (1 + max|ref|) on values (accumulation-order noise only);
 the end-to-end 1e-3 gate of north_star is checked in test_gpu_models.py."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -38,6 +39,14 @@ def precision(request):
     _lib.set_precision(request.param)
     yield request.param
     _lib.set_precision(old)
+
+
+def _note_margin(msg):
+    """measured margins of the tolerance tests, kept with the run's other outputs when that directory exists"""
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "test_margins.txt"), "a") as f:
+            f.write(msg + "\n")
 
 
 def ptol(precision, base=2e-5):
@@ -426,6 +435,21 @@ def test_attention_backward_single_pass(p, t):
             assert torch.equal(g1[..., 128:], g2[..., 128:]), "dK / dV of the single-pass and two-pass kernels differ"
             close(g1[..., :128], g2[..., :128], 4e-3, what="single-pass dQ vs two-pass dQ")
         assert torch.equal(res[2][1], res[3][1]), "the two single-pass forms differ"
+        # precision mode 3 ("bf16 data gradients"): the same kernel with dP = dO V^T as ONE bf16 product (template flag
+        # DP1) -- same keep bits (same seed), same forward; the gradient against the fp64 reference at the mode's gate
+        _lib.set_precision(3)
+        _lib.call("focr_set_tuning", 3, 2)
+        x = dev(qkv).requires_grad_(True)
+        od = _AttentionPacked.apply(x, 4, p, 4242)
+        od.backward(dev(go))
+        assert torch.equal(od.detach().cpu(), o2)
+        g3 = x.grad.detach().cpu()
+        e2 = (res[2][1].double() - qkv.grad).abs().max().item() / (1 + qkv.grad.abs().max().item())
+        e3 = (g3.double() - qkv.grad).abs().max().item() / (1 + qkv.grad.abs().max().item())
+        _note_margin("attention single-pass d qkv vs fp64 (p=%g, t=%d): mode 2 %.2e, mode 3 (bf16 dP) %.2e, gate %.0e"
+                     % (p, t, e2, e3, gtol(3)))
+        close(g3, qkv.grad, gtol(3), what="single-pass, mode 3 (single-bf16 dP): d qkv vs fp64")
+        assert torch.equal(g3[..., 256:], res[2][1][..., 256:]), "dV does not depend on dP"
     finally:
         _lib.call("focr_set_tuning", 3, 2)
         _lib.set_precision(2)

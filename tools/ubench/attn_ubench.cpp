@@ -122,6 +122,24 @@ int main(int argc, char** argv) {
       fq = maxdiff(dq1, dq2, n, &n1); fk = maxdiff(dk1, dk2, n, &n2); fv = maxdiff(dv1, dv2, n, &n3);
       printf("bwd1w p=%.1f: one wave per SIMD %7.1f us  max diff dq %.2e/%.2e dk %.2e/%.2e dv %.2e/%.2e\n", p, t3, fq, n1, fk, n2, fv, n3);
       fflush(stdout);
+      // precision mode 3: dP = dO V^T as a single bf16 product (template flag DP1), against the same two-pass result
+      CK(hipMemset(dq2, 0xff, n * 4)); CK(hipMemset(dk2, 0xff, n * 4)); CK(hipMemset(dv2, 0xff, n * 4));
+      g_tune[FOCR_TUNE_ATTN_BWD_DQ_VARIANT] = 2;
+      g_prec = 3;
+      focr_attention_bwd(q, k, v, nullptr, dO, lse0, mask, dq2, dk2, dv2, work, B, H, N, D, D, scale, p, 0);
+      CK(hipDeviceSynchronize());
+      float t4 = 1e9f, t2b = 1e9f;
+      for (int rep = 0; rep < 3; ++rep) {
+        g_prec = 2;
+        t2b = std::min(t2b, timeit([&]() { focr_attention_bwd(q, k, v, nullptr, dO, lse0, mask, dq0, dk0, dv0, work, B, H, N, D, D, scale, p, 0); }, 6));
+        g_prec = 3;
+        t4 = std::min(t4, timeit([&]() { focr_attention_bwd(q, k, v, nullptr, dO, lse0, mask, dq2, dk2, dv2, work, B, H, N, D, D, scale, p, 0); }, 6));
+      }
+      g_prec = 2;
+      CK(hipDeviceSynchronize());
+      fq = maxdiff(dq1, dq2, n, &n1); fk = maxdiff(dk1, dk2, n, &n2); fv = maxdiff(dv1, dv2, n, &n3);
+      printf("bwd1 DP1 p=%.1f: mode 2 %7.1f us  mode 3 (single-bf16 dP) %7.1f us  max diff dq %.2e/%.2e dk %.2e/%.2e dv %.2e/%.2e\n", p, t2b, t4, fq, n1, fk, n2, fv, n3);
+      fflush(stdout);
       CK(hipFree(dq2)); CK(hipFree(dk2)); CK(hipFree(dv2));
     }
     if (only_b1) continue;
