@@ -69,6 +69,9 @@ SIGNATURES = {
     "focr_maxpool_fwd": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "focr_maxpool_bwd": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "focr_maxpool_relu_bwd": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "focr_crnn_conv0_pool_supported": [I, I, I, I, I, I, I],
+    "focr_crnn_conv0_pool_fwd": [P, P, P, P, P, I, I, I, P],
+    "focr_crnn_conv0_pool_bwd": [P, P, P, P, P, I, I, I, P],
     "focr_tps_fwd": [P, P, P, P, P, P, I, I, I, I, I, P],
     "focr_tps_bwd": [P, P, P, P, P, P, I, I, I, I, I, P],
     "focr_tps_bwd_img": [P, P, P, I, I, I, I, P],

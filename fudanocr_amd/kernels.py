@@ -1524,6 +1524,57 @@ def maxpool(x, kernel, stride=None, pad=(0, 0), relu_input=False):
     return _MaxPool.apply(x, tuple(kernel), tuple(stride or kernel), tuple(pad), relu_input)
 
 
+class _Conv0ReluPool(torch.autograd.Function):
+    """Conv2d(1, 64, 3, 1, 1) -> ReLU -> MaxPool2d(2, 2) of a FROZEN recognizer in one launch each way
+    (csrc/crnn_conv0_pool.hip; model/crnn/crnn.py:51-52 of the reference): the 134 MB full-resolution activation and its
+    gradient never exist.  x: [N, H, W, 1] NHWC; weight [64, 1, 3, 3] and bias get no gradient here -- `conv0_relu_pool`
+    falls back to the per-layer path when they need one."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        n, h, w, _ = x.shape
+        _chk(x, weight)
+        y = torch.empty((n, h // 2, w // 2, 64), device=x.device)
+        idx = torch.empty((n, h // 2, w // 2, 64), device=x.device, dtype=torch.uint8)
+        _lib.call("focr_crnn_conv0_pool_fwd", _p(x), _p(weight), _p(bias), _p(y),
+                  ctypes.c_void_p(idx.data_ptr()), n, h, w, _stream())
+        ctx.cfg = (n, h, w)
+        ctx.save_for_backward(idx, y, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        idx, y, weight = ctx.saved_tensors
+        n, h, w = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty((n, h, w, 1), device=dy.device)
+        _lib.call("focr_crnn_conv0_pool_bwd", _p(dy), ctypes.c_void_p(idx.data_ptr()), _p(y), _p(weight), _p(dx), n, h, w,
+                  _stream())
+        return dx, None, None
+
+
+# FOCR_CONV0_POOL=0: first recognizer layer on the per-layer path (convolution, pooling, their two backward launches)
+_CONV0_POOL = os.environ.get("FOCR_CONV0_POOL", "1") != "0"
+
+
+def conv0_relu_pool_supported(x, weight, bias, pool_kernel, pool_stride, pool_pad):
+    """the fused first layer applies to: NHWC input with one channel, a 3x3 / pad 1 / 64-channel convolution whose
+    parameters need no gradient, 2x2 / stride 2 pooling, H % 4 == 0, even W <= 128"""
+    if not (_CONV0_POOL and x.is_cuda and x.dim() == 4 and x.shape[-1] == 1 and tuple(weight.shape) == (64, 1, 3, 3)):
+        return False
+    if torch.is_grad_enabled() and (weight.requires_grad or (bias is not None and bias.requires_grad)):
+        return False
+    if tuple(pool_kernel) != (2, 2) or tuple(pool_stride) != (2, 2) or tuple(pool_pad) != (0, 0):
+        return False
+    if not (weight.is_contiguous() and (bias is None or bias.is_contiguous())):
+        return False
+    return bool(_lib.load().focr_crnn_conv0_pool_supported(x.shape[1], x.shape[2], 1, 64, 3, 3, 1))
+
+
+def conv0_relu_pool(x, weight, bias):
+    return _Conv0ReluPool.apply(x.contiguous(), weight, bias)
+
+
 class _TPSWarp(torch.autograd.Function):
     """TPS grid + bilinear sampling of an NHWC image; gradients for the control points and -- when the image itself
     requires one (d loss / d LR image, F.grid_sample's input gradient) -- for the image."""

@@ -11,6 +11,10 @@ from ... import kernels as K
 from .._layers import BatchNorm2d, Conv2d, Linear, MaxPool2d, ReLUTag
 
 
+def _pair(v):
+    return v if isinstance(v, tuple) else (v, v)
+
+
 class BidirectionalLSTM(nn.Module):
     def __init__(self, nIn, nHidden, nOut):
         super().__init__()
@@ -85,7 +89,14 @@ class CRNN(nn.Module):
             name, m = mods[i]
             if name.startswith("conv"):
                 bn = mods[i + 1][1] if mods[i + 1][0].startswith("batchnorm") else None
-                if bn is None:
+                pool = mods[i + 2][1] if bn is None and i + 2 < len(mods) and mods[i + 2][0].startswith("pooling") else None
+                if pool is not None and K.conv0_relu_pool_supported(x, m.weight, m.bias, _pair(pool.kernel_size),
+                                                                    _pair(pool.stride), _pair(pool.padding)):
+                    # frozen first layer: conv + relu + 2x2 pooling as one launch each way (csrc/crnn_conv0_pool.hip)
+                    x = K.conv0_relu_pool(x, m.weight, m.bias)
+                    i += 3                      # conv, relu, pooling
+                    after_conv_relu = False
+                elif bn is None:
                     x = m(x, relu=True)
                     i += 2                      # conv, relu
                     after_conv_relu = True

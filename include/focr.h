@@ -300,6 +300,16 @@ int focr_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int N, int 
  * ypool = the pooling forward output; gradients of windows whose maximum is 0 are dropped (relu'(y <= 0) = 0) */
 int focr_maxpool_relu_bwd(const float* dy, const uint8_t* idx, const float* ypool, float* dx, int N, int H, int W, int C,
                           int kh, int kw, int sh, int sw, int ph, int pw, focr_stream_t stream);
+/* First recognizer layer fused with its activation and pooling: Conv2d(1, 64, 3, 1, 1) -> ReLU -> MaxPool2d(2, 2)
+ * (model/crnn/crnn.py:51-52 convRelu(0) + pooling0), frozen-recognizer form (interfaces/super_resolution.py:168-171: the
+ * training step needs d loss / d input only).  x [N, H, W, 1]; w [64][3][3][1] = nn.Conv2d's [64, 1, 3, 3]; bias [64] or
+ * NULL; y, ypool, dy [N, H/2, W/2, 64]; idx uint8 window-local argmax (focr_maxpool_fwd's rule); dx [N, H, W, 1].
+ * H % 4 == 0, W even and <= 128.  fp32 arithmetic in every precision mode. */
+int focr_crnn_conv0_pool_supported(int H, int W, int Cin, int Cout, int KH, int KW, int pad);
+int focr_crnn_conv0_pool_fwd(const float* x, const float* w, const float* bias, float* y, uint8_t* idx, int N, int H,
+                             int W, focr_stream_t stream);
+int focr_crnn_conv0_pool_bwd(const float* dy, const uint8_t* idx, const float* ypool, const float* w, float* dx, int N,
+                             int H, int W, focr_stream_t stream);
 /* TPS grid + F.grid_sample: model/tps_spatial_transformer.py:97-111,10-18 ; src: [B,H*W,2] */
 int focr_tps_fwd(const float* img, const float* ctrl, const float* inv_kernel, const float* coord_repr,
                  float* out, float* src, int B, int H, int W, int C, int NC, focr_stream_t stream);

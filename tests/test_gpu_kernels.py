@@ -642,6 +642,54 @@ def test_conv_relu_maxpool_fused_relu_backward():
         close(dbd, b.grad, ptol(2), what="conv-relu-pool db")
 
 
+@pytest.mark.parametrize("shape", [(3, 32, 128), (2, 8, 20), (1, 4, 2)])
+def test_crnn_conv0_relu_pool_fused(shape):
+    """csrc/crnn_conv0_pool.hip (crnn.py:51-52 conv0 -> relu -> pooling0 of the frozen recognizer, one launch each way).
+    Forward against F.conv2d + relu + max_pool2d in float64; the argmax bytes must point at a maximal window element; the
+    data gradient against a float64 conv_transpose2d of the gradient routed with the kernel's OWN argmax bytes and relu
+    mask (a near-tie inside a window or a pre-activation at the relu kink may be decided differently by any two
+    arithmetics: that is a different, equally valid routing, not an error); and against the per-layer HIP path."""
+    from fudanocr_amd import kernels as KM
+    n, h, w = shape
+    x = rnd(n, 1, h, w, seed=5)
+    wt = rnd(64, 1, 3, 3, seed=6) * 0.5
+    b = rnd(64, seed=7) * 0.3 - 0.2
+    gy = rnd(n, 64, h // 2, w // 2, seed=8)
+    xd = dev(x.permute(0, 2, 3, 1)).requires_grad_(True)
+    wd, bd = dev(wt), dev(b)
+    assert KM.conv0_relu_pool_supported(xd, wd, bd, (2, 2), (2, 2), (0, 0))
+    yd = KM.conv0_relu_pool(xd, wd, bd)
+    idx = yd.grad_fn.saved_tensors[0].cpu().permute(0, 3, 1, 2).long()
+    yd.backward(dev(gy.permute(0, 2, 3, 1)))
+    a = F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1))
+    y = F.max_pool2d(a, 2)
+    if y.numel() > 1000:
+        assert 0.05 < (y == 0).double().mean().item() < 0.95      # both relu branches are exercised
+    yk = yd.detach().cpu().permute(0, 3, 1, 2).double()
+    close(yk, y, what="conv0-relu-pool fwd")
+    win = a.unfold(2, 2, 2).unfold(3, 2, 2).reshape(n, 64, h // 2, w // 2, 4)       # [..., 2 a + b]
+    assert int(idx.max()) <= 3
+    pick = torch.gather(win, -1, idx.unsqueeze(-1)).squeeze(-1)
+    assert (y - pick).abs().max().item() <= 2e-5 * (1 + y.abs().max().item()), "argmax byte does not point at a maximum"
+    gm = gy.double() * (yk > 0)
+    full = torch.zeros(n, 64, h // 2, w // 2, 4, dtype=torch.float64).scatter_(-1, idx.unsqueeze(-1), gm.unsqueeze(-1))
+    full = full.reshape(n, 64, h // 2, w // 2, 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, 64, h, w)
+    dx_ref = F.conv_transpose2d(full, wt.double(), padding=1)
+    close(xd.grad.permute(0, 3, 1, 2), dx_ref, what="conv0-relu-pool dx (kernel's routing)")
+    # per-layer HIP path (convolution with fused relu, pooling whose backward applies the relu backward)
+    x2 = dev(x.permute(0, 2, 3, 1)).requires_grad_(True)
+    y2 = KM.maxpool(KM.conv2d(x2, wd, bd, pad=(1, 1), relu=True), (2, 2), relu_input=True)
+    y2.backward(dev(gy.permute(0, 2, 3, 1)))
+    close(yd, y2, what="fused vs per-layer forward")
+    # (99.9 % quantile: the two forward arithmetics may route a near-tie differently, see above)
+    d = (xd.grad - x2.grad).abs().flatten().double().cpu()
+    assert torch.quantile(d, 0.999).item() <= 5e-4 * (1 + x2.grad.abs().max().item()), "fused vs per-layer dx"
+    # a trainable first layer keeps the per-layer path
+    wreq = dev(wt).requires_grad_(True)
+    assert not KM.conv0_relu_pool_supported(xd, wreq, bd, (2, 2), (2, 2), (0, 0))
+    assert not KM.conv0_relu_pool_supported(xd, wd, bd, (2, 2), (2, 1), (0, 1))
+
+
 def test_tps_warp():
     from oracle import sr_oracle as O
     inv, rep, ctrl0 = O.tps_constants()
