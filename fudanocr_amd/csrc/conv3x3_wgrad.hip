@@ -72,6 +72,16 @@ __device__ __forceinline__ void stage_x(__bf16* Xh, __bf16* Xl, int c4, int pq, 
   }
 }
 
+#ifdef C3W_TIMING      // timing-only builds: s_memtime stamps of wave 0 of every block (tools/dev/c3w_timing.py)
+__device__ unsigned long long c3w_stamps[1024][16];
+extern "C" int focr_debug_c3w_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(c3w_stamps), sizeof(c3w_stamps)) == hipSuccess ? 0 : -1;
+}
+#define C3W_STAMP(i) do { if (tid == 0 && blockIdx.y < 1024) c3w_stamps[blockIdx.y][i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define C3W_STAMP(i) do { } while (0)
+#endif
+
 // PART != nullptr: the block writes its 9 x 64 x 64 partial tile to PART[blockIdx.y][co tile] with plain stores (no
 // same-address atomics: 256 blocks adding into one 147 KB array cost as much as the rest of the kernel) and
 // conv3x3_c64_reduce_kernel folds them.  PART == nullptr: fp32 atomics into dW.
@@ -86,6 +96,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64_wgrad_kernel(const float* __r
   __bf16* Dh = Xl + 3 * TILE_E;                        // [3 slots][64 co][GP]
   __bf16* Dl = Dh + 3 * TILE_E;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  C3W_STAMP(0);
   const int co0 = blockIdx.x * 64;
   const int R0 = blockIdx.y * rows_per_block, R1 = min(N * H, R0 + rows_per_block);
   if (R0 >= R1) return;
@@ -108,22 +119,35 @@ __global__ __launch_bounds__(256) void conv3x3_c64_wgrad_kernel(const float* __r
     _Pragma("unroll") for (int j = 0; j < 4; ++j) xr[j] =                                                \
         pxok ? *reinterpret_cast<const float4*>(p_ + (size_t)j * ldx) : make_float4(0.f, 0.f, 0.f, 0.f); \
   }
-#define LOAD_D(G)                                                                                        \
+#define LOAD_D_TO(G, R_)                                                                                 \
   {                                                                                                      \
     const float* p_ = dY + ((size_t)(G) * W + 4 * pq) * ldd + co0 + c4;                                  \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) dr[j] =                                                \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) R_[j] =                                                \
         pxok ? *reinterpret_cast<const float4*>(p_ + (size_t)j * ldd) : make_float4(0.f, 0.f, 0.f, 0.f); \
   }
-#define STAGE_D(G)                                                                                       \
+#define STAGE_D_FROM(G, R_)                                                                              \
   {                                                                                                      \
     const int s_ = (G) % 3;                                                                              \
-    stage_d(Dh + s_ * TILE_E, Dl + s_ * TILE_E, c4, pq, dr);                                             \
+    stage_d(Dh + s_ * TILE_E, Dl + s_ * TILE_E, c4, pq, R_);                                             \
     if (dbias && (G) >= R0 && (G) < R1) {                                                                \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                    \
-        bsum[0] += dr[j].x; bsum[1] += dr[j].y; bsum[2] += dr[j].z; bsum[3] += dr[j].w;                  \
+        bsum[0] += R_[j].x; bsum[1] += R_[j].y; bsum[2] += R_[j].z; bsum[3] += R_[j].w;                  \
       }                                                                                                  \
     }                                                                                                    \
   }
+// a dY row outside the image: zeros in its window slot, so that the product loop below needs no row conditions (straight-line
+// code: hipcc hoists the fragment reads over the matrix instructions; with `if (row valid)` around every tap row each of the
+// twelve (k step, tap row) groups waited out its own LDS reads)
+#define ZERO_D(G)                                                                                        \
+  {                                                                                                      \
+    const int s_ = (G) % 3;                                                                              \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                      \
+      st2(&Dh[s_ * TILE_E + (c4 + e) * GP + 4 * pq], 0u, 0u);                                            \
+      st2(&Dl[s_ * TILE_E + (c4 + e) * GP + 4 * pq], 0u, 0u);                                            \
+    }                                                                                                    \
+  }
+#define LOAD_D(G) LOAD_D_TO(G, dr)
+#define STAGE_D(G) STAGE_D_FROM(G, dr)
 
   bool have_x = false, have_d = false;                 // registers hold X row g / dY row g + 1 of the coming step
   for (int g = R0; g < R1; ++g) {
@@ -131,21 +155,51 @@ __global__ __launch_bounds__(256) void conv3x3_c64_wgrad_kernel(const float* __r
     const bool first = g == R0;
     // dY rows of this step: g + 1 - kh, valid while inside the image
     const bool v0 = iy + 1 < H, v1 = true, v2 = iy > 0;
+#if defined(C3W_ABL_LOAD) || defined(C3W_ABL_STAGE)     // timing-only builds: loads / staging of the first step only
+#ifdef C3W_ABL_LOAD
+#define C3W_LD first
+#define C3W_ST true
+#else
+#define C3W_LD true
+#define C3W_ST first
+#endif
+#else
+#define C3W_LD true
+#define C3W_ST true
+#endif
     if (first || iy == 0) {                            // window not primed (block start / new image): rows g-1, g
-      if (v2 && first) { LOAD_D(g - 1) STAGE_D(g - 1) }
-      LOAD_D(g) STAGE_D(g)
+      // ALL requests of the priming step go out before the first of them is consumed (round 4: they were issued and
+      // waited for one after the other -- four dependent HBM round trips, ~10 of the kernel's 43 us with 8 rows per block)
+      const bool pa = v2 && first;
+      float4 da[4], db[4];
+      LOAD_D_TO(pa ? g - 1 : g, da)
+      if (C3W_LD) LOAD_D_TO(g, db)
+      if (v0 && !have_d && C3W_LD) { LOAD_D(g + 1) have_d = true; }
+      if (!have_x && C3W_LD) { LOAD_X(g) have_x = true; }
+      if (pa) STAGE_D_FROM(g - 1, da)
+      if (C3W_ST) STAGE_D_FROM(g, db)
     }
     if (v0) {
-      if (!have_d) LOAD_D(g + 1)
-      STAGE_D(g + 1)
+      if (!have_d && C3W_LD) LOAD_D(g + 1)
+      if (C3W_ST) STAGE_D(g + 1)
+    } else {
+      ZERO_D(g + 1)                                    // below the image: the tap row kh = 0 multiplies zeros
     }
-    if (!have_x) LOAD_X(g)
-    stage_x(Xh, Xl, c4, pq, xr);
+    if (!v2) ZERO_D(g + 2)                             // above the image (slot of row g - 1): tap row kh = 2 likewise
+    if (!have_x && C3W_LD) LOAD_X(g)
+    if (C3W_ST) stage_x(Xh, Xl, c4, pq, xr);
+    if (g == R0 + 1) C3W_STAMP(4);                     // second step staged (before its barrier)
     __syncthreads();
+    if (first) C3W_STAMP(1);                           // primed: first barrier passed
+    if (g == R0 + 1) C3W_STAMP(5);
     have_x = g + 1 < R1;
+#ifdef C3W_ABL_LOAD
+    have_x = have_d = false;
+#else
     if (have_x) LOAD_X(g + 1)
     have_d = g + 1 < R1 && (g + 1) % H + 1 < H && (g + 1) % H != 0;   // next step stages row g + 2 from registers
     if (have_d) LOAD_D(g + 2)
+#endif
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       wbf16x8 bh[3], bl[3];
@@ -156,22 +210,31 @@ __global__ __launch_bounds__(256) void conv3x3_c64_wgrad_kernel(const float* __r
       }
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
-        const bool ok = kh == 0 ? v0 : kh == 1 ? v1 : v2;
-        if (ok) {
-          const int s = (g + 1 - kh) % 3;
-          wbf16x8 ah = *reinterpret_cast<const wbf16x8*>(&Dh[s * TILE_E + aoff + 16 * m]);
-          wbf16x8 al = *reinterpret_cast<const wbf16x8*>(&Dl[s * TILE_E + aoff + 16 * m]);
+        const int s = (g + 4 - kh) % 3;                 // slot of dY row g + 1 - kh (row -1 of the first image: slot 2, zeroed)
+        wbf16x8 ah = *reinterpret_cast<const wbf16x8*>(&Dh[s * TILE_E + aoff + 16 * m]);
+        wbf16x8 al = *reinterpret_cast<const wbf16x8*>(&Dl[s * TILE_E + aoff + 16 * m]);
+#ifdef C3W_ABL_MFMA
+        acc[kh * 3][0] += (float)ah[0] + (float)al[1] + (float)bh[0][0] + (float)bl[1][1] + (float)bh[2][2] + (float)bl[2][3] + (float)bh[1][4] + (float)bl[0][5];
+        continue;
+#endif
+        // product-major order: consecutive matrix instructions write different accumulators (each accumulator still
+        // receives hi*hi, hi*lo, lo*hi in that order)
 #pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[kw], acc[kh * 3 + kw], 0, 0, 0);
-            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[kw], acc[kh * 3 + kw], 0, 0, 0);
-            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[kw], acc[kh * 3 + kw], 0, 0, 0);
-          }
-        }
+        for (int kw = 0; kw < 3; ++kw)
+          acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[kw], acc[kh * 3 + kw], 0, 0, 0);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+          acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[kw], acc[kh * 3 + kw], 0, 0, 0);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+          acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[kw], acc[kh * 3 + kw], 0, 0, 0);
       }
     }
+    if (first) C3W_STAMP(2);                           // first step's products issued
     __syncthreads();
+    if (first) C3W_STAMP(3);
   }
+  C3W_STAMP(6);
   if (dbias) {     // fold the 16 pixel-quad lanes of each column: 64 atomics per block
     float* red = reinterpret_cast<float*>(Xh);
 #pragma unroll
@@ -185,6 +248,9 @@ __global__ __launch_bounds__(256) void conv3x3_c64_wgrad_kernel(const float* __r
     }
   }
   const int ci = wj * 32 + li;
+#ifdef C3W_ABL_EPI
+  if (acc[0][0] != 12345.f) return;
+#endif
   if (PART) {
     // slot layout = the dW slice of this co tile: [64 co][9][64 ci]
     float* slot = PART + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (64 * 9 * 64);
@@ -195,6 +261,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64_wgrad_kernel(const float* __r
         const int col = wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         slot[((size_t)col * 9 + t) * 64 + ci] = acc[t][r];
       }
+    C3W_STAMP(7);
     return;
   }
 #pragma unroll
