@@ -744,7 +744,10 @@ extern "C" int focr_bn_eval_fwd(const float* x, const float* gamma, const float*
 // train == 0: eval-mode backward (mean = running_mean, no batch-statistics terms, no dgamma/dbeta, ws unused).
 static inline int bwd_slabs(long rows) {
   long s = (rows + 63) / 64;
-  if (s > 2048) s = 2048;
+#ifndef BN_BWD_MAXSLABS
+#define BN_BWD_MAXSLABS 2048
+#endif
+  if (s > BN_BWD_MAXSLABS) s = BN_BWD_MAXSLABS;
   if (s < 1) s = 1;
   return (int)s;
 }

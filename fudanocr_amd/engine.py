@@ -281,6 +281,7 @@ class TrainStep:
             # issue them here, on the compute stream, not inside the comm-stream context below (where they would order
             # themselves behind in-flight all-reduces)
             self.ctx.flush_side()
+            self.ctx.flush_tail()                          # (a bucket with tail-parked gradients in it releases them now)
             ev = torch.cuda.Event()
             ev.record()                                    # gradients of this range are complete here ...
             with torch.cuda.stream(self.comm_stream):
@@ -356,6 +357,7 @@ class TrainStep:
                 c.side_stream().wait_stream(torch.cuda.current_stream())
             (loss * 100).backward()
             c.flush_side()             # weight gradients the last block parked (kernels.StepContext.defer_side)
+            c.flush_tail()             # ... and anything still parked for the tail (no TPS warp in this model)
         finally:
             c.side_enabled = False
             c.flips = None

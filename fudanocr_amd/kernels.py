@@ -103,6 +103,11 @@ class StepContext:
         self._mask_cursor = 0
         self._early_done = False
         self._pending_side = []          # weight-gradient launches parked for a better moment (defer_side)
+        self._tail_side = []             # ... parked until the backward reaches the STN head (park_tail)
+        self._fe_fwd_n = 0               # FeatureEnhancer blocks seen by this step's forward / backward
+        self._fe_bwd_i = 0
+        self._parking = False
+        self.tail_ready = False          # the step has a TPS warp with a trainable STN head behind it (release point)
 
     # -- attention dropout keep bits.  They depend on (shape, p, seed) only, so the engine draws the bits of ALL
     # attention layers at the start of the step on the side stream (idle during the forward pass) instead of in front
@@ -132,6 +137,7 @@ class StepContext:
         which the side stream waits for first."""
         self._mask_cursor = 0
         self._early_done = False
+        self.new_step()
         if not (self.mask_prefetch and self._masks):
             return
         late = [m for m in self._masks if m.get("alt_event") is None]
@@ -210,9 +216,39 @@ class StepContext:
         while self._pending_side:
             self._pending_side.pop(0)()
 
+    # -- weight gradients parked for the TAIL of the backward pass (FOCR_PARK_TAIL = k, see _PARK_TAIL): the STN head's
+    # backward is ~60 dependent launches of 4 - 20 us that leave the chip almost idle; the weight gradients of the k
+    # residual blocks that come last in backward order are issued when the backward reaches the TPS warp instead of beside
+    # those blocks' own (HBM-bound, LDS-full) main-stream kernels.  Released by _TPSWarp.backward, by every joiner of the
+    # side stream and at the end of the engine's backward: nothing can be left behind.
+    def fe_backward_begins(self):
+        self._fe_bwd_i += 1
+        self._parking = bool(self.side_enabled and self.tail_ready and _PARK_TAIL > 0 and
+                             self._fe_bwd_i > self._fe_fwd_n - _PARK_TAIL)
+
+    def park_tail(self, fn, otherwise=None):
+        """park `fn` for the tail if this block is one of the last k, else hand it to `otherwise` (default: run now)"""
+        if self._parking and self.side_enabled:
+            self._tail_side.append(fn)
+        elif otherwise is not None:
+            otherwise(fn)
+        else:
+            fn()
+
+    def flush_tail(self):
+        self._parking = False
+        while self._tail_side:
+            self._tail_side.pop(0)()
+
+    def new_step(self):
+        self._fe_fwd_n = self._fe_bwd_i = 0
+        self._parking = False
+        self.tail_ready = False
+
     def join_side_stream(self, stream=None):
         """make `stream` (default: current) wait for everything queued on the weight-gradient side stream"""
         self.flush_side()
+        self.flush_tail()
         if self.side_used and self.side_stream_obj is not None:
             (stream or torch.cuda.current_stream()).wait_stream(self.side_stream_obj)
 
@@ -1050,6 +1086,11 @@ _DGRAD_FIRST = os.environ.get("FOCR_DGRAD_FIRST", "1") != "0"
 # block's attention backward.  Measured (same box, interleaved): 15.32 ms vs 15.13 ms without -- the attention kernels lose
 # more to the extra company than the HBM-bound kernels gain; off by default, kept as an A/B switch.
 _DEFER_SIDE = os.environ.get("FOCR_DEFER_SIDE", "0") == "1"
+# FOCR_PARK_TAIL=k: weight gradients of the k residual blocks that come last in backward order wait for the STN head's
+# backward (StepContext.park_tail).  Measured (tools/gpu/r04_call30.sh, interleaved, two rounds): k = 0 / 1 / 2 / 3 ->
+# 13.50 / 13.56 / 13.79 / 13.99 ms -- the tail (0.5 ms of small launches) is shorter than one block's weight gradients
+# (0.25 ms each, un-overlapped), which the default schedule already hides beside that block's own kernels; off by default.
+_PARK_TAIL = int(os.environ.get("FOCR_PARK_TAIL", "0"))
 # FOCR_MASK_EARLY=1: next step's attention keep bits drawn under the recognizer's LSTM scan (second buffer per attention
 # call) instead of at the step start.  Measured (tools/gpu/r04_call25.sh, interleaved): 13.56 / 13.55 ms with, 13.45 / 13.50
 # ms without -- the 8-block groups of the persistent scan lose more to the company of the mask blocks than the first
@@ -1063,6 +1104,7 @@ FE_PARAM_NAMES = ("wqkv", "bqkv", "wo", "bo", "a1", "b1", "w1", "bb1", "w2", "bb
 def _fe_forward(step, feat, xres, pe, heads, p_attn, p_ffn, eps, params):
     """forward of the block on tokens feat [B, T, 64] -> (out [B, T, 64], saved tensors, cfg)"""
     wqkv, bqkv, wo, bo, a1, b1, w1, bb1, w2, bb2, a3, b3, wl, bl = params
+    step._fe_fwd_n += 1
     b, t, cf = feat.shape
     rows, d = b * t, 128
     dev = feat.device
@@ -1162,8 +1204,9 @@ def _fe_backward(step, saved, cfg, params, targets, d_out, need_dfeat, need_para
                       nws, rows, parts, _stream())
     dqkv = None
     step.flush_side()          # the previous block's parked weight gradients: beside THIS block's attention backward
+    step.fe_backward_begins()
     if need_params and _FE_WGRAD_EARLY:
-        wgrads(1, (d_out, xhat2, d_s2, h, d_hpre, xhat1, d_s1, o))
+        step.park_tail(lambda: wgrads(1, (d_out, xhat2, d_s2, h, d_hpre, xhat1, d_s1, o)))
     dqkv = torch.empty((b, t, 3 * d), device=dev)
     # `work` already holds D = rowsum(d_ctx * o) per (b, head, token), written by the chain kernel above
     if planes:
@@ -1180,9 +1223,9 @@ def _fe_backward(step, saved, cfg, params, targets, d_out, need_dfeat, need_para
         _lib.call("focr_fe_qkv_dgrad", _p(dqkv), _p(wqkv), _p(d_s1), _p(d_feat), rows, _stream())
     if need_params:
         if _FE_WGRAD_EARLY:
-            step.defer_side(lambda: wgrads(2, (dqkv, tok)))
+            step.park_tail(lambda: wgrads(2, (dqkv, tok)), step.defer_side)
         else:
-            step.defer_side(lambda: wgrads(3, (d_out, xhat2, d_s2, h, d_hpre, xhat1, d_s1, o, dqkv, tok)))
+            step.park_tail(lambda: wgrads(3, (d_out, xhat2, d_s2, h, d_hpre, xhat1, d_s1, o, dqkv, tok)), step.defer_side)
     return d_feat, grads
 
 
@@ -1338,7 +1381,7 @@ class _SRBFused(torch.autograd.Function):
             # the data gradient is on the step's critical path, the weight gradient is not: the main-stream kernel is
             # enqueued FIRST (the side stream only needs dyc, marked by an event recorded before it), so it gets the CUs first
             ev_dy = None
-            if _DGRAD_FIRST and need_p and step.side_enabled and not _DEFER_SIDE:
+            if _DGRAD_FIRST and need_p and step.side_enabled and not _DEFER_SIDE and not step._parking:
                 ev_dy = torch.cuda.Event()
                 ev_dy.record()
             if _DGRAD_FIRST:
@@ -1369,7 +1412,7 @@ class _SRBFused(torch.autograd.Function):
                         _lib.call("focr_conv2d_wgrad", _p(cin), _p(dyc), _p(dw), _p(dbias), n, h, w, 64, 64, 3, 3, 1, 1,
                                   0, 0, int(flat), _p(wsw), nws, _stream())
                 if flat:
-                    step.defer_side(conv_wgrad)      # issued beside the next block's attention backward
+                    step.park_tail(conv_wgrad, step.defer_side)   # (defer_side: beside the next block's attention backward)
                 else:
                     conv_wgrad()
                     grads[4 * i], grads[4 * i + 1] = dw, dbias
@@ -1590,6 +1633,9 @@ class _TPSWarp(torch.autograd.Function):
         _lib.call("focr_tps_fwd", _p(img), _p(ctrl), _p(inv_kernel), _p(coord_repr), _p(out), _p(src), b, h, w,
                   c, nc, _stream())
         ctx.cfg = (b, h, w, c, nc)
+        ctx.step = current_context()
+        if ctx.needs_input_grad[1]:
+            ctx.step.tail_ready = True       # a trainable STN head follows in the backward: release point of park_tail
         ctx.save_for_backward(img, src, inv_kernel, coord_repr)
         return out
 
@@ -1598,6 +1644,7 @@ class _TPSWarp(torch.autograd.Function):
         img, src, inv_kernel, coord_repr = ctx.saved_tensors
         b, h, w, c, nc = ctx.cfg
         dout = dout.contiguous()
+        ctx.step.flush_tail()        # parked weight gradients: beside the STN head's backward (StepContext.park_tail)
         dctrl = torch.empty((b, nc, 2), device=dout.device)
         _lib.call("focr_tps_bwd", _p(dout), _p(img), _p(src), _p(inv_kernel), _p(coord_repr), _p(dctrl), b, h,
                   w, c, nc, _stream())
