@@ -639,6 +639,137 @@ static inline int row_slabs(long rows) {
 
 // ws: focr_bn_ws_floats(rows, C) floats of scratch.  running_mean/var/nbt may be null (no running update).
 // Statistics are reduced deterministically (slab partials + fixed-order fold): bit-identical run to run.
+
+// ---------------------------------------------------------------------------------------
+// Small tensors (the STN head's BatchNorm layers on 2x8 .. 1x2 maps and its BatchNorm1d, stn_head.py:34-47: rows <= 8192):
+// statistics, finalize and apply in ONE launch, and reduce + apply of the backward in one launch.  The five-launch form
+// costs ~40 us per layer there (8-block column reductions of 64 dependent loads per thread, then three launches that do
+// almost nothing), and the head is a chain of ~60 such launches on the step's critical path.  One block per float4
+// column: it owns its four channels for all rows, so mean -> centred variance -> apply need no grid-wide step; the
+// re-reads hit L2 (the whole tensor is <= 8 MB).  Same formulas and the same two-pass variance as the large form,
+// fixed-order block reductions: deterministic.
+// ---------------------------------------------------------------------------------------
+#define BN_SMALL_MAX_ROWS 8192
+__device__ __forceinline__ float4 bn_block_sum4(float4 v, float4* red) {
+  __syncthreads();                                   // (the previous use of `red` is over)
+  red[threadIdx.x] = v;
+  __syncthreads();
+#pragma unroll
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) {
+      float4 a = red[threadIdx.x], b = red[threadIdx.x + w];
+      red[threadIdx.x] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+    __syncthreads();
+  }
+  return red[0];
+}
+__global__ __launch_bounds__(256) void bn_small_train_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
+    float* __restrict__ rvar, long long* nbt, const float* __restrict__ res, float* __restrict__ y,
+    float* __restrict__ save_mean, float* __restrict__ save_invstd, int rows, int C, float momentum, float eps, int act) {
+  __shared__ float4 red[256];
+  const int c = blockIdx.x * 4;
+  const float* xc = x + c;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(xc + (size_t)r * C);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  s = bn_block_sum4(s, red);
+  const float4 mu = make_float4(s.x / (float)rows, s.y / (float)rows, s.z / (float)rows, s.w / (float)rows);
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(xc + (size_t)r * C);
+    const float dx = v.x - mu.x, dy = v.y - mu.y, dz = v.z - mu.z, dw = v.w - mu.w;
+    q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
+  }
+  q = bn_block_sum4(q, red);
+  const float4 var = make_float4(q.x / (float)rows, q.y / (float)rows, q.z / (float)rows, q.w / (float)rows);
+  const float4 is = make_float4(rsqrtf(var.x + eps), rsqrtf(var.y + eps), rsqrtf(var.z + eps), rsqrtf(var.w + eps));
+  if (threadIdx.x == 0) {
+    *reinterpret_cast<float4*>(save_mean + c) = mu;
+    *reinterpret_cast<float4*>(save_invstd + c) = is;
+    if (rmean) {
+      const float k = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
+      const float m_[4] = {mu.x, mu.y, mu.z, mu.w}, v_[4] = {var.x, var.y, var.z, var.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float unb = rows > 1 ? v_[e] * k : v_[e];
+        rmean[c + e] = (1.f - momentum) * rmean[c + e] + momentum * m_[e];
+        rvar[c + e] = (1.f - momentum) * rvar[c + e] + momentum * unb;
+      }
+    }
+    if (c == 0 && nbt) *nbt += 1;
+  }
+  const float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(xc + (size_t)r * C);
+    float4 o;
+    o.x = act_fwd(g.x * (v.x - mu.x) * is.x + b.x, act);
+    o.y = act_fwd(g.y * (v.y - mu.y) * is.y + b.y, act);
+    o.z = act_fwd(g.z * (v.z - mu.z) * is.z + b.z, act);
+    o.w = act_fwd(g.w * (v.w - mu.w) * is.w + b.w, act);
+    if (res) {
+      const float4 rr = *reinterpret_cast<const float4*>(res + c + (size_t)r * C);
+      o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+    }
+    *reinterpret_cast<float4*>(y + c + (size_t)r * C) = o;
+  }
+}
+// backward: sum g, sum g * xhat over the rows (g = dz * act'(gamma * xhat + beta)), then
+// dx = gamma * invstd * (g - sum_g / rows - xhat * sum_gx / rows); dbeta = sum g, dgamma = sum g * xhat
+__global__ __launch_bounds__(256) void bn_small_train_bwd_kernel(
+    const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ invstd,
+    float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C, int act, int lddz) {
+  __shared__ float4 red[256];
+  const int c = blockIdx.x * 4;
+  const float4 g4 = *reinterpret_cast<const float4*>(gamma + c), b4 = *reinterpret_cast<const float4*>(beta + c);
+  const float4 m4 = *reinterpret_cast<const float4*>(mean + c), i4 = *reinterpret_cast<const float4*>(invstd + c);
+  const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+  const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ii[4] = {i4.x, i4.y, i4.z, i4.w};
+  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + c + (size_t)r * C);
+    const float4 dv = *reinterpret_cast<const float4*>(dz + c + (size_t)r * lddz);
+    const float xx[4] = {xv.x, xv.y, xv.z, xv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (xx[e] - mm[e]) * ii[e];
+      const float g = dd[e] * act_grad(gg[e] * xh + bb[e], act);
+      s0[e] += g;
+      s1[e] += g * xh;
+    }
+  }
+  const float4 sg = bn_block_sum4(make_float4(s0[0], s0[1], s0[2], s0[3]), red);
+  const float4 sgx = bn_block_sum4(make_float4(s1[0], s1[1], s1[2], s1[3]), red);
+  if (threadIdx.x == 0) {
+    *reinterpret_cast<float4*>(dbeta + c) = sg;
+    *reinterpret_cast<float4*>(dgamma + c) = sgx;
+  }
+  const float inv_rows = 1.f / (float)rows;
+  const float a0[4] = {sg.x * inv_rows, sg.y * inv_rows, sg.z * inv_rows, sg.w * inv_rows};
+  const float a1[4] = {sgx.x * inv_rows, sgx.y * inv_rows, sgx.z * inv_rows, sgx.w * inv_rows};
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + c + (size_t)r * C);
+    const float4 dv = *reinterpret_cast<const float4*>(dz + c + (size_t)r * lddz);
+    const float xx[4] = {xv.x, xv.y, xv.z, xv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
+    float oo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (xx[e] - mm[e]) * ii[e];
+      const float g = dd[e] * act_grad(gg[e] * xh + bb[e], act);
+      oo[e] = gg[e] * ii[e] * (g - a0[e] - xh * a1[e]);
+    }
+    *reinterpret_cast<float4*>(dx + c + (size_t)r * C) = make_float4(oo[0], oo[1], oo[2], oo[3]);
+  }
+}
+#ifndef BN_NO_SMALL
+static inline bool bn_small(long rows) { return rows <= BN_SMALL_MAX_ROWS; }
+#else
+static inline bool bn_small(long) { return false; }
+#endif
 extern "C" long focr_bn_ws_floats(long rows, int C) { return (long)(row_slabs(rows) + 2) * C; }
 
 extern "C" int focr_bn_train_fwd(const float* x, const float* gamma, const float* beta,
@@ -648,6 +779,12 @@ extern "C" int focr_bn_train_fwd(const float* x, const float* gamma, const float
                                  float eps, int act, hipStream_t stream) {
   FOCR_CHECK_ARG(x && gamma && beta && y && save_mean && save_invstd && ws, "null pointer");
   FOCR_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0, "need C % 4 == 0");
+  if (bn_small(rows)) {
+    hipLaunchKernelGGL(bn_small_train_fwd_kernel, dim3(C / 4), 256, 0, stream, x, gamma, beta, running_mean, running_var,
+                       nbt, residual, y, save_mean, save_invstd, (int)rows, C, momentum, eps, act);
+    FOCR_LAUNCH_CHECK();
+    return FOCR_OK;
+  }
   const int slabs = row_slabs(rows);
   float* sum = ws;                 // [C]
   float* sq = ws + C;              // [C]
@@ -762,6 +899,13 @@ extern "C" int focr_bn_bwd(const float* dz, const float* x, const float* gamma, 
   FOCR_CHECK_ARG(dz && x && gamma && beta && mean && invstd && dx, "null pointer");
   FOCR_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0, "need C % 4 == 0");
   long total4 = rows * C / 4;
+  if (train && bn_small(rows)) {
+    FOCR_CHECK_ARG(dgamma && dbeta, "null pointer");
+    hipLaunchKernelGGL(bn_small_train_bwd_kernel, dim3(C / 4), 256, 0, stream, dz, x, gamma, beta, mean, invstd, dx, dgamma,
+                       dbeta, (int)rows, C, act, lddz);
+    FOCR_LAUNCH_CHECK();
+    return FOCR_OK;
+  }
   if (train) {
     FOCR_CHECK_ARG(dgamma && dbeta && ws, "null pointer");
     const int slabs = bwd_slabs(rows);
