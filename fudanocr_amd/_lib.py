@@ -118,6 +118,7 @@ SIGNATURES = {
     "focr_get_tuning": [I],
     "focr_get_precision": [],
     "focr_clip_adam": [P, P, P, P, P, L, F, F, F, F, I, F, F, P],
+    "focr_zero": [P, L, P],
 }
 
 _lib = None

@@ -396,6 +396,11 @@ int focr_conv3x3_c64_wgrad(const float* x, const float* dy, float* dw, float* db
                            int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW, int ldd, int ldx,
                            hipStream_t stream);
 long focr_conv3x3_c64_ws_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW);
+// conv3x3_cin_small_wgrad.hip
+int focr_conv3x3_cin_small_wgrad(const float* x, const float* dy, float* dw, float* dbias, float* ws, long ws_floats, int N,
+                                 int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW, int ldd, int ldx,
+                                 hipStream_t stream);
+long focr_conv3x3_cin_small_ws_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW);
 // linear_wgrad.hip
 int focr_linear_wgrad_eligible(long M, int K, int Cout, int ldx, int ldd);
 long focr_linear_wgrad_ws_floats(long M, int K, int Cout);
@@ -529,6 +534,8 @@ extern "C" long focr_conv2d_wgrad_ws_floats(int N, int H, int W, int Cin, int Co
     return focr_linear_wgrad_ws_floats((long)N * H * W, Cin, Cout);
   long n = focr_conv3x3_c64_ws_floats(N, H, W, Cin, Cout, KH, KW, padH, padW);
   if (n > 0) return n;
+  n = focr_conv3x3_cin_small_ws_floats(N, H, W, Cin, Cout, KH, KW, padH, padW);
+  if (n > 0) return n;
   ConvGeom g;
   if (fill_geom(g, N, H, W, Cin, Cout, KH, KW, padH, padW) != 0) return 0;
   return focr_conv_wgrad_bx3_ws_floats(g.M, Cin, Cout, g.Ktot);
@@ -550,6 +557,12 @@ extern "C" int focr_conv2d_wgrad(const float* x, const float* dy, float* dw, flo
       focr_get_tuning(FOCR_TUNE_LINEAR_WGRAD_STREAM) && focr_linear_wgrad_eligible(g.M, Cin, Cout, g.ldx, ldd) &&
       ws_floats >= focr_linear_wgrad_ws_floats(g.M, Cin, Cout)) {
     focr_linear_wgrad(x, dy, dw, dbias, ws, ws_floats, g.M, Cin, Cout, g.ldx, ldd, prezeroed, stream);
+    FOCR_LAUNCH_CHECK();
+    return FOCR_OK;
+  }
+  // 3x3 with <= 4 input channels and 32 output channels (first STN layer): partial sums + fixed-order fold, overwrites dw / dbias
+  if (focr_get_precision() != 0 &&
+      focr_conv3x3_cin_small_wgrad(x, dy, dw, dbias, ws, ws_floats, N, H, W, Cin, Cout, KH, KW, padH, padW, ldd, g.ldx, stream)) {
     FOCR_LAUNCH_CHECK();
     return FOCR_OK;
   }

@@ -86,3 +86,21 @@ extern "C" int focr_clip_adam(float* p, const float* g, float* m, float* v, cons
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }
+
+// zero_grad of the flat gradient buffer (optimizer.zero_grad(), interfaces/super_resolution.py:82): float4 grid-stride
+// stores.  torch's fill kernel took 61 us for the 12.8 MB buffer at the head of every step (profiles/r04_step_sequence.txt).
+__global__ __launch_bounds__(256) void zero_kernel(float4* __restrict__ p, long n4, float* __restrict__ tail, int ntail) {
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) p[i] = z;
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0.f;
+}
+extern "C" int focr_zero(float* p, long n, hipStream_t stream) {
+  FOCR_CHECK_ARG(p && n > 0 && (reinterpret_cast<size_t>(p) & 15) == 0, "needs a 16-byte aligned buffer");
+  const long n4 = n / 4;
+  long gsz = (n4 + 255) / 256;
+  if (gsz > 2048) gsz = 2048;
+  if (gsz < 1) gsz = 1;
+  hipLaunchKernelGGL(zero_kernel, dim3((int)gsz), 256, 0, stream, reinterpret_cast<float4*>(p), n4, p + 4 * n4, (int)(n - 4 * n4));
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}

@@ -86,7 +86,11 @@ class FlatBuffers:
                 p._focr_grad = g          # kernels write the gradient here directly (kernels._target)
 
     def zero_grad(self):
-        self.flat_grad.zero_()
+        if self.flat_grad.is_cuda:
+            from . import _lib
+            _lib.call("focr_zero", K._p(self.flat_grad), self.flat_grad.numel(), K._stream())
+        else:
+            self.flat_grad.zero_()
         for p, off in zip(self.params, self.offsets):      # re-attach if something reset .grad
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
                 shape, order = _physical(p)

@@ -362,6 +362,8 @@ int focr_grad_sumsq(const float* g, float* sumsq, long n, float gscale, focr_str
 int focr_clip_adam(float* p, const float* g, float* m, float* v, const float* sumsq, long n, float lr,
                    float beta1, float beta2, float eps, int step, float max_norm, float gscale,
                    focr_stream_t stream);
+/* optimizer.zero_grad() on the flat gradient buffer (interfaces/super_resolution.py:82); p 16-byte aligned, n floats */
+int focr_zero(float* p, long n, focr_stream_t stream);
 
 /* ---- evaluation metrics on the device (utils/ssim_psnr.py:9-78; interfaces/super_resolution.py:178-181) ------
  * One pass over an NCHW pair (first 3 channels): sq_sum[b] = sum (255 a - 255 b)^2, ssim_sum[b] = sum of the SSIM map

@@ -101,6 +101,8 @@ CONV_CASES = [
     (9, 6, 33, 64, 64, 3, 3, 1, 1),       # halo kernel: H % 4 != 0, W = 33 (one valid pixel in the last tile)
     (128, 1, 4, 256, 256, 3, 3, 1, 1),    # split-K path: STN conv on the 1x4 map at the bench batch (16 tiles, 72 K chunks)
     (40, 2, 8, 128, 256, 3, 3, 1, 1),     # split-K path: ragged last row tile (M = 640), uneven split (36 chunks)
+    (5, 16, 64, 3, 32, 3, 3, 1, 1),       # STN conv1: tiny-Cin weight gradient (conv3x3_cin_small_wgrad.hip), several images per block
+    (3, 5, 10, 4, 32, 3, 3, 1, 1),        # the same with the mask channel, odd sizes, one image row per block
 ]
 
 
