@@ -644,6 +644,44 @@ def test_conv_relu_maxpool_fused_relu_backward():
         close(dbd, b.grad, ptol(2), what="conv-relu-pool db")
 
 
+@pytest.mark.parametrize("geom", [(16, 16, 64, 64, 4), (8, 16, 64, 128, 0), (33, 16, 64, 64, 1)])
+def test_batchnorm_backward_large(geom):
+    """BatchNorm backward at the sizes the residual blocks run it (rows >= 8192: slab partials + fixed-order fold + apply)
+    against autograd in float64, repeated on the same buffers: identical bits each time (the folds run in a fixed order).
+    (Round 4 measured a two-launch form here -- the last-arriving block of a slab group, found through self-resetting
+    ticket counters, folds the group -- and dropped it: correct, but the device-scope release fence every one of the 2048
+    blocks needs in front of its ticket is an L2 write-back on this part: 16.8 instead of 13.2 ms per step.)"""
+    n, h, w, c, act = geom
+    x = rnd(n, c, h, w, seed=1, scale=2).requires_grad_(True)
+    g = (rnd(c, seed=2) + 1.5).requires_grad_(True)
+    be = rnd(c, seed=3).requires_grad_(True)
+    rm, rv = torch.zeros(c), torch.ones(c)
+    y = F.batch_norm(x.double(), rm.double(), rv.double(), g.double(), be.double(), True, 0.1, 1e-5)
+    if act == 1:
+        y = F.relu(y)
+    elif act == 4:
+        y = y * torch.tanh(F.softplus(y))
+    gy = rnd(*y.shape, seed=7)
+    y.backward(gy.double())
+    xd = dev(x.permute(0, 2, 3, 1)).requires_grad_(True)
+    gd, bd = dev(g).requires_grad_(True), dev(be).requires_grad_(True)
+    nbt = torch.zeros((), dtype=torch.long, device="cuda")
+    first = None
+    for it in range(3):
+        for t in (xd, gd, bd):
+            t.grad = None
+        yd = K().batchnorm_act(xd, gd, bd, dev(rm), dev(rv), nbt, True, act=act)
+        yd.backward(dev(gy.permute(0, 2, 3, 1)))
+        got = (xd.grad.clone(), gd.grad.clone(), bd.grad.clone())
+        if first is None:
+            first = got
+            close(got[0].permute(0, 3, 1, 2), x.grad, 1e-4, what="bn large dx")
+            close(got[1], g.grad, 1e-4, what="bn large dgamma")
+            close(got[2], be.grad, 1e-4, what="bn large dbeta")
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(got, first)), "BatchNorm backward differs between launches (iteration %d)" % it
+
+
 @pytest.mark.parametrize("shape", [(3, 32, 128), (2, 8, 20), (1, 4, 2)])
 def test_crnn_conv0_relu_pool_fused(shape):
     """csrc/crnn_conv0_pool.hip (crnn.py:51-52 conv0 -> relu -> pooling0 of the frozen recognizer, one launch each way).
