@@ -889,6 +889,18 @@ __device__ __forceinline__ rbf16x8 lp_load8(const __bf16* p) {
   return *reinterpret_cast<const rbf16x8*>(p);
 #endif
 }
+// the scan's fp32 outputs (gates, c, h / dgx: read by LATER kernels only).  LSTM_NT_OUT = 1: nontemporal stores, so that the
+// lines do not sit dirty in L2 where the next step's release (an L2 write-back at agent scope) has to flush them
+#ifndef LSTM_NT_OUT
+#define LSTM_NT_OUT 0
+#endif
+__device__ __forceinline__ void lp_out(float* p, float v) {
+#if LSTM_NT_OUT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
 __device__ __forceinline__ void lp_store4(__bf16* p, unsigned long long v) {
 #if LSTM_XCHG == 1
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1014,12 +1026,12 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
       const int ebl = (tid >> 5) + 16 * e, eb = b0 + ebl;
       if (eb < B) {
         const size_t gb = (((size_t)t * B + eb) * 2 + dir) * 4 * H + j0 + eu;
-        gates[gb] = o_ig[e];
-        gates[gb + H] = o_fg[e];
-        gates[gb + 2 * H] = o_gg[e];
-        gates[gb + 3 * H] = o_og[e];
-        cseq[(((size_t)t * B + eb) * 2 + dir) * H + j0 + eu] = o_c[e];
-        hseq[((size_t)t * B + eb) * 2 * H + dir * H + j0 + eu] = o_h[e];
+        lp_out(&gates[gb], o_ig[e]);
+        lp_out(&gates[gb + H], o_fg[e]);
+        lp_out(&gates[gb + 2 * H], o_gg[e]);
+        lp_out(&gates[gb + 3 * H], o_og[e]);
+        lp_out(&cseq[(((size_t)t * B + eb) * 2 + dir) * H + j0 + eu], o_c[e]);
+        lp_out(&hseq[((size_t)t * B + eb) * 2 * H + dir * H + j0 + eu], o_h[e]);
       }
     }
   }
@@ -1149,7 +1161,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_bx3_kernel(
       if (eb < B) {
         const size_t ob = ((size_t)t * st_t + (size_t)eb * st_b) * 8 * H + dir * 4 * H + j0 + eu;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dgx[ob + q * H] = d4[e][q];
+        for (int q = 0; q < 4; ++q) lp_out(&dgx[ob + q * H], d4[e][q]);
       }
     }
   }
