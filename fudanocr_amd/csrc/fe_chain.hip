@@ -526,11 +526,23 @@ __global__ __launch_bounds__(256, 2) void fe_qkv_fwd_kernel(const float* __restr
                                                            const float* __restrict__ Wqkv,
                                                            const float* __restrict__ bqkv, float* __restrict__ tok,
                                                            float* __restrict__ qkv, int ntiles, int ntok,
-                                                           __bf16* __restrict__ planes, long pls, float qmul) {
+                                                           __bf16* __restrict__ planes, long pls, float qmul,
+                                                           const float* __restrict__ bn_gamma,
+                                                           const float* __restrict__ bn_beta,
+                                                           const float* __restrict__ bn_mean,
+                                                           const float* __restrict__ bn_invstd) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fc_smem[];
   __bf16* Wh = reinterpret_cast<__bf16*>(fc_smem);
   __bf16* Wl = Wh + WSZ128;
   float* vb = reinterpret_cast<float*>(Wl + WSZ128);
+  float* vbn = vb + FC_D;                                  // bn_gamma != nullptr: gamma | mean | invstd | beta, 64 each
+  if (bn_gamma)
+    for (int i = threadIdx.x; i < 64; i += 256) {
+      vbn[i] = bn_gamma[i];
+      vbn[64 + i] = bn_mean[i];
+      vbn[128 + i] = bn_invstd[i];
+      vbn[192 + i] = bn_beta[i];
+    }
   const int y = blockIdx.y;
   {  // stage with 256 threads (fc_stage_* assume FC_THREADS)
     constexpr int KP = KP128, Q = FC_D / 4;
@@ -555,6 +567,21 @@ __global__ __launch_bounds__(256, 2) void fe_qkv_fwd_kernel(const float* __restr
       f32x16 a[2], b[2];
       fc_load_row<2>(feat + row * 64, lh, a);
       fc_load_row<2>(pe + (row % (size_t)ntok) * 64, lh, b);
+      if (bn_gamma) {
+        // `feat` is the block's second convolution BEFORE its BatchNorm (tbsrn.py:246-251): normalised here, on load, with
+        // bn_apply_kernel's expression -- the 33.5 MB normalised tensor and its launch are gone (its only consumer was this load)
+        const int z0 = fc_opaque_zero();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x16 g_[1], mu[1], is[1], be[1];
+          fc_load_vec<1>(vbn + 32 * j + z0, lh, g_);
+          fc_load_vec<1>(vbn + 64 + 32 * j + z0, lh, mu);
+          fc_load_vec<1>(vbn + 128 + 32 * j + z0, lh, is);
+          fc_load_vec<1>(vbn + 192 + 32 * j + z0, lh, be);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) a[j][r] = g_[0][r] * (a[j][r] - mu[0][r]) * is[0][r] + be[0][r];
+        }
+      }
       v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
     }
     if (y == 0) fc_store_row<4>(tok + row * FC_D, lh, v);
@@ -710,7 +737,7 @@ constexpr size_t FC_LDS_FWD_B = (size_t)(2 * WSZ128 + 2 * 64 * KP128) * 2 + (5 *
 constexpr size_t FC_LDS_BWD_A = (size_t)(2 * FC_D * KP64 + 2 * WSZ128) * 2 + FC_D * 4;
 constexpr size_t FC_LDS_BWD_B = (size_t)4 * WSZ128 * 2 + FC_D * 4;
 constexpr size_t FC_LDS_BWD_QKV = (size_t)2 * 64 * KP384 * 2;
-constexpr size_t FC_LDS_QKV_FWD = (size_t)2 * WSZ128 * 2 + FC_D * 4;
+constexpr size_t FC_LDS_QKV_FWD = (size_t)2 * WSZ128 * 2 + FC_D * 4 + 4 * 64 * 4;
 
 int fc_blocks(int ntiles) {
   int nb = (ntiles + 7) / 8;
@@ -792,9 +819,20 @@ extern "C" int focr_fe_post_bwd(const float* d_out, const float* wl, const float
 }
 
 // tok [rows,128] = [feat | pe[row % ntok]], qkv [rows,384] = tok Wqkv^T + bqkv (packed q | k | v projection)
+// focr_fe_qkv_fwd_bn: `feat` is the input of a train-mode BatchNorm2d(64) whose statistics are final (save_mean / save_invstd
+// of focr_bn_train_fwd_stats with y = NULL): the normalisation gamma (x - mean) invstd + beta is applied on load
+extern "C" int focr_fe_qkv_fwd_bn(const float* feat, const float* pe, const float* wqkv, const float* bqkv, float* tok,
+                                  float* qkv, long rows, int ntok, void* planes, float q_mul, const float* bn_gamma,
+                                  const float* bn_beta, const float* bn_mean, const float* bn_invstd, hipStream_t stream);
 extern "C" int focr_fe_qkv_fwd(const float* feat, const float* pe, const float* wqkv, const float* bqkv, float* tok,
                                float* qkv, long rows, int ntok, void* planes, float q_mul, hipStream_t stream) {
+  return focr_fe_qkv_fwd_bn(feat, pe, wqkv, bqkv, tok, qkv, rows, ntok, planes, q_mul, nullptr, nullptr, nullptr, nullptr, stream);
+}
+extern "C" int focr_fe_qkv_fwd_bn(const float* feat, const float* pe, const float* wqkv, const float* bqkv, float* tok,
+                                  float* qkv, long rows, int ntok, void* planes, float q_mul, const float* bn_gamma,
+                                  const float* bn_beta, const float* bn_mean, const float* bn_invstd, hipStream_t stream) {
   FOCR_CHECK_ARG(feat && pe && wqkv && tok && (qkv || planes) && ntok > 0, "bad argument");
+  FOCR_CHECK_ARG(!bn_gamma || (bn_beta && bn_mean && bn_invstd), "BatchNorm vectors: all four or none");
   FOCR_CHECK_ARG(focr_fe_chain_supported(rows, FC_D), "rows must be a positive multiple of 32 (precision mode != 0)");
   static focr_dev_flags attr;
   if (focr_dev_first(attr)) {
@@ -808,7 +846,7 @@ extern "C" int focr_fe_qkv_fwd(const float* feat, const float* pe, const float* 
   int nb = (ntiles + 3) / 4;
   if (nb > 171) nb = 171;                   // x 3 column groups = 513 blocks: one round at two blocks per CU
   hipLaunchKernelGGL(fe_qkv_fwd_kernel, dim3(nb, 3), 256, FC_LDS_QKV_FWD, stream, feat, pe, wqkv, bqkv, tok, qkv, ntiles,
-                     ntok, reinterpret_cast<__bf16*>(planes), rows * 256, q_mul);
+                     ntok, reinterpret_cast<__bf16*>(planes), rows * 256, q_mul, bn_gamma, bn_beta, bn_mean, bn_invstd);
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }

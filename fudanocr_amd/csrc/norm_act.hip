@@ -886,10 +886,14 @@ extern "C" int focr_bn_train_fwd_stats(const float* x, const float* part, int np
                                        const float* beta, float* running_mean, float* running_var, long long* nbt,
                                        const float* residual, float* y, float* save_mean, float* save_invstd,
                                        long rows, int C, float momentum, float eps, int act, hipStream_t stream) {
-  FOCR_CHECK_ARG(x && part && gamma && beta && y && save_mean && save_invstd, "null pointer");
+  FOCR_CHECK_ARG(part && gamma && beta && save_mean && save_invstd && (x || !y), "null pointer");
   FOCR_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0 && nparts > 0, "need C % 4 == 0, nparts > 0");
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), 256, 0, stream, part, nparts, save_mean, save_invstd,
                      running_mean, running_var, nbt, rows, C, momentum, eps);
+  if (!y) {                 // statistics only: the consumer normalises on load (focr_fe_qkv_fwd_bn)
+    FOCR_LAUNCH_CHECK();
+    return FOCR_OK;
+  }
   long total4 = rows * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total4)), 256, 0, stream, x, gamma, beta,
                      (const float*)save_mean, (const float*)save_invstd, residual, y, total4, C, act);

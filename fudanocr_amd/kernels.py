@@ -1091,6 +1091,8 @@ _DEFER_SIDE = os.environ.get("FOCR_DEFER_SIDE", "0") == "1"
 # 13.50 / 13.56 / 13.79 / 13.99 ms -- the tail (0.5 ms of small launches) is shorter than one block's weight gradients
 # (0.25 ms each, un-overlapped), which the default schedule already hides beside that block's own kernels; off by default.
 _PARK_TAIL = int(os.environ.get("FOCR_PARK_TAIL", "0"))
+# FOCR_BN2_FUSE=0: the residual block's second BatchNorm as its own apply pass (A/B switch)
+_BN2_FUSE = os.environ.get("FOCR_BN2_FUSE", "1") != "0"
 # FOCR_MASK_EARLY=1: next step's attention keep bits drawn under the recognizer's LSTM scan (second buffer per attention
 # call) instead of at the step start.  Measured (tools/gpu/r04_call25.sh, interleaved): 13.56 / 13.55 ms with, 13.45 / 13.50
 # ms without -- the 8-block groups of the persistent scan lose more to the company of the mask blocks than the first
@@ -1101,8 +1103,10 @@ _FE_WGRAD_EARLY = os.environ.get("FOCR_FE_WGRAD_EARLY", "1") != "0"
 FE_PARAM_NAMES = ("wqkv", "bqkv", "wo", "bo", "a1", "b1", "w1", "bb1", "w2", "bb2", "a3", "b3", "wl", "bl")
 
 
-def _fe_forward(step, feat, xres, pe, heads, p_attn, p_ffn, eps, params):
-    """forward of the block on tokens feat [B, T, 64] -> (out [B, T, 64], saved tensors, cfg)"""
+def _fe_forward(step, feat, xres, pe, heads, p_attn, p_ffn, eps, params, bn=None):
+    """forward of the block on tokens feat [B, T, 64] -> (out [B, T, 64], saved tensors, cfg).
+    bn = (gamma, beta, mean, invstd): feat is the INPUT of the BatchNorm in front of the block; the projection kernel
+    normalises it on load (focr_fe_qkv_fwd_bn)"""
     wqkv, bqkv, wo, bo, a1, b1, w1, bb1, w2, bb2, a3, b3, wl, bl = params
     step._fe_fwd_n += 1
     b, t, cf = feat.shape
@@ -1119,15 +1123,15 @@ def _fe_forward(step, feat, xres, pe, heads, p_attn, p_ffn, eps, params):
         # the projection writes Q * scale * log2(e), K, V ALREADY split to bf16 hi / lo ([3][rows][256]: every 4 columns as
         # [hi4 | lo4], the bytes of the fp32 tensor): the attention kernels stage them by plain copies (attention_bx3.hip)
         qkv = torch.empty((rows, 6 * d), device=dev, dtype=torch.bfloat16)       # [rows][Q | K | V], 256 bf16 each
-        _lib.call("focr_fe_qkv_fwd", _p(feat), _p(pe), _p(wqkv), _p(bqkv), _p(tok), _NULL, rows, t, _p(qkv),
-                  scale * _LOG2E, _stream())
+        _lib.call("focr_fe_qkv_fwd_bn", _p(feat), _p(pe), _p(wqkv), _p(bqkv), _p(tok), _NULL, rows, t, _p(qkv),
+                  scale * _LOG2E, *[_p(v_) for v_ in (bn or (None,) * 4)], _stream())
         pq, pk, pv = (ctypes.c_void_p(qkv.data_ptr() + i * 2 * d * 2) for i in range(3))
         _lib.call("focr_attention_planes_fwd", pq, pk, pv, _p(o), _p(lse), _p(mask), b, heads, t, 6 * d, d,
                   float(p_attn), _new_seed() if (p_attn > 0 and not ready) else 0, int(ready), _stream())
     else:
         qkv = torch.empty((b, t, 3 * d), device=dev)
-        _lib.call("focr_fe_qkv_fwd", _p(feat), _p(pe), _p(wqkv), _p(bqkv), _p(tok), _p(qkv), rows, t, _NULL, 1.0,
-                  _stream())
+        _lib.call("focr_fe_qkv_fwd_bn", _p(feat), _p(pe), _p(wqkv), _p(bqkv), _p(tok), _p(qkv), rows, t, _NULL, 1.0,
+                  *[_p(v_) for v_ in (bn or (None,) * 4)], _stream())
         if ready:
             _lib.call("focr_attention_fwd_premasked", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _p(o), _p(lse),
                       _p(mask), b, heads, t, 3 * d, d, scale, float(p_attn), _stream())
@@ -1329,15 +1333,22 @@ class _SRBFused(torch.autograd.Function):
             stats = torch.empty((tiles, 64, 2), device=dev)
             _lib.call("focr_conv3x3_frag_fwd", _p(inp), ctypes.c_void_p(frag.data_ptr()), _p(bias), _NULL, _p(y),
                       _p(stats), n, h, w, 64, 64, 1.0, 0, 2, 0, 0, 0, _stream())
-            z = torch.empty_like(y)
+            # the second BatchNorm's output has ONE consumer, the packed projection's load: statistics only here, the
+            # normalisation rides on that load (FOCR_BN2_FUSE=0: separate apply pass)
+            fuse = i == 1 and _BN2_FUSE
+            z = None if fuse else torch.empty_like(y)
             mean, invstd = torch.empty(64, device=dev), torch.empty(64, device=dev)
             _lib.call("focr_bn_train_fwd_stats", _p(y), _p(stats), tiles, _p(gamma), _p(beta), _p(rmean), _p(rvar),
                       _p(nbt), _NULL, _p(z), _p(mean), _p(invstd), rows, 64, float(mom), float(eps_bn),
                       ACT_MISH if i == 0 else ACT_NONE, _stream())
             ys.append(y), zs.append(z), means.append(mean), invs.append(invstd)
             inp = z
-        out, fsaved, ctx.cfg = _fe_forward(step, zs[1].view(n, h * w, 64), x.view(n, h * w, 64), pe, heads, p_attn,
-                                           p_ffn, eps_ln, fparams)
+        if zs[1] is None:
+            out, fsaved, ctx.cfg = _fe_forward(step, ys[1].view(n, h * w, 64), x.view(n, h * w, 64), pe, heads, p_attn,
+                                               p_ffn, eps_ln, fparams, bn=(cparams[6], cparams[7], means[1], invs[1]))
+        else:
+            out, fsaved, ctx.cfg = _fe_forward(step, zs[1].view(n, h * w, 64), x.view(n, h * w, 64), pe, heads, p_attn,
+                                               p_ffn, eps_ln, fparams)
         ctx.geom = (n, h, w)
         ctx.targets = tuple(_target(p_) for p_ in params)
         ctx.save_for_backward(x, ys[0], zs[0], ys[1], means[0], invs[0], means[1], invs[1], *fsaved, *params)
@@ -1511,9 +1522,11 @@ class _CTC(torch.autograd.Function):
         return out, None, None, None
 
 
-def ctc_loss(logits, targets, lengths):
-    """targets: int32 [sum L] (device), lengths: int32 [B] (device)."""
-    offsets = (torch.cumsum(lengths, 0) - lengths).to(torch.int32)
+def ctc_loss(logits, targets, lengths, offsets=None):
+    """targets: int32 [sum L] (device), lengths: int32 [B] (device), offsets: int32 [B] exclusive prefix sums of the lengths
+    (CTCFocusLoss.encode computes them on the host; derived here when absent)."""
+    if offsets is None:
+        offsets = (torch.cumsum(lengths, 0) - lengths).to(torch.int32)
     return _CTC.apply(logits, targets.to(torch.int32).contiguous(), lengths.to(torch.int32).contiguous(),
                       offsets.contiguous())
 

@@ -31,7 +31,9 @@ class CTCFocusLoss(nn.Module):
             warnings.warn("CTC: %d label(s) longer than the recognizer's %d output steps contribute loss 0 / gradient 0 "
                           "(as F.ctc_loss with zero_infinity=True)" % (int((l > self.T_STEPS).sum()), self.T_STEPS))
             CTCFocusLoss._warned = True
-        return t.to(device), l.to(device)
+        # (target offsets = exclusive prefix sums of the lengths, on the host with the rest of the encoding: on the device they
+        # were a scan + two elementwise launches in front of every CTC kernel)
+        return t.to(device), l.to(device), (torch.cumsum(l, 0) - l).to(torch.int32).to(device)
 
     def forward(self, sr_img, hr_img, label_strs=None, encoded=None):
         mse = K.mse_loss(sr_img, hr_img)
@@ -42,5 +44,5 @@ class CTCFocusLoss(nn.Module):
             encoded = self.encode(label_strs, sr_img.device)
         gray = K.bicubic_gray(sr_img, 100)                  # parse_crnn_data, base.py:319-325
         logits = rec(gray)                                  # [26, B, 37]
-        ctc = K.ctc_loss(logits, encoded[0], encoded[1])
+        ctc = K.ctc_loss(logits, encoded[0], encoded[1], encoded[2] if len(encoded) > 2 else None)
         return mse + ctc, mse, -1, ctc

@@ -272,6 +272,12 @@ int focr_fe_post_bwd(const float* d_out, const float* wl, const float* xhat2, co
                      void* d_ctx_planes, float planes_mul, focr_stream_t stream);
 int focr_fe_qkv_fwd(const float* feat, const float* pe, const float* wqkv, const float* bqkv, float* tok,
                     float* qkv, long rows, int ntok, void* planes, float q_mul, focr_stream_t stream);
+/* the same with `feat` = the INPUT of the train-mode BatchNorm2d(64) in front of the block's FeatureEnhancer (tbsrn.py:246-251):
+ * gamma (x - mean) invstd + beta is applied on load (statistics from focr_bn_train_fwd_stats with y = NULL); the normalised
+ * tensor is never written */
+int focr_fe_qkv_fwd_bn(const float* feat, const float* pe, const float* wqkv, const float* bqkv, float* tok,
+                       float* qkv, long rows, int ntok, void* planes, float q_mul, const float* bn_gamma,
+                       const float* bn_beta, const float* bn_mean, const float* bn_invstd, focr_stream_t stream);
 int focr_fe_qkv_dgrad(const float* dqkv, const float* wqkv, const float* d_s1, float* d_feat, long rows,
                       focr_stream_t stream);
 long focr_fe_wgrads_ws_floats(long rows);

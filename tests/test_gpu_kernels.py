@@ -1032,8 +1032,8 @@ def test_ctc_long_label_and_determinism():
     crit = CTCFocusLoss(None)
     CTCFocusLoss._warned = False
     with pytest.warns(UserWarning):
-        enc_t, enc_l = crit.encode(["a" * 32, "abc"], "cuda")
-    assert enc_l.tolist() == [32, 3]
+        enc_t, enc_l, enc_off = crit.encode(["a" * 32, "abc"], "cuda")
+    assert enc_l.tolist() == [32, 3] and enc_off.tolist() == [0, 32]
     t, c = 26, 37
     labels = ["abc", "b" * 40, "hello"]
     tgt = torch.tensor([ord(ch) - ord("a") + 11 for s_ in labels for ch in s_], dtype=torch.int32)

@@ -58,6 +58,14 @@ def test_product_fails_loudly_without_gpu_tensors():
         K.prelu(torch.zeros(8), torch.zeros(1))
 
 
+def test_ctc_encode_returns_host_computed_offsets():
+    """CTCFocusLoss.encode: targets, lengths and the exclusive prefix sums of the lengths (the CTC kernel's per-sequence target
+    offsets), all computed on the host (utils/utils_crnn.py:21-53 label codec)"""
+    from fudanocr_amd.loss.ctc_focus_loss import CTCFocusLoss
+    t, l, off = CTCFocusLoss(None).encode(["Ab0", "zz", "q"], "cpu")
+    assert l.tolist() == [3, 2, 1] and off.tolist() == [0, 3, 5] and off.dtype == torch.int32 and t.numel() == 6
+
+
 def test_label_codec():
     from fudanocr_amd.utils.utils_crnn import get_crnn_pred, strLabelConverter
     c = strLabelConverter("0123456789abcdefghijklmnopqrstuvwxyz")
