@@ -35,6 +35,40 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     idx[i] = (uint8_t)bi;
   }
 }
+// four channels per thread (C % 4 == 0): float4 loads / store, the four argmax bytes as one word.  Same rule as above (first
+// strict maximum in (a, b) scan order).  The scalar form took 20 us on each of the recognizer's three pooling layers whatever
+// their size (34 - 67 MB in): one element per thread, four divisions each.
+__global__ __launch_bounds__(256) void maxpool_fwd_vec4_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                               uint8_t* __restrict__ idx, long total4, int H, int W, int C,
+                                                               int OH, int OW, int kh, int kw, int sh, int sw, int ph,
+                                                               int pw) {
+  const int C4 = C >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long t = i / C4;
+    const int ox = (int)(t % OW);
+    t /= OW;
+    const int oy = (int)(t % OH);
+    const long n = t / OH;
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    uint32_t bi[4] = {0u, 0u, 0u, 0u};
+    for (int a = 0; a < kh; ++a) {
+      const int iy = oy * sh - ph + a;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      for (int b = 0; b < kw; ++b) {
+        const int ix = ox * sw - pw + b;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const float4 v4 = reinterpret_cast<const float4*>(x)[(((size_t)n * H + iy) * W + ix) * C4 + c4];
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (v[e] > best[e]) { best[e] = v[e]; bi[e] = (uint32_t)(a * kw + b); }
+      }
+    }
+    reinterpret_cast<float4*>(y)[i] = make_float4(best[0], best[1], best[2], best[3]);
+    reinterpret_cast<uint32_t*>(idx)[i] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+  }
+}
 // gather form: dx[n,iy,ix,c] = sum over windows (oy,ox) containing it whose argmax is it
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy,
                                                           const uint8_t* __restrict__ idx,
@@ -322,6 +356,12 @@ extern "C" int focr_maxpool_fwd(const float* x, float* y, uint8_t* idx, int N, i
   int OH = (H + 2 * ph - kh) / sh + 1, OW = (W + 2 * pw - kw) / sw + 1;
   FOCR_CHECK_ARG(OH > 0 && OW > 0 && kh * kw <= 255, "bad geometry");
   long total = (long)N * OH * OW * C;
+#ifndef MAXPOOL_NO_VEC4
+  if (C % 4 == 0)
+    hipLaunchKernelGGL(maxpool_fwd_vec4_kernel, dim3(ew_grid(total / 4)), 256, 0, stream, x, y, idx, total / 4, H, W, C, OH,
+                       OW, kh, kw, sh, sw, ph, pw);
+  else
+#endif
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total)), 256, 0, stream, x, y, idx, total, H, W, C, OH, OW,
                      kh, kw, sh, sw, ph, pw);
   FOCR_LAUNCH_CHECK();
