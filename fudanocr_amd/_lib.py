@@ -35,6 +35,7 @@ SIGNATURES = {
     "focr_bn_train_fwd": [P, P, P, P, P, P, P, P, P, P, P, L, I, F, F, I, P],
     "focr_bn_train_fwd_stats": [P, P, I, P, P, P, P, P, P, P, P, P, L, I, F, F, I, P],
     "focr_bn_eval_fwd": [P, P, P, P, P, P, P, P, L, I, F, I, P],
+    "focr_bn_eval_apply": [P, P, P, P, P, P, P, L, I, I, P],
     "focr_bn_bwd": [P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, P],
     "focr_layernorm_fwd": [P, P, P, P, P, P, P, L, I, F, P],
     "focr_layernorm_bwd": [P, P, P, P, P, P, P, P, P, L, I, F, I, P],

@@ -916,6 +916,20 @@ extern "C" int focr_bn_eval_fwd(const float* x, const float* gamma, const float*
   return FOCR_OK;
 }
 
+// eval with the inverse standard deviation already known (focr_bn_eval_fwd's invstd_out of an earlier call with the same
+// running_var and eps: a frozen recognizer normalises with the same statistics every step -- one launch instead of two)
+extern "C" int focr_bn_eval_apply(const float* x, const float* gamma, const float* beta, const float* running_mean,
+                                  const float* invstd, const float* residual, float* y, long rows, int C, int act,
+                                  hipStream_t stream) {
+  FOCR_CHECK_ARG(x && gamma && beta && running_mean && invstd && y, "null pointer");
+  FOCR_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0, "need C % 4 == 0");
+  long total4 = rows * C / 4;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total4)), 256, 0, stream, x, gamma, beta, running_mean, invstd, residual,
+                     y, total4, C, act);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+
 // train-mode backward.  dgamma/dbeta: C floats each (overwritten); ws: focr_bn_bwd_ws_floats(rows, C) floats.
 // The two channel reductions (sum g*xhat = dgamma, sum g = dbeta) are slab partials + a fixed-order fold.
 // train == 0: eval-mode backward (mean = running_mean, no batch-statistics terms, no dgamma/dbeta, ws unused).

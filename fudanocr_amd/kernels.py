@@ -712,6 +712,9 @@ def _row_pitch(t):
     return pitch
 
 
+_EVAL_INVSTD = {}     # id(running_var) -> ((version, data_ptr, eps, C), invstd, weakref): eval-mode BatchNorm, see forward
+
+
 class _BatchNormAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, rmean, rvar, nbt, residual, training, act, momentum, eps, stats=None):
@@ -735,9 +738,22 @@ class _BatchNormAct(torch.autograd.Function):
                       act, _stream())
         else:
             mean = rmean
-            invstd = torch.empty(c, device=x.device)
-            _lib.call("focr_bn_eval_fwd", _p(x), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(residual), _p(y),
-                      _p(invstd), rows, c, float(eps), act, _stream())
+            # frozen statistics (the recognizer of the training step): 1 / sqrt(var + eps) is computed once per
+            # (running_var storage, version, eps) and reused -- the tensor is never written again
+            key = id(rvar)
+            hit = _EVAL_INVSTD.get(key)
+            if hit is not None and hit[2]() is rvar and hit[0] == (rvar._version, rvar.data_ptr(), float(eps), c):
+                invstd = hit[1]
+                _lib.call("focr_bn_eval_apply", _p(x), _p(gamma), _p(beta), _p(rmean), _p(invstd), _p(residual), _p(y),
+                          rows, c, act, _stream())
+            else:
+                invstd = torch.empty(c, device=x.device)
+                _lib.call("focr_bn_eval_fwd", _p(x), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(residual), _p(y),
+                          _p(invstd), rows, c, float(eps), act, _stream())
+                if len(_EVAL_INVSTD) > 256:        # (entries of tensors that are gone)
+                    for k_ in [k_ for k_, v_ in _EVAL_INVSTD.items() if v_[2]() is None]:
+                        del _EVAL_INVSTD[k_]
+                _EVAL_INVSTD[key] = ((rvar._version, rvar.data_ptr(), float(eps), c), invstd, weakref.ref(rvar))
         ctx.cfg = (rows, c, act, bool(training), residual is not None)
         ctx.targets = (_target(gamma), _target(beta))
         ctx.save_for_backward(x, gamma, beta, mean, invstd)

@@ -202,6 +202,11 @@ int focr_bn_train_fwd_stats(const float* x, const float* part, int nparts, const
 int focr_bn_eval_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean,
                      const float* running_var, const float* residual, float* y, float* invstd_out,
                      long rows, int C, float eps, int act, focr_stream_t stream);
+/* the same with invstd = focr_bn_eval_fwd's invstd_out of an earlier call (same running_var, eps): frozen statistics need
+ * the 1/sqrt(var + eps) pass once, not every step */
+int focr_bn_eval_apply(const float* x, const float* gamma, const float* beta, const float* running_mean,
+                       const float* invstd, const float* residual, float* y, long rows, int C, int act,
+                       focr_stream_t stream);
 int focr_bn_bwd(const float* dz, const float* x, const float* gamma, const float* beta, const float* mean,
                 const float* invstd, float* dx, float* dgamma, float* dbeta, float* ws, long rows, int C,
                 int act, int train, int lddz, focr_stream_t stream);
