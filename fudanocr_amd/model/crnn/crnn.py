@@ -4,11 +4,17 @@
 the reference does (interfaces/super_resolution.py:168-171): gradients flow to its input.  With requires_grad left on
 it trains like any other module (convolution / BatchNorm / Linear weight gradients as everywhere, LSTM weight
 gradients from kernels._LSTMRecur)."""
+import os
+
 import torch
 from torch import nn
 
 from ... import kernels as K
 from .._layers import BatchNorm2d, Conv2d, Linear, MaxPool2d, ReLUTag
+
+
+# FOCR_CRNN_FOLD_BN=0: frozen conv -> BatchNorm -> relu layers as convolution + eval-BatchNorm passes (A/B switch)
+_FOLD_BN = os.environ.get("FOCR_CRNN_FOLD_BN", "1") != "0"
 
 
 def _pair(v):
@@ -79,6 +85,30 @@ class CRNN(nn.Module):
         self.cnn = cnn
         self.rnn = nn.Sequential(BidirectionalLSTM(512, nh, nh), BidirectionalLSTM(nh, nh, nclass))
 
+    @staticmethod
+    def _foldable(conv, bn):
+        """conv -> BatchNorm(eval) -> relu with nothing to train: fold the normalisation into the convolution"""
+        if not _FOLD_BN or bn.training or not bn.track_running_stats or not conv.weight.is_cuda:
+            return False
+        ps = (conv.weight, conv.bias, bn.weight, bn.bias)
+        return not any(p is not None and p.requires_grad for p in ps)
+
+    def _folded(self, name, conv, bn):
+        """(weight * a[co], (bias - mean) * a + beta) with a = gamma / sqrt(running_var + eps), cached until one of the
+        six tensors changes (version counters); the weight keeps the channels_last layout the kernels read"""
+        ts = (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        key = tuple((t.data_ptr(), t._version) if t is not None else None for t in ts) + (bn.eps,)
+        cache = self.__dict__.setdefault("_fold_cache", {})
+        hit = cache.get(name)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                a = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                wf = (conv.weight * a.view(-1, 1, 1, 1)).contiguous(memory_format=torch.channels_last)
+                b0 = conv.bias if conv.bias is not None else torch.zeros_like(bn.running_mean)
+                bf = ((b0 - bn.running_mean) * a + bn.bias).contiguous()
+            cache[name] = hit = (key, wf, bf)
+        return hit[1], hit[2]
+
     def forward(self, input):
         x = K.to_nhwc(input) if input.shape[1] != 1 else input.reshape(input.shape[0], input.shape[2],
                                                                        input.shape[3], 1)
@@ -100,6 +130,14 @@ class CRNN(nn.Module):
                     x = m(x, relu=True)
                     i += 2                      # conv, relu
                     after_conv_relu = True
+                elif self._foldable(m, bn):
+                    # frozen layer with eval-mode statistics: BatchNorm is a per-channel affine map of the convolution's
+                    # output -- folded into its weights and bias once, the layer is conv + relu with no BatchNorm pass at
+                    # all (forward: one launch less and no second tensor; backward: no eval-BatchNorm gradient pass)
+                    wf, bf = self._folded(name, m, bn)
+                    x = K.conv2d(x, wf, bf, pad=m.padding, relu=True)
+                    i += 3                      # conv, batchnorm, relu
+                    after_conv_relu = False
                 else:
                     x = bn(m(x), act=K.ACT_RELU)
                     i += 3                      # conv, batchnorm, relu
