@@ -66,6 +66,38 @@ def test_ctc_encode_returns_host_computed_offsets():
     assert l.tolist() == [3, 2, 1] and off.tolist() == [0, 3, 5] and off.dtype == torch.int32 and t.numel() == 6
 
 
+def test_crnn_folded_batchnorm_algebra():
+    """model/crnn/crnn.py CRNN._folded: conv -> eval BatchNorm == conv with (weight * a, (bias - mean) * a + beta),
+    a = gamma / sqrt(running_var + eps) (reference crnn.py:41-47 convRelu(i, True) on a frozen recognizer); the cache
+    follows in-place updates of any of the six tensors; trainable or train-mode layers are not folded"""
+    import torch.nn.functional as F
+    from fudanocr_amd.model.crnn.crnn import CRNN
+    torch.manual_seed(0)
+    net = CRNN(32, 1, 37, 256).eval()
+    conv, bn = net.cnn.conv2, net.cnn.batchnorm2
+    with torch.no_grad():
+        bn.running_mean.normal_()
+        bn.running_var.uniform_(0.5, 2.0)
+        bn.weight.normal_()
+        bn.bias.normal_()
+    x = torch.randn(2, 128, 5, 7)
+    wf, bf = net._folded("conv2", conv, bn)
+    ref = F.batch_norm(F.conv2d(x, conv.weight, conv.bias, padding=1), bn.running_mean, bn.running_var, bn.weight, bn.bias,
+                       False, 0.0, bn.eps)
+    assert (F.conv2d(x, wf, bf, padding=1) - ref).abs().max().item() < 1e-4
+    assert net._folded("conv2", conv, bn)[0] is wf                      # cached
+    with torch.no_grad():
+        bn.running_var.mul_(2.0)
+    wf2, _ = net._folded("conv2", conv, bn)
+    assert wf2 is not wf and not torch.equal(wf2, wf)                   # follows the in-place update
+    assert not CRNN._foldable(conv, bn)                                 # CPU tensors / trainable parameters: per-layer path
+    for p_ in net.parameters():
+        p_.requires_grad_(False)
+    assert not CRNN._foldable(conv, bn)                                 # (still CPU)
+    bn.train()
+    assert not CRNN._foldable(conv, bn)
+
+
 def test_label_codec():
     from fudanocr_amd.utils.utils_crnn import get_crnn_pred, strLabelConverter
     c = strLabelConverter("0123456789abcdefghijklmnopqrstuvwxyz")
