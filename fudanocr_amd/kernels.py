@@ -722,6 +722,10 @@ class _BatchNormAct(torch.autograd.Function):
         rows = x.numel() // c
         _chk(x, gamma, beta, rmean, rvar, residual)
         y = torch.empty_like(x)
+        if training:
+            # the train kernels rewrite running_mean / running_var through raw pointers (no version bump): a cached
+            # eval-mode 1/sqrt(var + eps) of this tensor is stale from here on
+            _EVAL_INVSTD.pop(id(rvar), None)
         if training and stats is not None:
             # batch statistics from the producing convolution's per-tile partial sums: no statistics pass over x
             mean = torch.empty(c, device=x.device)
@@ -739,7 +743,7 @@ class _BatchNormAct(torch.autograd.Function):
         else:
             mean = rmean
             # frozen statistics (the recognizer of the training step): 1 / sqrt(var + eps) is computed once per
-            # (running_var storage, version, eps) and reused -- the tensor is never written again
+            # (running_var storage, version, eps) and reused until a train-mode forward on the same tensor drops it
             key = id(rvar)
             hit = _EVAL_INVSTD.get(key)
             if hit is not None and hit[2]() is rvar and hit[0] == (rvar._version, rvar.data_ptr(), float(eps), c):
@@ -1343,6 +1347,7 @@ class _SRBFused(torch.autograd.Function):
         for i in range(2):
             wgt, bias, gamma, beta = cparams[4 * i:4 * i + 4]
             rmean, rvar, nbt = bn_bufs[3 * i:3 * i + 3]
+            _EVAL_INVSTD.pop(id(rvar), None)          # running statistics are rewritten below (see _BatchNormAct)
             mom, eps_bn = bn_cfg[i]
             frag = _frag_weights(step, wgt, _ohwi(wgt), 64, 3, 3, 64, False)
             y = torch.empty((n, h, w, 64), device=dev)

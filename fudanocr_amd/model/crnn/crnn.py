@@ -106,6 +106,10 @@ class CRNN(nn.Module):
                 wf = (conv.weight * a.view(-1, 1, 1, 1)).contiguous(memory_format=torch.channels_last)
                 b0 = conv.bias if conv.bias is not None else torch.zeros_like(bn.running_mean)
                 bf = ((b0 - bn.running_mean) * a + bn.bias).contiguous()
+            if hit is not None:
+                # keep the replaced tensors alive: a new fold must never reuse their addresses, which key the frozen
+                # entries of kernels.FlipTable / FragTable (rebuilds are rare: checkpoint loads, freeze cycles)
+                self.__dict__.setdefault("_fold_retired", []).append(hit[1:])
             cache[name] = hit = (key, wf, bf)
         return hit[1], hit[2]
 
@@ -139,6 +143,9 @@ class CRNN(nn.Module):
                     i += 3                      # conv, batchnorm, relu
                     after_conv_relu = False
                 else:
+                    # trainable layer or train-mode statistics: its tensors may be rewritten behind autograd's version
+                    # counters (raw-pointer Adam, BatchNorm running statistics) -- a fold cached earlier is void
+                    self.__dict__.setdefault("_fold_cache", {}).pop(name, None)
                     x = bn(m(x), act=K.ACT_RELU)
                     i += 3                      # conv, batchnorm, relu
                     after_conv_relu = False

@@ -203,3 +203,47 @@ def test_sld_full_size_properties():
     assert all(np.isfinite(losses)) and max(losses) < 50 and abs(losses[0] - 2.0) < 0.5, losses
     first = [SLDTrainStep(_build_gpu(), dropout=False)(image, length, text_input, text_gt)["loss"].item() for _ in range(2)]
     assert first[0] == first[1], first
+
+
+@pytest.mark.gpu
+def test_sld_full_size_step_vs_oracle():
+    """BASELINE configs[4] at its per-GPU size (batch 32) against the CPU oracle's step (train.py:63-77 restated in
+    oracle.sld_oracle), bench arithmetic mode (3), dropout slots in eval: ragged predictions <= 1e-3 of max,
+    cross-entropy <= 1e-3, encoder features and attention maps <= 1e-3, gradient norm <= 2e-2."""
+    from fudanocr_amd import _lib
+    from fudanocr_amd.sld import util
+    from fudanocr_amd.sld.engine import SLDTrainStep
+    from oracle import sld_oracle as O
+    old = _lib.get_precision()
+    _lib.set_precision(3)
+    nthr = torch.get_num_threads()
+    try:
+        image, labels = make_sld_batch(32, 2025)
+        length, text_input, text_gt, _ = util.converter("stroke", labels, device="cuda", strokes=True)
+        m = _build_gpu()
+        step = SLDTrainStep(m, dropout=False)
+        m.train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.eval()
+        res = m(image.cuda(), length, text_input)
+        pred, conv, amap = res["pred"].detach().cpu(), res["conv"].detach().cpu(), res["map"].detach().cpu()
+        m.load_state_dict({k: v for k, v in _build_gpu().state_dict().items()})     # undo the BN running-stat update
+        out = step(image.cuda(), length, text_input, text_gt)
+        gn_hip = float(step.flat.flat_grad.double().norm())      # Adadelta does not touch the gradient buffer
+        P = O.make_params()
+        fill_dict_({k: v.data for k, v in P.items()})
+        opt = O.AdadeltaState([v for k, v in P.items() if v.requires_grad])
+        torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+        r = O.train_step(P, opt, image, length.cpu(), text_input.cpu(), text_gt.cpu())
+        e = (_rel(pred, r["pred"]), abs(out["loss"].item() - r["loss"]) / r["loss"], _rel(conv, r["conv"]),
+             _rel(amap, r["map"]), abs(gn_hip - r["grad_norm"]) / r["grad_norm"])
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        if os.path.isdir(d):
+            with open(os.path.join(d, "test_margins.txt"), "a") as f:
+                f.write("sld_full_size_step_vs_oracle (B = 32, mode 3): pred %.2e loss %.2e conv %.2e map %.2e grad-norm %.2e\n" % e)
+        assert e[0] < 1e-3 and e[1] < 1e-3 and e[2] < 1e-3 and e[3] < 1e-3, e
+        assert e[4] < 2e-2, e
+    finally:
+        torch.set_num_threads(nthr)
+        _lib.set_precision(old)
