@@ -114,6 +114,8 @@ SIGNATURES = {
     "focr_comm_init": [I, I, P],
     "focr_allreduce_async": [P, L, I, P],
     "focr_comm_nranks": [],
+    "focr_comm_count": [],
+    "focr_comm_rccl_version": [],
     "focr_comm_async_error": [],
     "focr_comm_wait": [P, I],
     "focr_comm_destroy": [],

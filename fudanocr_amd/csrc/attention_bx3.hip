@@ -1106,7 +1106,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_bx3_kernel(
 }
 
 #include "attention_bwd1_bx3.h"
-#include "attention_bwd1w_bx3.h"
+#ifdef FOCR_UBENCH_BWD1W          // one-wave-per-SIMD experiment (measured slower): tools/ubench only
+#include "../../tools/ubench/attention_bwd1w_bx3.h"
+#endif
 
 // launchers used by the dispatching C ABI entry points in attention.hip
 // 0: one query tile per wave (128-query blocks); 1: two tiles per wave (256-query blocks, needs Ntok % 256 == 0)
@@ -1146,8 +1148,9 @@ int focr_attn_bwd_bx3(const float* q, const float* k, const float* v, const floa
                       const float* dwork, const uint32_t* mask, float* dq, float* dk, float* dv, int B, int H,
                       int Ntok, int ld, int ldo, float scale, float p_drop, hipStream_t stream) {
   const bool fast = focr_get_precision() >= 2;
+#ifdef FOCR_UBENCH_BWD1W
   if (fast && focr_get_tuning(FOCR_TUNE_ATTN_BWD_DQ_VARIANT) == 3 && Ntok % 256 == 0) {
-    // experiment: the single pass with one wave per SIMD (attention_bwd1w_bx3.h)
+    // experiment: the single pass with one wave per SIMD (tools/ubench/attention_bwd1w_bx3.h)
     if (p_drop > 0.f) {
       (void)hipFuncSetAttribute((const void*)attn_bwd1w_bx3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, B1_LDS_BYTES);
       hipLaunchKernelGGL((attn_bwd1w_bx3_kernel<true>), dim3(B * H), 256, B1_LDS_BYTES, stream, q, k, v, d_o, lse, dwork, dq,
@@ -1159,6 +1162,7 @@ int focr_attn_bwd_bx3(const float* q, const float* k, const float* v, const floa
     }
     return 0;
   }
+#endif
   if (fast && focr_get_tuning(FOCR_TUNE_ATTN_BWD_DQ_VARIANT) == 2 && Ntok % 256 == 0) {
     // single pass: dQ, dK, dV from one S / dP evaluation (attention_bwd1_bx3.h); 138.5 KB of LDS per block.  The
     // attribute is per device: set on every call (a host-side table lookup) rather than cached in a process-wide flag.
@@ -1168,12 +1172,24 @@ int focr_attn_bwd_bx3(const float* q, const float* k, const float* v, const floa
 #else
     const bool dp1 = focr_get_precision() >= 3;
 #endif
+    // 138.5 KB of dynamic LDS: the attribute is set once per device and instantiation (focr_dev_flags); a device that
+    // refuses it falls through to the two-pass kernels below (static LDS only) instead of failing the launch
+    bool launched = false;
 #define LAUNCH_BWD1(DR, D1)                                                                                       \
   do {                                                                                                            \
-    (void)hipFuncSetAttribute((const void*)attn_bwd1_bx3_kernel<DR, D1>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              B1_LDS_BYTES);                                                                      \
-    hipLaunchKernelGGL((attn_bwd1_bx3_kernel<DR, D1>), dim3(B * H), 512, B1_LDS_BYTES, stream, q, k, v, d_o, lse, dwork, \
-                       dq, dk, dv, mask, Ntok, ld, ldo, ld, scale, p_drop, H);                                    \
+    static focr_dev_flags attr_set_;                                                                              \
+    bool ok_ = true;                                                                                              \
+    if (focr_dev_first(attr_set_)) {                                                                              \
+      ok_ = hipFuncSetAttribute((const void*)attn_bwd1_bx3_kernel<DR, D1>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                B1_LDS_BYTES) == hipSuccess;                                                      \
+      if (ok_) focr_dev_mark(attr_set_);                                                                          \
+      else (void)hipGetLastError();                                                                               \
+    }                                                                                                             \
+    if (ok_) {                                                                                                    \
+      hipLaunchKernelGGL((attn_bwd1_bx3_kernel<DR, D1>), dim3(B * H), 512, B1_LDS_BYTES, stream, q, k, v, d_o, lse, dwork, \
+                         dq, dk, dv, mask, Ntok, ld, ldo, ld, scale, p_drop, H);                                  \
+      launched = true;                                                                                            \
+    }                                                                                                             \
   } while (0)
     if (p_drop > 0.f) {
       if (dp1) LAUNCH_BWD1(true, true);
@@ -1183,7 +1199,7 @@ int focr_attn_bwd_bx3(const float* q, const float* k, const float* v, const floa
       else LAUNCH_BWD1(false, false);
     }
 #undef LAUNCH_BWD1
-    return 0;
+    if (launched) return 0;
   }
   dim3 grid(B * H * (Ntok / 128));
   const bool dq2 = focr_get_tuning(FOCR_TUNE_ATTN_BWD_DQ_VARIANT) == 1 && Ntok % 256 == 0;      // two query tiles per wave in the dQ pass

@@ -21,6 +21,8 @@ struct Rccl {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;
   ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 } g_rccl;
 ncclComm_t g_comm = nullptr;
@@ -41,6 +43,8 @@ int load_rccl() {
   g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
   g_rccl.CommGetAsyncError = reinterpret_cast<decltype(g_rccl.CommGetAsyncError)>(dlsym(h, "ncclCommGetAsyncError"));
   g_rccl.CommAbort = reinterpret_cast<decltype(g_rccl.CommAbort)>(dlsym(h, "ncclCommAbort"));
+  g_rccl.CommCount = reinterpret_cast<decltype(g_rccl.CommCount)>(dlsym(h, "ncclCommCount"));
+  g_rccl.GetVersion = reinterpret_cast<decltype(g_rccl.GetVersion)>(dlsym(h, "ncclGetVersion"));
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
     focr_set_error("focr_comm: librccl.so lacks an expected symbol");
     dlclose(h);
@@ -132,6 +136,23 @@ extern "C" int focr_comm_wait(hipStream_t stream, int timeout_ms) {
   }
 }
 extern "C" int focr_comm_nranks(void) { return g_comm ? g_nranks : 0; }
+// What RCCL itself says: the rank count of the live communicator (ncclCommCount; 0 without a communicator, negative
+// error code on failure) and the library's version code (ncclGetVersion, e.g. 22105; loads RCCL if necessary).
+extern "C" int focr_comm_count(void) {
+  if (!g_comm) return 0;
+  if (!g_rccl.CommCount) return g_nranks;
+  int n = 0;
+  const int rc = check(g_rccl.CommCount(g_comm, &n), "ncclCommCount");
+  return rc == FOCR_OK ? n : rc;
+}
+extern "C" int focr_comm_rccl_version(void) {
+  int rc = load_rccl();
+  if (rc != FOCR_OK) return rc;
+  if (!g_rccl.GetVersion) return 0;
+  int v = 0;
+  rc = check(g_rccl.GetVersion(&v), "ncclGetVersion");
+  return rc == FOCR_OK ? v : rc;
+}
 extern "C" int focr_comm_destroy(void) {
   if (!g_comm) return FOCR_OK;
   int rc = check(g_rccl.CommDestroy(g_comm), "ncclCommDestroy");

@@ -470,12 +470,12 @@ static int launch_h3(const float* x, const __bf16* wf, const float* bias, const 
                      int N, int H, int W, int Cin, int Cout, int ldx, int ldy, int ldr, float alpha, int relu,
                      hipStream_t stream) {
   constexpr int LDS = PLANES * H3_PLANE_BYTES + H3_NBUF * (2 * H3_KSC * PLANES) * 1024;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static focr_dev_flags attr_set;
+  if (focr_dev_first(attr_set)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<PLANES>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return 0;
-    attr_set = true;
+    focr_dev_mark(attr_set);
   }
   H3Geom g;
   g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ldx = ldx; g.ldy = ldy; g.ldr = ldr;

@@ -335,12 +335,12 @@ int focr_conv3x3_c64_wgrad(const float* x, const float* dy, float* dw, float* db
                            hipStream_t stream) {
   if (!c3_applicable(W, Cin, Cout, KH, KW, padH, padW, ldd, ldx)) return 0;
   static const size_t lds = (size_t)12 * TILE_E * sizeof(__bf16);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static focr_dev_flags attr_set;
+  if (focr_dev_first(attr_set)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_wgrad_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return 0;
-    attr_set = true;
+    focr_dev_mark(attr_set);
   }
   int nb, rpb;
   c3_blocks(N, H, Cout, nb, rpb);

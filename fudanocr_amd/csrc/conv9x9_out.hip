@@ -318,14 +318,14 @@ extern "C" int focr_conv9x9_small_cout_fwd(const float* x, const float* w, const
   }
   if (focr_get_precision() != 0) {
     static const size_t lds = (size_t)2 * 9 * 32 * WBP * sizeof(__bf16) + (size_t)WAVES9 * 32 * ZP * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static focr_dev_flags attr_set;
+    if (focr_dev_first(attr_set)) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv9x9_out_fwd_bx3_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         focr_set_error("focr_conv9x9_small_cout_fwd: cannot raise the dynamic LDS limit");
         return FOCR_EHIP;
       }
-      attr_set = true;
+      focr_dev_mark(attr_set);
     }
     const int T = cdiv(W, OT);
     int RR = cdiv(256 * WAVES9, N * T);               // at least one strip per wave slot of the chip

@@ -530,15 +530,20 @@ extern "C" int focr_linear_masked_fwd(const float* x, const float* w, const floa
 extern "C" long focr_conv2d_wgrad_ws_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int padH,
                                             int padW) {
   if (focr_get_precision() == 0) return 0;
+  // Which kernel takes the layer is decided again at launch time with the caller's row pitches (ldd / ldx), which this
+  // query does not see: the workspace is sized for the LARGEST candidate, so that whichever path the launch falls to
+  // finds room (every path also checks ws_floats against its own need before touching the buffer).
+  long n = 0;
   if (KH == 1 && KW == 1 && padH == 0 && padW == 0 && focr_linear_wgrad_eligible((long)N * H * W, Cin, Cout, 4, 4))
-    return focr_linear_wgrad_ws_floats((long)N * H * W, Cin, Cout);
-  long n = focr_conv3x3_c64_ws_floats(N, H, W, Cin, Cout, KH, KW, padH, padW);
-  if (n > 0) return n;
-  n = focr_conv3x3_cin_small_ws_floats(N, H, W, Cin, Cout, KH, KW, padH, padW);
-  if (n > 0) return n;
+    n = focr_linear_wgrad_ws_floats((long)N * H * W, Cin, Cout);
+  long m = focr_conv3x3_c64_ws_floats(N, H, W, Cin, Cout, KH, KW, padH, padW);
+  if (m > n) n = m;
+  m = focr_conv3x3_cin_small_ws_floats(N, H, W, Cin, Cout, KH, KW, padH, padW);
+  if (m > n) n = m;
   ConvGeom g;
-  if (fill_geom(g, N, H, W, Cin, Cout, KH, KW, padH, padW) != 0) return 0;
-  return focr_conv_wgrad_bx3_ws_floats(g.M, Cin, Cout, g.Ktot);
+  if (fill_geom(g, N, H, W, Cin, Cout, KH, KW, padH, padW) != 0) return n;
+  m = focr_conv_wgrad_bx3_ws_floats(g.M, Cin, Cout, g.Ktot);
+  return m > n ? m : n;
 }
 
 extern "C" int focr_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N,

@@ -162,12 +162,12 @@ static int launch_ls_(const float* x, const float* w, const float* bias, const f
                       int ldx, int ldy, int ldr, float alpha, int relu, uint32_t drop_k, float drop_scale,
                       uint32_t drop_seed, float mask_scale, hipStream_t stream) {
   const size_t lds = (size_t)2 * 32 * NT * (K + 8) * sizeof(__bf16);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static focr_dev_flags attr_set;
+  if (focr_dev_first(attr_set)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_stream_bx3_kernel<K, NT, HAS_RES, HAS_DROP>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return 0;
-    attr_set = true;
+    focr_dev_mark(attr_set);
   }
   const int ny = cdiv(Cout, 32 * NT);
   const int ntiles = cdiv(M, 32);

@@ -227,10 +227,12 @@ int focr_linear_wgrad(const float* x, const float* dy, float* dw, float* dbias, 
   lw_splits(M, K, Cout, sp, rows);
   const long slot = (long)Cout * K + Cout;
   if (!ws || ws_floats < (long)sp * slot) return 1;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)linear_wgrad_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LW_LDS);
-    attr_done = true;
+  static focr_dev_flags attr_done;
+  if (focr_dev_first(attr_done)) {
+    if (hipFuncSetAttribute((const void*)linear_wgrad_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LW_LDS) !=
+        hipSuccess)
+      return 1;                                        // caller falls back to the generic weight-gradient kernel
+    focr_dev_mark(attr_done);
   }
   hipLaunchKernelGGL(linear_wgrad_stream_kernel, dim3(K / 128, Cout / 128, sp), 256, LW_LDS, stream, x, dy, ws, (int)M,
                      ldx, ldd, K, Cout, rows, dbias ? 1 : 0);

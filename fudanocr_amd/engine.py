@@ -189,6 +189,9 @@ class TrainStep:
         edges = [n * i // n_buckets // 4 * 4 for i in range(n_buckets)] + [n]
         self.buckets = [(edges[i], edges[i + 1]) for i in range(n_buckets) if edges[i + 1] > edges[i]]
         self._works, self._sent = [], []
+        # bench.py's N > 1 line: per step, the time the COMPUTE stream spends waiting for the exchange after the last
+        # backward / weight-gradient kernel (event pair around the tail launches + waits) = the exposed communication
+        self.comm_timing, self._comm_events = False, []
         self._plan_overlap(boundaries, tail)
 
     def _attach_packed_qkv(self):
@@ -304,6 +307,10 @@ class TrainStep:
         """All-reduce whatever the backward hooks have not sent yet, then wait for everything."""
         if self.world == 1:
             return
+        timed = self.comm_timing and self.flat.flat_grad.is_cuda
+        if timed:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()                  # backward and the side stream's weight gradients are complete here
         sent = sorted(self._sent)
         todo, pos = [], 0
         for lo, hi in sent + [(self.flat.numel, self.flat.numel)]:
@@ -324,7 +331,37 @@ class TrainStep:
             else:
                 _lib.call("focr_comm_async_error")
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if timed:
+            ev1.record()                  # the compute stream continues (clip + Adam) only after every range has arrived
+            self._comm_events.append((ev0, ev1))
         self._works, self._sent = [], []
+
+    def rccl_ranks(self):
+        """the rank count the MEASURED communicator reports: a sum all-reduce of 1 over the path the gradients take
+        (torch.distributed's backend, or the library's own communicator with FOCR_COMM=native + ncclCommCount)"""
+        if self.world == 1:
+            return 1
+        one = torch.ones(4, device=self.flat.flat_grad.device)
+        if self.native_comm:
+            from . import _lib
+            _lib.call("focr_allreduce_async", ctypes.c_void_p(one.data_ptr()), 4, 0,
+                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            n = int(round(one[0].item()))
+            cnt = _lib.load().focr_comm_count()
+            if cnt != n:
+                raise RuntimeError("ncclCommCount says %d ranks, an all-reduce of 1 returned %d" % (cnt, n))
+            return n
+        dist.all_reduce(one, op=dist.ReduceOp.SUM, group=self.pg)
+        return int(round(one[0].item()))
+
+    def exposed_comm_ms(self):
+        """mean over the timed steps (comm_timing = True) of the compute stream's wait for the gradient exchange"""
+        if not self._comm_events:
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._comm_events]
+        self._comm_events = []
+        return sum(ms) / len(ms)
 
     def _set_modes(self):
         """train mode (nn.Dropout slots in eval for parity runs).  Walking the 190 modules costs ~0.8 ms, so it is done

@@ -187,6 +187,19 @@ class StepContext:
     def take_deferred(self, t):
         return self.deferred.pop(_dkey(t), None)
 
+    def mark_premasked(self, t):
+        """`t` is a gradient whose producer already applied the consumer layer's relu backward.  Keyed by address but
+        matched by storage identity + shape (a weak reference): an entry nobody consumed -- an autograd.grad on an
+        intermediate outside the engine -- can never be taken for a later tensor that reuses the address."""
+        self.premasked[t.data_ptr()] = (weakref.ref(t.untyped_storage()), t.numel())
+
+    def take_premasked(self, t):
+        hit = self.premasked.pop(t.data_ptr(), None)
+        if hit is None:
+            return False
+        st = hit[0]()
+        return st is not None and st is t.untyped_storage() and hit[1] == t.numel()
+
     def check_deferred(self):
         self.premasked.clear()
         if self.deferred:
@@ -558,7 +571,7 @@ class _Conv2d(torch.autograd.Function):
         cout = weight.shape[0]
         oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
         dy4 = dy.contiguous().reshape(n, oh, ow, cout)
-        if relu and step.premasked.pop(dy4.data_ptr(), None) is not None:
+        if relu and step.take_premasked(dy4):
             pass        # the consumer's data-gradient kernel already applied (y > 0) * scale in its epilogue
         elif relu:
             g = torch.empty_like(dy4)
@@ -642,7 +655,7 @@ class _Conv2d(torch.autograd.Function):
                                                         ctypes.c_float(ctx.in_relu_scale), _stream())
                 if rc == 0:
                     fused_mask = True
-                    step.premasked[dx4.data_ptr()] = True
+                    step.mark_premasked(dx4)
                 elif rc != -2:
                     raise RuntimeError("focr_linear_masked_fwd failed: " + _lib.load().focr_last_error().decode())
             if fused_mask:
@@ -1590,7 +1603,7 @@ class _MaxPool(torch.autograd.Function):
         if ctx.relu_input:
             _lib.call("focr_maxpool_relu_bwd", _p(dy), ctypes.c_void_p(idx.data_ptr()), _p(ctx.saved_tensors[1]), _p(dx), n,
                       h, w, c, kh, kw, sh, sw, ph, pw, _stream())
-            ctx.step.premasked[dx.data_ptr()] = True
+            ctx.step.mark_premasked(dx)
         else:
             _lib.call("focr_maxpool_bwd", _p(dy), ctypes.c_void_p(idx.data_ptr()), _p(dx), n, h, w, c, kh, kw, sh,
                       sw, ph, pw, _stream())

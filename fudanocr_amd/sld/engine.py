@@ -45,6 +45,7 @@ class SLDTrainStep:
                            group=process_group)
         self.comm_stream = torch.cuda.Stream() if (self.world > 1 and self.flat.flat_grad.is_cuda) else None
         self._works, self._sent_lo = [], self.flat.numel
+        self.comm_timing, self._comm_events = False, []       # see engine.TrainStep.exposed_comm_ms
         ids = {id(p): off for p, off in zip(self.flat.params, self.flat.offsets)}
         enc = model.encoder
         self._stage_lo = {}
@@ -113,9 +114,32 @@ class SLDTrainStep:
             self.flips.build(self.flat.flat_grad.device)
             c.join_side_stream()
         if self.world > 1:
+            timed = self.comm_timing and on_gpu
+            if timed:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
             self._send_down_to(0)
             for w in self._works:
                 w.wait()
+            if timed:
+                ev1.record()
+                self._comm_events.append((ev0, ev1))
         self.opt.step(self.world)
         K.bump_weight_epoch()
         return {"loss": loss.detach(), "pred": result["pred"].detach()}
+
+    def rccl_ranks(self):
+        """sum all-reduce of 1 over the communicator the gradient buckets use"""
+        if self.world == 1:
+            return 1
+        one = torch.ones(4, device=self.flat.flat_grad.device)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM, group=self.pg)
+        return int(round(one[0].item()))
+
+    def exposed_comm_ms(self):
+        if not self._comm_events:
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._comm_events]
+        self._comm_events = []
+        return sum(ms) / len(ms)

@@ -434,6 +434,8 @@ int focr_weight_cross_entropy_fwd(const float* logits, const long long* target, 
  * focr_comm_init: collective, on the thread whose current device is the rank's GPU;
  * focr_allreduce_async: buf[0..n) <- sum over ranks, in place, on `stream` (dtype 0 = fp32);
  * focr_comm_nranks: 0 when there is no communicator;
+ * focr_comm_count: the rank count RCCL reports for the live communicator (ncclCommCount; 0 without one);
+ * focr_comm_rccl_version: ncclGetVersion's code of the RCCL instance the library is bound to (negative: cannot load);
  * focr_comm_async_error: non-blocking ncclCommGetAsyncError (also checked in front of every focr_allreduce_async);
  * focr_comm_wait: host-side watchdog -- waits for `stream` to drain while polling the communicator; on an asynchronous
  *   error or after timeout_ms (<= 0: no limit) the communicator is aborted (ncclCommAbort) and FOCR_ENCCL returned. */
@@ -442,6 +444,8 @@ int focr_comm_unique_id(void* id_out);
 int focr_comm_init(int rank, int nranks, const void* unique_id);
 int focr_allreduce_async(void* buf, size_t n, int dtype, focr_stream_t stream);
 int focr_comm_nranks(void);
+int focr_comm_count(void);
+int focr_comm_rccl_version(void);
 int focr_comm_async_error(void);
 int focr_comm_wait(focr_stream_t stream, int timeout_ms);
 int focr_comm_destroy(void);

@@ -127,6 +127,10 @@ def test_bench_self_launches_its_ranks():
     res = json.loads(line[0])
     assert res["n_gpus"] == 2 and res["config"]["collective_backend"] == "gloo" and res["value"] > 0
     assert res["config"]["global_batch"] == 16
+    # scaling-run evidence carried by every N > 1 line: the rank count an all-reduce of 1 over the measured communicator
+    # returns, the collective library's version (None on gloo) and the event-timed exposed communication per step
+    assert res["rccl_ranks"] == 2 and "rccl_version" in res and res["comm_path"].startswith("torch.distributed")
+    assert res["exposed_comm_ms"] is not None and res["exposed_comm_ms"] >= 0.0
 
 
 MAIN_WORKER = r"""

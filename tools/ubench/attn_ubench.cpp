@@ -7,6 +7,7 @@
 #include <vector>
 #include <cmath>
 #include <algorithm>
+#define FOCR_UBENCH_BWD1W 1
 #include "../../fudanocr_amd/csrc/attention.hip"
 #include "../../fudanocr_amd/csrc/attention_bx3.hip"
 
