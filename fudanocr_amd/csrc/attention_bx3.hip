@@ -240,7 +240,14 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_bx3_kernel(const float* __res
 // =======================================================================================
 __device__ __forceinline__ void hi_regs(const f32x16& s, int m, bf16x8& hi);
 // PL: Q / K / V point to bf16 hi planes (row pitch ld = 128 elements, lo plane `pls` elements behind), Q pre-scaled
-template <bool DROPOUT, bool PL>
+// MV (keep-word schedule, round 5): the 64-lane keep masks are wave-uniform scalar loads, and scalar loads share the
+// lgkm counter with the LDS fragment reads -- out of order, so EVERY LDS wait behind them is a wait for them too.
+//   0: masks requested at the top of a key group, in front of the K-fragment reads: the first score MFMA waits for the
+//      HBM round trip of the keep words (the forward's 47 us dropout penalty);
+//   1: K fragments are read and waited for FIRST, then the masks are requested and travel under the twelve score MFMAs,
+//      the max tree and the exp2 stretch; the cross-half max exchange is a v_permlane32_swap (no LDS operation, no lgkm
+//      wait) so that nothing between the request and the first v_cndmask waits on the counter.
+template <bool DROPOUT, bool PL, int MV = 0>
 __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                             const float* __restrict__ V, float* __restrict__ O,
                                                             float* __restrict__ LSE, const uint32_t* __restrict__ MASK,
@@ -322,6 +329,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __re
       // keep-bit lane masks of both tiles (wave-uniform -> scalar loads), requested before the score MFMAs so that
       // their latency is covered
       uint64_t mk[2][16];
+      bf16x8 ah[2], al[2];
+      if (MV == 1) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          ah[m] = *reinterpret_cast<const bf16x8*>(&Kh[(sub * 32 + li) * RP + 16 * m + 8 * lh]);
+          al[m] = *reinterpret_cast<const bf16x8*>(&Kl[(sub * 32 + li) * RP + 16 * m + 8 * lh]);
+        }
+        if (DROPOUT) {
+          __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the fragments are here BEFORE the scalar requests go out
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
       if (DROPOUT) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -338,13 +357,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __re
         for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Kh[(sub * 32 + li) * RP + 16 * m + 8 * lh]);
-        bf16x8 al = *reinterpret_cast<const bf16x8*>(&Kl[(sub * 32 + li) * RP + 16 * m + 8 * lh]);
+        if (MV != 1) {
+          ah[m] = *reinterpret_cast<const bf16x8*>(&Kh[(sub * 32 + li) * RP + 16 * m + 8 * lh]);
+          al[m] = *reinterpret_cast<const bf16x8*>(&Kl[(sub * 32 + li) * RP + 16 * m + 8 * lh]);
+        }
 #ifdef ATTN_ABL_MFMA_S
-        s[0][0] += (float)ah[0] + (float)al[1]; s[1][0] += (float)ah[2];
+        s[0][0] += (float)ah[m][0] + (float)al[m][1]; s[1][0] += (float)ah[m][2];
 #else
-        MFMA3(s[0], ah, al, qh[0][m], ql[0][m]);
-        MFMA3(s[1], ah, al, qh[1][m], ql[1][m]);
+        MFMA3(s[0], ah[m], al[m], qh[0][m], ql[0][m]);
+        MFMA3(s[1], ah[m], al[m], qh[1][m], ql[1][m]);
 #endif
       }
 #ifndef ATTN_ABL_SOFTMAX
@@ -353,7 +374,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __re
         float mx = s[t][0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (MV == 1) {
+          // lanes l and l ^ 32 hold the two key halves of one query: swap the halves in the VALU (gfx950
+          // v_permlane32_swap: upper row of the first operand <-> lower row of the second), max of the pair = max of
+          // own and partner in every lane
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+          mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        } else {
+          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        }
         // Thresholded running max (wave-uniform branch): O / l are rescaled only when some query's max grew by more
         // than 2^ATTN_RESCALE_THR since the last rescale; otherwise P is merely bounded by 2^THR instead of 1 --
         // harmless for fp32 accumulation with split operands -- and the exp + 16 multiplies of the common case go away
@@ -377,11 +406,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __re
           ls += p;
           s[t][r] = p;
         }
-        if (DROPOUT) {
+        if (DROPOUT && MV != 1) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) s[t][r] = keep_lanes(s[t][r], mk[t][r]);   // 1/(1-p) at the end
         }
         l[t] += ls;
+      }
+      if (DROPOUT && MV == 1) {
+        // both tiles' max / exp2 / row sums first (no mask needed), THEN the selects: the scalar requests have had the
+        // score MFMAs and ~230 VALU instructions to arrive
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[t][r] = keep_lanes(s[t][r], mk[t][r]);   // 1/(1-p) at the end
       }
 #endif
 #pragma unroll
@@ -1127,7 +1165,10 @@ int focr_attn_fwd_bx3(const float* q, const float* k, const float* v, float* o, 
   }
   if (focr_get_tuning(FOCR_TUNE_ATTN_FWD_VARIANT) == 1 && Ntok % 256 == 0) {
     dim3 grid2(B * H * (Ntok / 256));
-    if (p_drop > 0.f)
+    if (p_drop > 0.f && focr_get_tuning(FOCR_TUNE_ATTN_FWD_MASK) == 1)
+      hipLaunchKernelGGL((attn_fwd2_bx3_kernel<true, false, 1>), grid2, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ld, ldo,
+                         scale, p_drop, seed, H, 0L);
+    else if (p_drop > 0.f)
       hipLaunchKernelGGL((attn_fwd2_bx3_kernel<true, false>), grid2, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ld, ldo,
                          scale, p_drop, seed, H, 0L);
     else
@@ -1253,7 +1294,10 @@ int focr_attn_fwd_bx3_planes(const void* qp, const void* kp, const void* vp, flo
   const float* k = reinterpret_cast<const float*>(kp);
   const float* v = reinterpret_cast<const float*>(vp);
   dim3 grid2(B * H * (Ntok / 256));
-  if (p_drop > 0.f)
+  if (p_drop > 0.f && focr_get_tuning(FOCR_TUNE_ATTN_FWD_MASK) == 1)
+    hipLaunchKernelGGL((attn_fwd2_bx3_kernel<true, true, 1>), grid2, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ldp, ldo,
+                       1.f, p_drop, (uint64_t)0, H, pls);
+  else if (p_drop > 0.f)
     hipLaunchKernelGGL((attn_fwd2_bx3_kernel<true, true>), grid2, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ldp, ldo,
                        1.f, p_drop, (uint64_t)0, H, pls);
   else

@@ -18,7 +18,8 @@ extern "C" int focr_get_precision(void);
 #define FOCR_TUNE_ATTN_FWD_VARIANT 1
 #define FOCR_TUNE_LSTM_PERSISTENT 2
 #define FOCR_TUNE_ATTN_BWD_DQ_VARIANT 3
-#define FOCR_TUNING_COUNT 4
+#define FOCR_TUNE_ATTN_FWD_MASK 4
+#define FOCR_TUNING_COUNT 5
 extern "C" int focr_get_tuning(int key);
 
 #define FOCR_CHECK_ARG(cond, msg)                          \

@@ -49,7 +49,8 @@ int focr_set_precision(int mode);
  * key 2: persistent LSTM scan, one launch per layer (1, default) or one launch per time step (0);
  * key 3: attention backward: 2 (default) = single pass, dQ / dK / dV from one S / dP evaluation (precision modes 2 / 3
  * and Ntok % 256 == 0, otherwise as 1); 1 = two passes (dK/dV, then dQ with 256-query blocks); 0 = two passes,
- * 128-query dQ blocks. */
+ * 128-query dQ blocks; key 4: keep-word schedule of the 256-query attention forward: 1 (default) = scalar mask requests
+ * behind the K-fragment reads, travelling under the score MFMAs; 0 = in front of them (round 1-4 schedule). */
 int focr_set_tuning(int key, int value);
 int focr_get_tuning(int key);
 int focr_get_precision(void);

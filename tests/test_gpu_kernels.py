@@ -405,7 +405,8 @@ def test_attention_backward_single_pass(p, t):
         qkv = rnd(b, t, 384, seed=11, scale=1.5).requires_grad_(True)
         go = rnd(b, t, 128, seed=4)
         res = {}
-        for variant in (2, 3, 1):         # 2 = the default single pass, 3 = its one-wave-per-SIMD form (A/B), 1 = two passes
+        for variant in (2, 1):            # 2 = the default single pass, 1 = two passes (the one-wave-per-SIMD experiment
+                                          # lives in tools/ubench only since round 5)
             _lib.call("focr_set_tuning", 3, variant)
             x = dev(qkv).requires_grad_(True)
             od = _AttentionPacked.apply(x, 4, p, 4242)
@@ -429,14 +430,13 @@ def test_attention_backward_single_pass(p, t):
         o = (pr @ heads(v)).transpose(1, 2).reshape(b, t, 128)
         o.backward(go)
         o2, g2 = res[1]
-        for variant in (2, 3):
+        for variant in (2,):
             o1, g1 = res[variant]
             assert torch.equal(o1, o2)
             close(o1, o, ptol(2), what="single-pass: forward")
             close(g1, qkv.grad, gtol(2), what="single-pass (variant %d): d qkv vs fp64" % variant)
             assert torch.equal(g1[..., 128:], g2[..., 128:]), "dK / dV of the single-pass and two-pass kernels differ"
             close(g1[..., :128], g2[..., :128], 4e-3, what="single-pass dQ vs two-pass dQ")
-        assert torch.equal(res[2][1], res[3][1]), "the two single-pass forms differ"
         # precision mode 3 ("bf16 data gradients"): the same kernel with dP = dO V^T as ONE bf16 product (template flag
         # DP1) -- same keep bits (same seed), same forward; the gradient against the fp64 reference at the mode's gate
         _lib.set_precision(3)

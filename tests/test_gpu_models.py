@@ -354,7 +354,7 @@ def test_step_vs_oracle_fresh_batch(batch, prec_mode):
 
 
 # allowance of test_gradients_elementwise_b32_fp64 per arithmetic mode (measured margins: profiles/r05_test_margins.txt)
-GRAD_ALLOWANCE_B32 = {2: 2e-3, 3: 7e-3}
+GRAD_ALLOWANCE_B32 = {2: 1e-3, 3: 9e-3}
 
 SMOOTH_PARAMS = ("conv1.weight", "conv2.weight", ".pff.w_1.weight", ".pff.w_2.weight", ".linears.0.weight",
                  ".linears.1.weight", ".linears.2.weight", ".linears.3.weight", ".feature_enhancer.linear.weight",
@@ -566,7 +566,11 @@ def test_gradients_elementwise_b32_fp64(mode):
     test_train_gradients_elementwise_vs_oracle) is gone: B = 32, TBSRN + CRNN-CTC, fp64 oracle as the truth.  Per smooth
     parameter err(HIP, fp64) <= 2 x err(fp32 oracle, fp64) + allowance; the allowance is what the ARITHMETIC MODE costs
     (mode 2: split products except the attention's gradient accumulations; mode 3: + single-bf16 data-gradient
-    convolutions and dP), measured in gpurun_out/test_margins.txt and stated here."""
+    convolutions and dP), measured (profiles/r05_test_margins.txt) and stated here.  Mode 2: the worst HIP gradient is 1.9e-3
+    from the fp64 truth where the fp32 CPU oracle is at 2.6e-3 (pff.w_1.bias of block2) -- never further than the fp32
+    oracle + 4e-4: allowance 1e-3.  Mode 3: 7.5e-3 on block2's q / k projection weights (fp32 oracle 3e-4): ten bf16
+    data-gradient convolutions and five bf16 dP products lie between the loss and that block -- this IS the price of the
+    mode at a batch size where BatchNorm noise no longer hides it; allowance 9e-3."""
     from fudanocr_amd import _lib
     from fudanocr_amd.utils.weight_fill import fill_dict_
     from oracle import sr_oracle as O

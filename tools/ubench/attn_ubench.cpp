@@ -14,7 +14,7 @@
 extern "C" void focr_set_error(const char* fmt, ...) { va_list a; va_start(a, fmt); vfprintf(stderr, fmt, a); va_end(a); fputc('\n', stderr); }
 static int g_prec = 2;
 extern "C" int focr_get_precision(void) { return g_prec; }
-static int g_tune[FOCR_TUNING_COUNT] = {1, 1, 1, 1};
+static int g_tune[FOCR_TUNING_COUNT] = {1, 1, 1, 1, 0};
 extern "C" int focr_get_tuning(int key) { return g_tune[key]; }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -57,6 +57,31 @@ int main(int argc, char** argv) {
   const float scale = 1.f / sqrtf(32.f);
   const double fl = 4.0 * B * H * (double)N * N * 32;
   const bool only_b1 = argc > 4 && !strcmp(argv[4], "b1");      // single-pass backward section only
+  if (getenv("FOCR_UB_MASKV")) g_tune[FOCR_TUNE_ATTN_FWD_MASK] = atoi(getenv("FOCR_UB_MASKV"));
+  if (argc > 4 && !strcmp(argv[4], "fm")) {
+    // round 5: keep-word schedule of the 256-query forward (tuning key 4): kernel alone on pre-drawn bits, packed
+    // 1536-byte-pitch operands as in the step, interleaved A B A B A B, outputs must be bit-identical; p = 0 for reference
+    float* qkv = dalloc(3 * n, 7, 1.5f);
+    const int ldp = 3 * D;
+    CK(focr_attention_dropout_mask(mask, B, H, N, 0.1f, 1234, 0) ? hipErrorUnknown : hipSuccess);
+    g_tune[FOCR_TUNE_ATTN_FWD_VARIANT] = 1;
+    float tv[2] = {1e9f, 1e9f}, tp0 = 1e9f;
+    for (int rep = 0; rep < 3; ++rep) {
+      for (int mv = 0; mv < 2; ++mv) {
+        g_tune[FOCR_TUNE_ATTN_FWD_MASK] = mv;
+        float* o = mv ? o1 : o0; float* ls = mv ? lse1 : lse0;
+        int rc = focr_attention_fwd_premasked(qkv, qkv + D, qkv + 2 * D, o, ls, mask, B, H, N, ldp, D, scale, 0.1f, 0);
+        if (rc) { printf("premasked forward failed %d\n", rc); return 1; }
+        tv[mv] = std::min(tv[mv], timeit([&]() { focr_attention_fwd_premasked(qkv, qkv + D, qkv + 2 * D, o, ls, mask, B, H, N, ldp, D, scale, 0.1f, 0); }, 8));
+      }
+      tp0 = std::min(tp0, timeit([&]() { focr_attention_fwd(qkv, qkv + D, qkv + 2 * D, dq0, work, mask, B, H, N, ldp, D, scale, 0.f, 1234, 0); }, 8));
+    }
+    CK(hipDeviceSynchronize());
+    double mx, e = maxdiff(o0, o1, n, &mx), mx2, e2 = maxdiff(lse0, lse1, (long)B * H * N, &mx2);
+    printf("fwd keep-word schedule (packed operands, premasked, p = 0.1): MV0 %7.1f us  MV1 %7.1f us  | p = 0: %7.1f us | max|dO| %.2e of %.2e, max|dLSE| %.2e\n",
+           tv[0], tv[1], tp0, e, mx, e2);
+    return 0;
+  }
   for (float p : {0.1f, 0.0f}) {
     float t0 = 1e9f, t1 = 1e9f;
     if (only_b1) {
