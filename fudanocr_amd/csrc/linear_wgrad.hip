@@ -13,6 +13,7 @@
 //   * the bias gradient falls out of the A fragments (fp32 adds of the raw values);
 //   * every row split writes its 128 x 128 tile to its own slot with plain stores; slot_reduce_kernel folds the slots
 //     in a fixed order (deterministic, no atomics) straight into the gradient buffer.
+#include <stdlib.h>
 #include "focr_common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 lw_bf16x8;
@@ -54,6 +55,11 @@ __device__ __forceinline__ void lw_split(const lw_f32x2 (&v)[8], int t, lw_bf16x
 }
 
 // grid (K / 128, Cout / 128, splits), 256 threads.  PART: [splits][Cout * K + Cout] floats.
+// HALF (round 5): Cout = 64 (the FeatureEnhancer's 128 -> 64 projection, which ran on the generic kernel at 47 us): a dY row
+// is 256 bytes, so the two lane quarters of a DMA piece fetch the same 64 columns (the LDS image keeps the 512-byte row
+// slots, columns 64.. are never read), all four waves read dY columns 0..63, and the wave pair (wi = 0 / 1) of a K half
+// takes the even / odd 16-row stages; the pair's tiles are added through LDS after the loop (fixed order: even + odd).
+template <bool HALF>
 __global__ __launch_bounds__(256, 2) void linear_wgrad_stream_kernel(const float* __restrict__ X,
                                                                      const float* __restrict__ dY,
                                                                      float* __restrict__ PART, int M, int ldx, int ldd,
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_stream_kernel(const float
   for (int i = 0; i < 4; ++i) {
     const int P = wave + 4 * i, mat = P >> 3, q = P & 7;
     const int ld = mat ? ldx : ldd;
-    gp[i] = (mat ? X + k0 : dY + co0) + (size_t)(row_beg + 2 * q + lh) * ld + 4 * li;
+    gp[i] = (mat ? X + k0 : dY + co0) + (size_t)(row_beg + 2 * q + lh) * ld + 4 * ((HALF && !mat) ? (li & 15) : li);
     gstep[i] = (size_t)LW_ROWS * ld;
     ldso[i] = mat * LW_MAT + q * LW_PIECE;
   }
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_stream_kernel(const float
   const bool do_bias = want_bias && blockIdx.x == 0 && wj == 0;
 
   // fragment read addresses inside a stage: rows 8 lh + j, columns 64 w + 2 li (+ t)
-  const unsigned aoff = lbase + (4 * lh) * LW_PIECE + (64 * wi + 2 * li) * 4;
+  const unsigned aoff = lbase + (4 * lh) * LW_PIECE + ((HALF ? 0 : 64 * wi) + 2 * li) * 4;
   const unsigned boff = lbase + LW_MAT + (4 * lh) * LW_PIECE + (64 * wj + 2 * li) * 4;
 
 #pragma unroll
@@ -115,6 +121,7 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_stream_kernel(const float
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();       // every wave's pieces of stage c are in LDS; stage c - 1 is free again
     if (c + LW_NS - 1 < nchunks) issue(c + LW_NS - 1);
+    if (HALF && (c & 1) != wi) continue;                      // (wave-uniform) the partner wave takes this stage
     const unsigned st = (unsigned)(c % LW_NS) * LW_STAGE;
     LwRaw raw;
     lw_read(raw, aoff + st, boff + st);
@@ -141,13 +148,38 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_stream_kernel(const float
         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
       }
   }
+  if (HALF) {
+    // odd-stage tiles (wi = 1) -> LDS -> added to the even-stage tiles (wi = 0): the stage buffers are idle now
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lw_smem) + wj * (4 * 16 + 2) * 64 + lane;
+    if (wi == 1) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((a * 2 + b) * 16 + r) * 64] = acc[a][b][r];
+      red[64 * 64] = bsum[0];
+      red[65 * 64] = bsum[1];
+    }
+    __syncthreads();
+    if (wi == 1) return;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] += red[((a * 2 + b) * 16 + r) * 64];
+    bsum[0] += red[64 * 64];
+    bsum[1] += red[65 * 64];
+  }
   // tile (a, b): row i of the MFMA is co = co0 + 64 wi + 2 i + a, column n is k = k0 + 64 wj + 2 n + b
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int co = co0 + 64 * wi + 2 * i + a;
+      const int co = co0 + (HALF ? 0 : 64 * wi) + 2 * i + a;
       float2 v = make_float2(acc[a][0][r], acc[a][1][r]);
       *reinterpret_cast<float2*>(slot + (size_t)co * K + k0 + 64 * wj + 2 * li) = v;
     }
@@ -155,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_stream_kernel(const float
     bsum[0] += __shfl_xor(bsum[0], 32);
     bsum[1] += __shfl_xor(bsum[1], 32);
     if (lh == 0)
-      *reinterpret_cast<float2*>(slot + (size_t)Cout * K + co0 + 64 * wi + 2 * li) = make_float2(bsum[0], bsum[1]);
+      *reinterpret_cast<float2*>(slot + (size_t)Cout * K + co0 + (HALF ? 0 : 64 * wi) + 2 * li) = make_float2(bsum[0], bsum[1]);
   }
 }
 
@@ -203,7 +235,7 @@ __global__ __launch_bounds__(256) void slot_reduce_kernel(const float* __restric
 #define LW_BLOCKS 512
 #endif
 static void lw_splits(long M, int K, int Cout, int& sp, int& rows) {
-  const int tiles = (K / 128) * (Cout / 128);
+  const int tiles = (K / 128) * (Cout >= 128 ? Cout / 128 : 1);
   sp = LW_BLOCKS / tiles;
   if (sp < 1) sp = 1;
   rows = (int)(((M + sp - 1) / sp + LW_ROWS - 1) / LW_ROWS) * LW_ROWS;
@@ -211,7 +243,9 @@ static void lw_splits(long M, int K, int Cout, int& sp, int& rows) {
   sp = (int)((M + rows - 1) / rows);
 }
 int focr_linear_wgrad_eligible(long M, int K, int Cout, int ldx, int ldd) {
-  return M >= 1024 && M % LW_ROWS == 0 && K % 128 == 0 && Cout % 128 == 0 && ldx % 4 == 0 && ldd % 4 == 0 &&
+  static const bool half_ok = !(getenv("FOCR_LW_HALF") && getenv("FOCR_LW_HALF")[0] == '0');      // A/B: 128 -> 64 on the generic kernel
+  if (Cout == 64 && !half_ok) return 0;
+  return M >= 1024 && M % LW_ROWS == 0 && K % 128 == 0 && (Cout % 128 == 0 || Cout == 64) && ldx % 4 == 0 && ldd % 4 == 0 &&
          (long)K * Cout <= 128 * 384;
 }
 long focr_linear_wgrad_ws_floats(long M, int K, int Cout) {
@@ -229,13 +263,19 @@ int focr_linear_wgrad(const float* x, const float* dy, float* dw, float* dbias, 
   if (!ws || ws_floats < (long)sp * slot) return 1;
   static focr_dev_flags attr_done;
   if (focr_dev_first(attr_done)) {
-    if (hipFuncSetAttribute((const void*)linear_wgrad_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LW_LDS) !=
-        hipSuccess)
+    if (hipFuncSetAttribute((const void*)linear_wgrad_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            LW_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)linear_wgrad_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            LW_LDS) != hipSuccess)
       return 1;                                        // caller falls back to the generic weight-gradient kernel
     focr_dev_mark(attr_done);
   }
-  hipLaunchKernelGGL(linear_wgrad_stream_kernel, dim3(K / 128, Cout / 128, sp), 256, LW_LDS, stream, x, dy, ws, (int)M,
-                     ldx, ldd, K, Cout, rows, dbias ? 1 : 0);
+  if (Cout == 64)
+    hipLaunchKernelGGL(linear_wgrad_stream_kernel<true>, dim3(K / 128, 1, sp), 256, LW_LDS, stream, x, dy, ws, (int)M, ldx,
+                       ldd, K, Cout, rows, dbias ? 1 : 0);
+  else
+    hipLaunchKernelGGL(linear_wgrad_stream_kernel<false>, dim3(K / 128, Cout / 128, sp), 256, LW_LDS, stream, x, dy, ws,
+                       (int)M, ldx, ldd, K, Cout, rows, dbias ? 1 : 0);
   const long n_dw4 = (long)Cout * K / 4, n_all4 = n_dw4 + (dbias ? Cout / 4 : 0);
   hipLaunchKernelGGL(slot_reduce_kernel, dim3((int)((n_all4 + 7) / 8)), 256, 0, stream, (const float*)ws, dw, dbias,
                      n_dw4, n_all4, slot, sp, accumulate);

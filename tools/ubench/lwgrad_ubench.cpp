@@ -52,7 +52,9 @@ struct Shape { const char* name; long M; int K, Cout, ldx, ldd; };
 int main() {
   const Shape shapes[] = {{"proj 128->128", 131072, 128, 128, 128, 128}, {"qkv 128->384", 131072, 128, 384, 128, 384},
                           {"b64 128->128", 65536, 128, 128, 128, 128},   {"small rows", 4096, 128, 128, 128, 128},
-                          {"ragged rows", 131072 - 48, 128, 128, 128, 128}, {"strided", 32768, 128, 128, 256, 384}};
+                          {"ragged rows", 131072 - 48, 128, 128, 128, 128}, {"strided", 32768, 128, 128, 256, 384},
+                          {"out 128->64", 131072, 128, 64, 128, 64},     {"out 128->64 b64", 65536, 128, 64, 128, 64},
+                          {"out 128->64 ragged", 131072 - 80, 128, 64, 128, 64}, {"out 128->64 small", 2048, 128, 64, 128, 64}};
   for (const Shape& s : shapes) {
     float* X = dalloc(s.M * s.ldx, 11, 1.f);
     float* dY = dalloc(s.M * s.ldd, 23, 0.01f);
