@@ -335,8 +335,7 @@ def main():
     conv_steps = min(2, args.steps)      # the conv / linear launches are event-timed in the last steps only (each event
                                          # pair costs host time: keeps the perturbation of `value` < 0.5 %)
     sync()
-    _lib.start_timing(["focr_attention_fwd", "focr_attention_fwd_premasked", "focr_attention_bwd",
-                       "focr_attention_planes_fwd", "focr_attention_planes_bwd"])
+    _lib.start_timing(["focr_attention_fwd", "focr_attention_fwd_premasked", "focr_attention_bwd"])
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i == args.steps - conv_steps:
@@ -448,9 +447,8 @@ def main():
                             3 if bx3 else 1))
         # (keep bits are drawn ahead of time on the side stream from the second step on: the forward is then the
         # `premasked` entry = the attention kernel alone)
-        fwd = [t for t, _ in kt.get("focr_attention_fwd", []) + kt.get("focr_attention_fwd_premasked", []) +
-               kt.get("focr_attention_planes_fwd", [])]
-        bwd = [t for t, _ in kt.get("focr_attention_bwd", []) + kt.get("focr_attention_planes_bwd", [])]
+        fwd = [t for t, _ in kt.get("focr_attention_fwd", []) + kt.get("focr_attention_fwd_premasked", [])]
+        bwd = [t for t, _ in kt.get("focr_attention_bwd", [])]
         if fwd:
             fa = 4.0 * batch * 4 * 1024 * 1024 * 32
             r = row("attn_fwd2_bx3_kernel (fused QK^T-softmax-dropout-PV; keep bits pre-drawn on the side stream)",

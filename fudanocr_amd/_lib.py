@@ -54,11 +54,7 @@ SIGNATURES = {
     "focr_fe_post_bwd": [P] * 7 + [F] + [P] * 9 + [L, F, P, P, I, P, F, P],
     "focr_fe_qkv_fwd": [P, P, P, P, P, P, L, I, P, F, P],
     "focr_fe_qkv_fwd_bn": [P, P, P, P, P, P, L, I, P, F, P, P, P, P, P],
-    "focr_attention_planes_supported": [I, I, I],
     "focr_attention_keep_scale": [F],
-    "focr_attention_make_planes": [P, P, L, I, F, P],
-    "focr_attention_planes_fwd": [P, P, P, P, P, P, I, I, I, I, I, F, U, I, P],
-    "focr_attention_planes_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, F, P],
     "focr_fe_qkv_dgrad": [P, P, P, P, L, P],
     "focr_fe_wgrads_ws_floats": [L],
     "focr_fe_wgrads": [P] * 31 + [L, L, I, P],

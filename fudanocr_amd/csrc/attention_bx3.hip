@@ -1265,6 +1265,7 @@ int focr_attn_bwd_bx3(const float* q, const float* k, const float* v, const floa
   return 0;
 }
 
+#ifdef FOCR_UBENCH_PLANES          // tools/ubench only (see attention.hip)
 // ---------------------------------------------------------------------------------------------------------------
 // pre-split operand planes: producer for arbitrary fp32 inputs + the launchers of the PL kernel variants
 // ---------------------------------------------------------------------------------------------------------------
@@ -1330,3 +1331,4 @@ int focr_attn_bwd_bx3_planes(const void* qp, const void* kp, const void* vp, con
   }
   return 0;
 }
+#endif

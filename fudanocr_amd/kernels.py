@@ -1104,12 +1104,6 @@ def fe_chain_supported(feat, heads=4, d_model=128):
                 and _lib.load().focr_fe_chain_supported(feat.shape[0] * feat.shape[1], 128))
 
 
-# FOCR_ATTN_PLANES=1: the QKV projection / the backward chain hand the attention kernels PRE-SPLIT operands (bf16 hi / lo,
-# same bytes) and the kernels stage tiles by plain copies (csrc/attention_bx3.hip PL variants).  Standalone the kernels
-# gain (forward 310 -> 292 us, backward 682 -> 636 us on separate arrays, profiles/r03_attention_planes.md); inside the
-# step the forward is bound by the latency of its keep-bit scalar loads, which the longer fp32 staging phase happens to
-# cover: split forward +25 us, backward -12 us per block, step +0.1 ms.  Off by default, kept tested behind the switch.
-_ATTN_PLANES = os.environ.get("FOCR_ATTN_PLANES", "0") == "1"
 # FOCR_C9_WGRAD_BX3=0: weight gradient of the 9x9 output layer on the round-1 fp32-MFMA kernel (A/B switch)
 _C9_WGRAD_BX3 = os.environ.get("FOCR_C9_WGRAD_BX3", "1") != "0"
 _LOG2E = 1.4426950408889634
@@ -1152,25 +1146,15 @@ def _fe_forward(step, feat, xres, pe, heads, p_attn, p_ffn, eps, params, bn=None
     lse = torch.empty((b, heads, t), device=dev)
     mask, ready = step.next_mask(b, heads, t, p_attn, dev) if p_attn > 0 else (None, False)
     scale = 1.0 / math.sqrt(d // heads)
-    if _ATTN_PLANES and _lib.load().focr_attention_planes_supported(heads, t, d):
-        # the projection writes Q * scale * log2(e), K, V ALREADY split to bf16 hi / lo ([3][rows][256]: every 4 columns as
-        # [hi4 | lo4], the bytes of the fp32 tensor): the attention kernels stage them by plain copies (attention_bx3.hip)
-        qkv = torch.empty((rows, 6 * d), device=dev, dtype=torch.bfloat16)       # [rows][Q | K | V], 256 bf16 each
-        _lib.call("focr_fe_qkv_fwd_bn", _p(feat), _p(pe), _p(wqkv), _p(bqkv), _p(tok), _NULL, rows, t, _p(qkv),
-                  scale * _LOG2E, *[_p(v_) for v_ in (bn or (None,) * 4)], _stream())
-        pq, pk, pv = (ctypes.c_void_p(qkv.data_ptr() + i * 2 * d * 2) for i in range(3))
-        _lib.call("focr_attention_planes_fwd", pq, pk, pv, _p(o), _p(lse), _p(mask), b, heads, t, 6 * d, d,
-                  float(p_attn), _new_seed() if (p_attn > 0 and not ready) else 0, int(ready), _stream())
+    qkv = torch.empty((b, t, 3 * d), device=dev)
+    _lib.call("focr_fe_qkv_fwd_bn", _p(feat), _p(pe), _p(wqkv), _p(bqkv), _p(tok), _p(qkv), rows, t, _NULL, 1.0,
+              *[_p(v_) for v_ in (bn or (None,) * 4)], _stream())
+    if ready:
+        _lib.call("focr_attention_fwd_premasked", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _p(o), _p(lse),
+                  _p(mask), b, heads, t, 3 * d, d, scale, float(p_attn), _stream())
     else:
-        qkv = torch.empty((b, t, 3 * d), device=dev)
-        _lib.call("focr_fe_qkv_fwd_bn", _p(feat), _p(pe), _p(wqkv), _p(bqkv), _p(tok), _p(qkv), rows, t, _NULL, 1.0,
-                  *[_p(v_) for v_ in (bn or (None,) * 4)], _stream())
-        if ready:
-            _lib.call("focr_attention_fwd_premasked", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _p(o), _p(lse),
-                      _p(mask), b, heads, t, 3 * d, d, scale, float(p_attn), _stream())
-        else:
-            _lib.call("focr_attention_fwd", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _p(o), _p(lse), _p(mask), b,
-                      heads, t, 3 * d, d, scale, float(p_attn), _new_seed() if p_attn > 0 else 0, _stream())
+        _lib.call("focr_attention_fwd", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _p(o), _p(lse), _p(mask), b,
+                  heads, t, 3 * d, d, scale, float(p_attn), _new_seed() if p_attn > 0 else 0, _stream())
     xhat1, xhat2, h = torch.empty_like(tok), torch.empty_like(tok), torch.empty_like(tok)
     rinv1, rinv2 = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
     out = torch.empty((b, t, cf), device=dev)
@@ -1198,19 +1182,10 @@ def _fe_backward(step, saved, cfg, params, targets, d_out, need_dfeat, need_para
     dev = d_out.device
     d_s2, d_hpre, d_s1 = (torch.empty_like(tok) for _ in range(3))
     work = torch.empty((b, heads, t), device=dev)
-    planes = qkv.dtype == torch.bfloat16          # the forward ran on pre-split planes: so does the backward
-    if planes:
-        # the chain kernel hands the attention backward dO / P(keep) as bf16 hi / lo planes (no fp32 d_ctx at all)
-        d_ctx = torch.empty((2, rows, d), device=dev, dtype=torch.bfloat16)
-        ik = _lib.load().focr_attention_keep_scale(float(p_attn))
-        _lib.call("focr_fe_post_bwd", _p(d_out), _p(wl), _p(xhat2), _p(rinv2), _p(a3), _p(w2), _p(h), keep_scale,
-                  _p(w1), _p(xhat1), _p(rinv1), _p(a1), _p(wo), _p(d_s2), _p(d_hpre), _p(d_s1), _NULL, rows, eps,
-                  _p(o), _p(work), t, _p(d_ctx), float(ik), _stream())
-    else:
-        d_ctx = torch.empty_like(tok)
-        _lib.call("focr_fe_post_bwd", _p(d_out), _p(wl), _p(xhat2), _p(rinv2), _p(a3), _p(w2), _p(h), keep_scale,
-                  _p(w1), _p(xhat1), _p(rinv1), _p(a1), _p(wo), _p(d_s2), _p(d_hpre), _p(d_s1), _p(d_ctx), rows, eps,
-                  _p(o), _p(work), t, _NULL, 1.0, _stream())
+    d_ctx = torch.empty_like(tok)
+    _lib.call("focr_fe_post_bwd", _p(d_out), _p(wl), _p(xhat2), _p(rinv2), _p(a3), _p(w2), _p(h), keep_scale,
+              _p(w1), _p(xhat1), _p(rinv1), _p(a1), _p(wo), _p(d_s2), _p(d_hpre), _p(d_s1), _p(d_ctx), rows, eps,
+              _p(o), _p(work), t, _NULL, 1.0, _stream())
     grads = [None] * len(FE_PARAM_NAMES)
     side, g, nws = None, None, 0
     if need_params:
@@ -1246,14 +1221,9 @@ def _fe_backward(step, saved, cfg, params, targets, d_out, need_dfeat, need_para
         step.park_tail(lambda: wgrads(1, (d_out, xhat2, d_s2, h, d_hpre, xhat1, d_s1, o)))
     dqkv = torch.empty((b, t, 3 * d), device=dev)
     # `work` already holds D = rowsum(d_ctx * o) per (b, head, token), written by the chain kernel above
-    if planes:
-        pq, pk, pv = (ctypes.c_void_p(qkv.data_ptr() + i * 2 * d * 2) for i in range(3))
-        _lib.call("focr_attention_planes_bwd", pq, pk, pv, _p(d_ctx), _p(lse), _p(work), _p(mask), _po(dqkv, 0),
-                  _po(dqkv, d), _po(dqkv, 2 * d), b, heads, t, 6 * d, 2 * d, 3 * d, scale, p_attn, _stream())
-    else:
-        _lib.call("focr_attention_bwd", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _NULL, _p(d_ctx), _p(lse), _p(mask),
-                  _po(dqkv, 0), _po(dqkv, d), _po(dqkv, 2 * d), _p(work), b, heads, t, 3 * d, d, scale, p_attn,
-                  _stream())
+    _lib.call("focr_attention_bwd", _po(qkv, 0), _po(qkv, d), _po(qkv, 2 * d), _NULL, _p(d_ctx), _p(lse), _p(mask),
+              _po(dqkv, 0), _po(dqkv, d), _po(dqkv, 2 * d), _p(work), b, heads, t, 3 * d, d, scale, p_attn,
+              _stream())
     d_feat = None
     if need_dfeat:
         d_feat = torch.empty((b, t, 64), device=dev)

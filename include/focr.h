@@ -163,24 +163,8 @@ int focr_attention_fwd_premasked(const float* q, const float* k, const float* v,
                                  const uint32_t* mask, int B, int H, int Ntok, int ld, int ldo, float scale,
                                  float p_drop, focr_stream_t stream);
 /* dwork: B*H*Ntok floats */
-/* ---- attention on pre-split operands (csrc/attention_bx3.hip PL variants): the split form of a [rows][128] fp32 tensor
- * is [rows][256] bf16 in which every group of four columns is stored as [hi x 4 | lo x 4] (x = hi + lo; the bytes of
- * the fp32 row, so producers and consumers move 16 bytes per lane exactly as with fp32).  Q planes hold Q * scale * log2(e),
- * dO planes dO * focr_attention_keep_scale(p_drop); the kernels then stage their tiles by plain copies -- the fp32 ->
- * bf16 split is done once by the producer (focr_fe_qkv_fwd / focr_fe_post_bwd, or focr_attention_make_planes for any
- * fp32 tensor) instead of by every consumer block.  4 heads of 32, Ntok % 256 == 0, precision mode != 0.
- * ldp / ldop: row pitch (bf16 elements) of the split Q | K | V rows / of the split dO rows: 256 for separate tensors,
- * 768 for the packed [rows][Q | K | V] form focr_fe_qkv_fwd writes.
- * focr_attention_planes_bwd: dwork = D = rowsum(dO * O) from the UNSCALED dO; dq / dk / dv fp32 with row pitch ldg. */
-int focr_attention_planes_supported(int H, int Ntok, int d_model);
+/* 1 / P(keep) of the attention dropout (P(keep) = 1 - p_drop quantised to 1/4096); 1 when p_drop rounds to "no dropout" */
 float focr_attention_keep_scale(float p_drop);
-int focr_attention_make_planes(const float* x, void* planes, long rows, int ld, float mul, focr_stream_t stream);
-int focr_attention_planes_fwd(const void* qp, const void* kp, const void* vp, float* o, float* lse, uint32_t* mask,
-                              int B, int H, int Ntok, int ldp, int ldo, float p_drop, uint64_t seed, int mask_ready,
-                              focr_stream_t stream);
-int focr_attention_planes_bwd(const void* qp, const void* kp, const void* vp, const void* dop, const float* lse,
-                              const float* dwork, const uint32_t* mask, float* dq, float* dk, float* dv, int B, int H,
-                              int Ntok, int ldp, int ldop, int ldg, float scale, float p_drop, focr_stream_t stream);
 /* o == NULL: dwork already holds D = rowsum(d_o * o) per (b, head, token) (see focr_fe_post_bwd) */
 int focr_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o,
                        const float* lse, const uint32_t* mask, float* dq, float* dk, float* dv,
@@ -255,9 +239,11 @@ int focr_slice_cols(const float* x, const float* add, float* out, long rows, int
  *                      With dwork != NULL it also writes D[b][head][token] = sum_d d_ctx * ctx (ntok tokens per image),
  *                      the row term of the attention backward: focr_attention_bwd is then called with o = NULL.
  *   focr_fe_qkv_fwd  : tok = [feat | pe[row % ntok]] (tbsrn.py:83-86) and the packed q | k | v projection in one kernel.
- *                      planes != NULL: Q * q_mul, K, V are (also, or with qkv = NULL: only) written pre-split as
- *                      [3 tensors][rows][256] bf16 for focr_attention_planes_* (layout there); focr_fe_post_bwd's
- *                      d_ctx_planes likewise receives d_ctx * planes_mul as [rows][256] (d_ctx itself may then be NULL).
+ *                      planes != NULL (optional; NULL in the product): Q * q_mul, K, V are (also, or with qkv = NULL:
+ *                      only) written pre-split: [rows][3 x 256] bf16, every four columns of a [rows][128] fp32 tensor as
+ *                      [hi x 4 | lo x 4] (x = hi + lo, hi = bf16(x): the bytes of the fp32 row) -- the operand form of
+ *                      the PL attention kernels, an experiment kept in tools/ubench; focr_fe_post_bwd's d_ctx_planes
+ *                      likewise receives d_ctx * planes_mul as [rows][256] (d_ctx itself may then be NULL).
  *   focr_fe_qkv_dgrad: d_feat[rows,64] = dqkv[rows,384] Wqkv[:, 0:64] + d_s1[:, 0:64] (the positional-encoding half of
  *                      the token, tbsrn.py:83-86, has no gradient consumer).
  *   focr_fe_wgrads   : every parameter gradient of these layers in one call (targets are overwritten); the LayerNorm

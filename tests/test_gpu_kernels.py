@@ -1193,17 +1193,13 @@ def _fe_reference(feat, xres, pe, P, heads=4, eps=1e-6):
     return out + xres if xres is not None else out
 
 
-@pytest.mark.parametrize("planes", [False, True], ids=["fp32-qkv", "split-qkv"])
 @pytest.mark.parametrize("b,with_res", [(2, True), (1, False)])
-def test_feature_enhancer_fused_chain(b, with_res, planes, precision, monkeypatch):
+def test_feature_enhancer_fused_chain(b, with_res, precision):
     """csrc/fe_chain.hip through kernels.feature_enhancer_fused: output, input gradients and ALL 14 parameter gradients
-    (incl. the LayerNorm a_2 / b_2 gradients that come out of the weight-gradient GEMMs on xhat) vs float64.
-    split-qkv: the projection / backward chain hand the attention kernels pre-split bf16 hi / lo operands
-    (focr_attention_planes_*, the PL kernel variants) instead of fp32 -- same tolerances."""
+    (incl. the LayerNorm a_2 / b_2 gradients that come out of the weight-gradient GEMMs on xhat) vs float64."""
     k = K()
     if precision == 0:
         pytest.skip("the fused chains are bf16x3 kernels; mode 0 keeps the per-layer fp32 path")
-    monkeypatch.setattr(k, "_ATTN_PLANES", bool(planes))
     t = 1024
     feat = rnd(b, t, 64, seed=1)
     xres = rnd(b, t, 64, seed=2) if with_res else None
@@ -1270,71 +1266,27 @@ def test_feature_enhancer_fused_dropout_statistics():
     assert torch.allclose(h1[kept], h0[kept] * ks, rtol=1e-5, atol=1e-6)
 
 
-def test_attention_planes_c_abi(precision):
-    """focr_attention_make_planes + focr_attention_planes_fwd / _bwd.  (1) Oracle leg: against a float64 reference that uses
-    the very keep bits the forward wrote (forward and all three gradients).  (2) Against the fp32-input TWO-PASS entry
-    points on the same keep bits (tuning key 3 = 1): forward and dQ identical (the split is the same arithmetic), dK / dV
-    equal up to where the dropout scale is applied (bf16-level in modes 2 / 3)."""
+def test_qkv_projection_split_output_is_the_split_of_the_fp32_output(precision):
+    """focr_fe_qkv_fwd's optional `planes` output (include/focr.h; NULL in the product, the operand form of the PL
+    attention experiment in tools/ubench): [rows][3 x 256] bf16 holding, for every four columns of Q * q_mul | K | V,
+    [hi x 4 | lo x 4] with hi = bf16(x), lo = bf16(x - hi) -- bit for bit the split of the fp32 output of the same call."""
     import ctypes
     from fudanocr_amd import _lib
     if precision == 0:
-        pytest.skip("the PL kernel variants are bf16x3 kernels")
-    lib = _lib.load()
-    _lib.call("focr_set_tuning", 3, 1)
-    try:
-        _attention_planes_body(precision, lib, _lib, ctypes)
-    finally:
-        _lib.call("focr_set_tuning", 3, 2)
-
-
-def _attention_planes_body(precision, lib, _lib, ctypes):
-    b, h, t, d = 2, 4, 1024, 128
-    rows = b * t
-    assert lib.focr_attention_planes_supported(h, t, d) == 1 and lib.focr_attention_planes_supported(h, 1000, d) == 0
-    q, kk, v, do = (dev(rnd(b, t, d, seed=i, scale=s_)) for i, s_ in ((1, 2.0), (2, 2.0), (3, 1.0), (4, 1.0)))
+        pytest.skip("the fused chains are bf16x3 kernels")
+    rows, t, d = 2048, 1024, 128
+    feat, pe = dev(rnd(rows, 64, seed=1)), dev(rnd(t, 64, seed=2))
+    w, bq = dev(rnd(384, 128, seed=3, scale=0.09)), dev(rnd(384, seed=4, scale=0.1))
+    tok, qkv = torch.empty(rows, d, device="cuda"), torch.empty(rows, 3 * d, device="cuda")
+    planes = torch.empty(rows, 6 * d, device="cuda", dtype=torch.bfloat16)
     P_ = lambda x: ctypes.c_void_p(x.data_ptr())
-    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    scale, p = 1.0 / math.sqrt(32), 0.1
-    o0, o1 = torch.empty_like(q), torch.empty_like(q)
-    lse0, lse1 = torch.empty(b, h, t, device="cuda"), torch.empty(b, h, t, device="cuda")
-    mask = torch.empty((b, h, t // 32, t // 32, 32), device="cuda", dtype=torch.int32)
-    _lib.call("focr_attention_fwd", P_(q), P_(kk), P_(v), P_(o0), P_(lse0), P_(mask), b, h, t, d, d, scale, p, 77, st)
-    planes = [torch.empty((rows, 2 * d), device="cuda", dtype=torch.bfloat16) for _ in range(4)]
-    ik = lib.focr_attention_keep_scale(p)
-    assert abs(ik - 1.0 / (1.0 - round(p * 4096) / 4096.0)) < 1e-6
-    for x, pl, mul in ((q, planes[0], scale * 1.4426950408889634), (kk, planes[1], 1.0), (v, planes[2], 1.0), (do, planes[3], ik)):
-        _lib.call("focr_attention_make_planes", P_(x), P_(pl), rows, d, float(mul), st)
-    _lib.call("focr_attention_planes_fwd", P_(planes[0]), P_(planes[1]), P_(planes[2]), P_(o1), P_(lse1), P_(mask), b, h, t,
-              2 * d, d, p, 0, 1, st)
+    qmul = 0.25
+    _lib.call("focr_fe_qkv_fwd", P_(feat), P_(pe), P_(w), P_(bq), P_(tok), P_(qkv), rows, t, P_(planes), qmul,
+              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
-    close(o1, o0, 1e-6, "planes forward o")
-    close(lse1, lse0, 1e-6, "planes forward lse")
-    work = torch.empty(b, h, t, device="cuda")
-    g0 = [torch.empty_like(q) for _ in range(3)]
-    g1 = [torch.empty_like(q) for _ in range(3)]
-    _lib.call("focr_attention_bwd", P_(q), P_(kk), P_(v), P_(o0), P_(do), P_(lse0), P_(mask), P_(g0[0]), P_(g0[1]), P_(g0[2]),
-              P_(work), b, h, t, d, d, scale, p, st)
-    _lib.call("focr_attention_planes_bwd", P_(planes[0]), P_(planes[1]), P_(planes[2]), P_(planes[3]), P_(lse0), P_(work),
-              P_(mask), P_(g1[0]), P_(g1[1]), P_(g1[2]), b, h, t, 2 * d, 2 * d, d, scale, p, st)
-    torch.cuda.synchronize()
-    close(g1[0], g0[0], 1e-6, "planes dq")
-    close(g1[1], g0[1], gtol(precision), "planes dk")
-    close(g1[2], g0[2], 5e-3 if precision >= 2 else 1e-4, "planes dv")
-    # oracle leg: float64 attention with the keep bits the forward wrote
-    ng = t // 32
-    w = mask.cpu().to(torch.int64) & 0xFFFFFFFF
-    slot = torch.arange(32)
-    key_of_slot = ((slot >> 1) & 3) + 8 * (slot >> 3) + 4 * (slot & 1)
-    bits = (w.unsqueeze(-1) >> torch.arange(32)) & 1
-    dense = torch.zeros(b, h, ng, ng, 32, 32, dtype=torch.int64)
-    dense[:, :, :, :, key_of_slot, :] = bits
-    keep = dense.permute(0, 1, 2, 5, 3, 4).reshape(b, h, t, t).double()
-    q64, k64, v64 = (z.detach().cpu().double().requires_grad_(True) for z in (q, kk, v))
-    heads = lambda z: z.view(b, t, h, 32).transpose(1, 2)
-    pr = torch.softmax(heads(q64) @ heads(k64).transpose(-1, -2) / math.sqrt(32), -1) * keep * ik
-    oref = (pr @ heads(v64)).transpose(1, 2).reshape(b, t, d)
-    oref.backward(do.cpu().double())
-    close(o1, oref, ptol(precision), "planes forward vs fp64")
-    close(g1[0], q64.grad, gtol(precision), "planes dq vs fp64")
-    close(g1[1], k64.grad, gtol(precision), "planes dk vs fp64")
-    close(g1[2], v64.grad, gtol(precision), "planes dv vs fp64")
+    x = qkv.clone()
+    x[:, :d] *= qmul
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    want = torch.stack([hi.view(rows, 96, 4), lo.view(rows, 96, 4)], 2).reshape(rows, 6 * d)
+    assert torch.equal(planes.view(torch.int16), want.view(torch.int16))

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <algorithm>
 #define FOCR_UBENCH_BWD1W 1
+#define FOCR_UBENCH_PLANES 1
 #include "../../fudanocr_amd/csrc/attention.hip"
 #include "../../fudanocr_amd/csrc/attention_bx3.hip"
 
