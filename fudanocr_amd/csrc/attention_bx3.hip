@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __re
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
-  float mrun[2] = {-1e30f, -1e30f}, l[2] = {0.f, 0.f};
+  float mrun[2] = {MV == 2 ? 0.f : -1e30f, MV == 2 ? 0.f : -1e30f}, l[2] = {0.f, 0.f};
   const uint32_t thr = DROPOUT ? attn_drop_thr16(p_drop) : 0u;
   const float inv_keep = DROPOUT ? 1.f / (1.f - (float)thr / 65536.f) : 1.f;
   const int NG = Ntok / 32;
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __re
       // their latency is covered
       uint64_t mk[2][16];
       bf16x8 ah[2], al[2];
-      if (MV == 1) {
+      if (MV >= 1) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
           ah[m] = *reinterpret_cast<const bf16x8*>(&Kh[(sub * 32 + li) * RP + 16 * m + 8 * lh]);
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __re
         for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        if (MV != 1) {
+        if (MV < 1) {
           ah[m] = *reinterpret_cast<const bf16x8*>(&Kh[(sub * 32 + li) * RP + 16 * m + 8 * lh]);
           al[m] = *reinterpret_cast<const bf16x8*>(&Kl[(sub * 32 + li) * RP + 16 * m + 8 * lh]);
         }
@@ -371,6 +371,40 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __re
 #ifndef ATTN_ABL_SOFTMAX
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
+        float ls = 0.f;
+        if (MV == 2) {
+          // Scores RELATIVE to the running reference first (the subtraction the exponent needs anyway): the max tree then
+          // works on arithmetic results (no NaN-quieting v_max x, x in front of it) and every lane tests ITS OWN key half
+          // against the threshold -- the ballot spans both halves of every query, so the wave takes the rescale branch
+          // exactly when some query's full max exceeds it, and the cross-half exchange is only needed INSIDE that branch.
+          // The first key group of a block always takes the branch (the reference starts at 0 and becomes the true max).
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[t][r] -= mrun[t];
+          float mx = s[t][0];
+#pragma unroll
+          for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
+          const bool first = kt == 0 && sub == 0;
+          if (first || __builtin_amdgcn_ballot_w64(mx > ATTN_RESCALE_THR) != 0ull) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            const float delta = first ? mx : fmaxf(mx, 0.f);
+            const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);       // (O and l are still zero on `first`)
+            mrun[t] += delta;
+            l[t] *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[t][r] -= delta;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(s[t][r]);
+            ls += p;
+            s[t][r] = p;
+          }
+          l[t] += ls;
+          continue;
+        }
         float mx = s[t][0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
@@ -395,7 +429,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __re
           for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
         }
         const float mn = mrun[t];
-        float ls = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
 #ifdef ATTN_ABL_EXP
@@ -406,13 +439,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_bx3_kernel(const float* __re
           ls += p;
           s[t][r] = p;
         }
-        if (DROPOUT && MV != 1) {
+        if (DROPOUT && MV < 1) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) s[t][r] = keep_lanes(s[t][r], mk[t][r]);   // 1/(1-p) at the end
         }
         l[t] += ls;
       }
-      if (DROPOUT && MV == 1) {
+      if (DROPOUT && MV >= 1) {
         // both tiles' max / exp2 / row sums first (no mask needed), THEN the selects: the scalar requests have had the
         // score MFMAs and ~230 VALU instructions to arrive
         __builtin_amdgcn_sched_barrier(0);
@@ -1165,11 +1198,18 @@ int focr_attn_fwd_bx3(const float* q, const float* k, const float* v, float* o, 
   }
   if (focr_get_tuning(FOCR_TUNE_ATTN_FWD_VARIANT) == 1 && Ntok % 256 == 0) {
     dim3 grid2(B * H * (Ntok / 256));
-    if (p_drop > 0.f && focr_get_tuning(FOCR_TUNE_ATTN_FWD_MASK) == 1)
+    const int mv = focr_get_tuning(FOCR_TUNE_ATTN_FWD_MASK);
+    if (p_drop > 0.f && mv == 2)
+      hipLaunchKernelGGL((attn_fwd2_bx3_kernel<true, false, 2>), grid2, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ld, ldo,
+                         scale, p_drop, seed, H, 0L);
+    else if (p_drop > 0.f && mv == 1)
       hipLaunchKernelGGL((attn_fwd2_bx3_kernel<true, false, 1>), grid2, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ld, ldo,
                          scale, p_drop, seed, H, 0L);
     else if (p_drop > 0.f)
       hipLaunchKernelGGL((attn_fwd2_bx3_kernel<true, false>), grid2, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ld, ldo,
+                         scale, p_drop, seed, H, 0L);
+    else if (mv == 2)
+      hipLaunchKernelGGL((attn_fwd2_bx3_kernel<false, false, 2>), grid2, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ld, ldo,
                          scale, p_drop, seed, H, 0L);
     else
       hipLaunchKernelGGL((attn_fwd2_bx3_kernel<false, false>), grid2, 256, 0, stream, q, k, v, o, lse, mask, Ntok, ld, ldo,

@@ -909,6 +909,30 @@ __device__ __forceinline__ void lp_store4(__bf16* p, unsigned long long v) {
 #endif
 }
 
+// -DLP_TRACE (variant library `python __graft_entry__.py --variant lptrace LP_TRACE`, tools/dev/lstm_phases.py): thread 0 of
+// every block stamps the 100 MHz wall clock at the phase boundaries of every time step of the FORWARD scan --
+//   0 step begins (gx requested) | 1 partners' step counter seen, L1 invalidated, block released | 2 h_{t-1} rows arrived
+//   (an extra vmcnt(0) in this build) | 3 24 MFMAs done | 4 K halves folded through LDS | 5 gates, c, h computed, payload
+//   staged | 6 payload stores issued | 7 release increment done (lp_arrive returned); fp32 outputs follow
+// -- into a device array the tool reads back; XCC_ID of the block in slot 7 of step 0's row... see focr_lstm_trace_dump.
+#ifdef LP_TRACE
+#define LP_TRACE_STEPS 32
+__device__ unsigned long long lp_trace_buf[256 * LP_TRACE_STEPS * 8];
+__device__ unsigned lp_trace_xcc[256];
+#define LP_STAMP(k)                                                                                              \
+  do {                                                                                                           \
+    if (threadIdx.x == 0 && step < LP_TRACE_STEPS && blockIdx.x < 256)                                           \
+      lp_trace_buf[((size_t)blockIdx.x * LP_TRACE_STEPS + step) * 8 + (k)] = wall_clock64();                     \
+  } while (0)
+extern "C" int focr_lstm_trace_dump(unsigned long long* host_stamps, unsigned* host_xcc) {
+  if (hipMemcpyFromSymbol(host_stamps, HIP_SYMBOL(lp_trace_buf), sizeof(lp_trace_buf)) != hipSuccess) return FOCR_EHIP;
+  if (hipMemcpyFromSymbol(host_xcc, HIP_SYMBOL(lp_trace_xcc), sizeof(lp_trace_xcc)) != hipSuccess) return FOCR_EHIP;
+  return FOCR_OK;
+}
+#else
+#define LP_STAMP(k)
+#endif
+
 __global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
     const float* __restrict__ gx, const __bf16* __restrict__ whh2, const float* __restrict__ bhh,
     float* __restrict__ hseq, __bf16* __restrict__ hseq2, float* __restrict__ gates, float* __restrict__ cseq,
@@ -940,10 +964,14 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
   const float4 bias = make_float4(bhh[(size_t)dir * 4 * H + j0 + eu], bhh[(size_t)dir * 4 * H + H + j0 + eu],
                                   bhh[(size_t)dir * 4 * H + 2 * H + j0 + eu], bhh[(size_t)dir * 4 * H + 3 * H + j0 + eu]);
   __syncthreads();
+#ifdef LP_TRACE
+  if (threadIdx.x == 0 && blockIdx.x < 256) lp_trace_xcc[blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+#endif
   const int br = min(b0 + li, B - 1);
   for (int step = 0; step < T; ++step) {
     const int t = dir == 0 ? step : T - 1 - step;
     const int tp = dir == 0 ? t - 1 : t + 1;
+    LP_STAMP(0);
     float gxv[2][4];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -957,6 +985,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     if (step > 0) {
       lp_wait(flag, 8u * (unsigned)step, err, &lp_bad);
+      LP_STAMP(1);
       const __bf16* arow = hseq2 + ((size_t)tp * B + br) * 2 * H + dir * H + 128 * kq + 8 * lh;
       const __bf16* brow = Wh + (g * 32 + li) * LP_WP + 128 * kq + 8 * lh;
       rbf16x8 ah[8], al[8];
@@ -965,6 +994,10 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
         ah[i] = lp_load8(arow + 16 * i);
         al[i] = lp_load8(arow + nh + 16 * i);
       }
+#ifdef LP_TRACE
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      LP_STAMP(2);
+#endif
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const rbf16x8 wh = *reinterpret_cast<const rbf16x8*>(brow + 16 * i);
@@ -974,6 +1007,10 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], wh, acc, 0, 0, 0);
       }
     }
+#ifdef LP_TRACE
+    asm volatile("s_nop 0" : "+v"(acc));          // (the accumulators are complete before the stamp)
+    LP_STAMP(3);
+#endif
     if (kq == 1) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) part[g][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = acc[r];
@@ -987,6 +1024,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
       }
     }
     __syncthreads();
+    LP_STAMP(4);
     // the partners only need the bf16 hi/lo copy of h: it goes out first and the step counter right behind it; the
     // fp32 outputs the BACKWARD pass reads (gates, c, h) are stored after the signal, off the critical path
     float o_ig[2], o_fg[2], o_gg[2], o_og[2], o_c[2], o_h[2];
@@ -1014,13 +1052,16 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
       pay[1024 + ebl * 32 + eu] = (__bf16)(o_h[e] - (float)hh);
     }
     __syncthreads();
+    LP_STAMP(5);
     {
       const int pl = tid >> 8, sq = (tid >> 3) & 31, ch = tid & 7;
       if (b0 + sq < B)
         lp_store4(hseq2 + (size_t)pl * nh + ((size_t)t * B + b0 + sq) * 2 * H + dir * H + j0 + 4 * ch,
                   *reinterpret_cast<const unsigned long long*>(&pay[pl * 1024 + sq * 32 + 4 * ch]));
     }
+    LP_STAMP(6);
     if (step + 1 < T) lp_arrive(flag);          // (the barrier inside also protects `part` for the next step)
+    LP_STAMP(7);
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int ebl = (tid >> 5) + 16 * e, eb = b0 + ebl;

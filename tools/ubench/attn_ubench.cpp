@@ -23,6 +23,14 @@ __global__ void fill_kernel(float* p, long n, uint32_t seed, float scale) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { uint32_t h = hash32((uint32_t)i * 2654435761u + seed); p[i] = scale * ((h >> 8) * (1.f / 8388608.f) - 1.f); }
 }
+// packed [rows][q | k | v]: q := |q|, k := -|k|
+__global__ void sign_kernel(float* p, long rows, int ld, int d) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * ld) return;
+  const int c = (int)(i % ld);
+  if (c < d) p[i] = fabsf(p[i]);
+  else if (c < 2 * d) p[i] = -fabsf(p[i]);
+}
 static float* dalloc(long n, uint32_t seed, float scale) {
   float* p; CK(hipMalloc(&p, n * sizeof(float)));
   if (seed) hipLaunchKernelGGL(fill_kernel, dim3((n + 255) / 256), 256, 0, 0, p, n, seed, scale);
@@ -66,21 +74,39 @@ int main(int argc, char** argv) {
     const int ldp = 3 * D;
     CK(focr_attention_dropout_mask(mask, B, H, N, 0.1f, 1234, 0) ? hipErrorUnknown : hipSuccess);
     g_tune[FOCR_TUNE_ATTN_FWD_VARIANT] = 1;
-    float tv[2] = {1e9f, 1e9f}, tp0 = 1e9f;
+    float tv[3] = {1e9f, 1e9f, 1e9f}, tp0[3] = {1e9f, 1e9f, 1e9f};
+    float *o2 = dalloc(n, 0, 0), *lse2 = dalloc((long)B * H * N, 0, 0);
     for (int rep = 0; rep < 3; ++rep) {
-      for (int mv = 0; mv < 2; ++mv) {
+      for (int mv = 0; mv < 3; ++mv) {
         g_tune[FOCR_TUNE_ATTN_FWD_MASK] = mv;
-        float* o = mv ? o1 : o0; float* ls = mv ? lse1 : lse0;
+        float* o = mv == 0 ? o0 : mv == 1 ? o1 : o2; float* ls = mv == 0 ? lse0 : mv == 1 ? lse1 : lse2;
         int rc = focr_attention_fwd_premasked(qkv, qkv + D, qkv + 2 * D, o, ls, mask, B, H, N, ldp, D, scale, 0.1f, 0);
         if (rc) { printf("premasked forward failed %d\n", rc); return 1; }
         tv[mv] = std::min(tv[mv], timeit([&]() { focr_attention_fwd_premasked(qkv, qkv + D, qkv + 2 * D, o, ls, mask, B, H, N, ldp, D, scale, 0.1f, 0); }, 8));
+        tp0[mv] = std::min(tp0[mv], timeit([&]() { focr_attention_fwd(qkv, qkv + D, qkv + 2 * D, dq0, work, mask, B, H, N, ldp, D, scale, 0.f, 1234, 0); }, 8));
       }
-      tp0 = std::min(tp0, timeit([&]() { focr_attention_fwd(qkv, qkv + D, qkv + 2 * D, dq0, work, mask, B, H, N, ldp, D, scale, 0.f, 1234, 0); }, 8));
     }
     CK(hipDeviceSynchronize());
     double mx, e = maxdiff(o0, o1, n, &mx), mx2, e2 = maxdiff(lse0, lse1, (long)B * H * N, &mx2);
-    printf("fwd keep-word schedule (packed operands, premasked, p = 0.1): MV0 %7.1f us  MV1 %7.1f us  | p = 0: %7.1f us | max|dO| %.2e of %.2e, max|dLSE| %.2e\n",
-           tv[0], tv[1], tp0, e, mx, e2);
+    double e3 = maxdiff(o0, o2, n, &mx), e4 = maxdiff(lse0, lse2, (long)B * H * N, &mx2);
+    printf("fwd keep-word schedule (packed operands, premasked, p = 0.1): MV0 %7.1f us  MV1 %7.1f us  MV2 %7.1f us | p = 0: %7.1f / %7.1f / %7.1f us\n"
+           "   MV1 vs MV0: max|dO| %.2e of %.2e, max|dLSE| %.2e;  MV2 vs MV0: max|dO| %.2e, max|dLSE| %.2e of %.2e\n",
+           tv[0], tv[1], tv[2], tp0[0], tp0[1], tp0[2], e, mx, e2, e3, e4, mx2);
+    // robustness of the relative-max form (MV2): (a) large scores of both signs, (b) EVERY score of every row far below
+    // zero (q >= 0, k <= 0): the first key group must move the reference down to the true maximum
+    for (int cas = 0; cas < 2; ++cas) {
+      float* qs = dalloc(3 * n, 99, 12.f);
+      if (cas == 1) hipLaunchKernelGGL(sign_kernel, dim3((unsigned)((B * (long)N * 3 * D + 255) / 256)), 256, 0, 0, qs, (long)B * N, 3 * D, D);
+      for (int mv : {0, 2}) {
+        g_tune[FOCR_TUNE_ATTN_FWD_MASK] = mv;
+        focr_attention_fwd_premasked(qs, qs + D, qs + 2 * D, mv ? o2 : o0, mv ? lse2 : lse0, mask, B, H, N, ldp, D, scale, 0.1f, 0);
+      }
+      CK(hipDeviceSynchronize());
+      double a_ = maxdiff(o0, o2, n, &mx), b_ = maxdiff(lse0, lse2, (long)B * H * N, &mx2);
+      printf("   %s: MV2 vs MV0 max|dO| %.2e of %.2e, max|dLSE| %.2e of %.2e\n",
+             cas ? "all scores negative (q >= 0, k <= 0, |.| <= 12)" : "large scores (|q|, |k| <= 12)", a_, mx, b_, mx2);
+      CK(hipFree(qs));
+    }
     return 0;
   }
   for (float p : {0.1f, 0.0f}) {
