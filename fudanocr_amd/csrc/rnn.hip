@@ -911,8 +911,8 @@ __device__ __forceinline__ void lp_store4(__bf16* p, unsigned long long v) {
 
 // -DLP_TRACE (variant library `python __graft_entry__.py --variant lptrace LP_TRACE`, tools/dev/lstm_phases.py): thread 0 of
 // every block stamps the 100 MHz wall clock at the phase boundaries of every time step of the FORWARD scan --
-//   0 step begins (gx requested) | 1 partners' step counter seen, L1 invalidated, block released | 2 h_{t-1} rows arrived
-//   (an extra vmcnt(0) in this build) | 3 24 MFMAs done | 4 K halves folded through LDS | 5 gates, c, h computed, payload
+//   0 step begins (gx requested) | 1 partners' step counter seen, L1 invalidated, block released | 2 h_{t-1} tile in LDS
+//   (block barrier) | 3 24 MFMAs done | 4 K halves folded through LDS | 5 gates, c, h computed, payload
 //   staged | 6 payload stores issued | 7 release increment done (lp_arrive returned); fp32 outputs follow
 // -- into a device array the tool reads back; XCC_ID of the block in slot 7 of step 0's row... see focr_lstm_trace_dump.
 #ifdef LP_TRACE
@@ -967,7 +967,25 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
 #ifdef LP_TRACE
   if (threadIdx.x == 0 && blockIdx.x < 256) lp_trace_xcc[blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
 #endif
-  const int br = min(b0 + li, B - 1);
+  // Round 5 (phase stamps, profiles/r05_lstm_phases_*.txt: 2.5 of 7.6 us per step went into sixteen scattered 16-byte
+  // loads of the partners' h rows per lane, 1.3 us into the W fragment reads interleaved with the MFMAs):
+  //   * this wave's W_hh fragments -- rows g * 32 + li, columns 128 kq .. + 127, hi and lo: the same sixteen 16-byte
+  //     pieces in EVERY step -- are read from the LDS image ONCE and stay in 64 VGPRs for the whole scan (the LDS copy only
+  //     serves this transposition); the per-step matrix phase is 24 MFMAs and nothing else;
+  //   * the LDS behind W is then free: h_{t-1} of the group's 32 sequences (hi + lo, 32 KB) is fetched by the whole block
+  //     as whole 512-byte rows (4 coalesced 16-byte loads per thread instead of 16 row-scattered ones per lane, each
+  //     row fetched once instead of once per gate wave) and the A fragments come from there.
+  rbf16x8 wfh[8], wfl[8];
+  {
+    const __bf16* brow = Wh + (g * 32 + li) * LP_WP + 128 * kq + 8 * lh;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      wfh[i] = *reinterpret_cast<const rbf16x8*>(brow + 16 * i);
+      wfl[i] = *reinterpret_cast<const rbf16x8*>(brow + 128 * LP_WP + 16 * i);
+    }
+  }
+  __syncthreads();                                   // every wave holds its fragments: the W image may be overwritten
+  __bf16* Hs = Wh;                                   // [2 planes][32 sequences][LP_WP]
   for (int step = 0; step < T; ++step) {
     const int t = dir == 0 ? step : T - 1 - step;
     const int tp = dir == 0 ? t - 1 : t + 1;
@@ -986,25 +1004,28 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
     if (step > 0) {
       lp_wait(flag, 8u * (unsigned)step, err, &lp_bad);
       LP_STAMP(1);
-      const __bf16* arow = hseq2 + ((size_t)tp * B + br) * 2 * H + dir * H + 128 * kq + 8 * lh;
-      const __bf16* brow = Wh + (g * 32 + li) * LP_WP + 128 * kq + 8 * lh;
-      rbf16x8 ah[8], al[8];
+      // the group's h_{t-1} tile: thread -> (plane, sequence, 16-byte chunk of the 512-byte row), 4 pieces each
+      rbf16x8 piece[4];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        ah[i] = lp_load8(arow + 16 * i);
-        al[i] = lp_load8(arow + nh + 16 * i);
+      for (int k = 0; k < 4; ++k) {
+        const int c = tid + 512 * k, pl = c >> 10, sq = (c >> 5) & 31, ch = c & 31;
+        piece[k] = lp_load8(hseq2 + (size_t)pl * nh + ((size_t)tp * B + min(b0 + sq, B - 1)) * 2 * H + dir * H + 8 * ch);
       }
-#ifdef LP_TRACE
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = tid + 512 * k, pl = c >> 10, sq = (c >> 5) & 31, ch = c & 31;
+        *reinterpret_cast<rbf16x8*>(Hs + (pl * 32 + sq) * LP_WP + 8 * ch) = piece[k];
+      }
+      __syncthreads();
       LP_STAMP(2);
-#endif
+      const __bf16* arow = Hs + li * LP_WP + 128 * kq + 8 * lh;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const rbf16x8 wh = *reinterpret_cast<const rbf16x8*>(brow + 16 * i);
-        const rbf16x8 wl = *reinterpret_cast<const rbf16x8*>(brow + 128 * LP_WP + 16 * i);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], wh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], wl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], wh, acc, 0, 0, 0);
+        const rbf16x8 ah = *reinterpret_cast<const rbf16x8*>(arow + 16 * i);
+        const rbf16x8 al = *reinterpret_cast<const rbf16x8*>(arow + 32 * LP_WP + 16 * i);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wfh[i], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wfl[i], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wfh[i], acc, 0, 0, 0);
       }
     }
 #ifdef LP_TRACE
@@ -1105,7 +1126,20 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_bx3_kernel(
   float carry[2] = {0.f, 0.f};
   const int eu = tid & 31;
   __syncthreads();
-  const int br = min(b0 + li, B - 1);
+  // as in the forward scan (round 5): this wave's W_hh^T fragments (rows = 32 units, its 128 gate columns, hi + lo) are
+  // the same in every step -> 64 VGPRs for the whole scan; the LDS image behind them then holds the group's gate-gradient
+  // tile of the previous step (32 sequences x 4H, hi + lo = 128 KB), fetched by the whole block as whole 2-KB rows
+  rbf16x8 wfh[8], wfl[8];
+  {
+    const __bf16* brow = Wh + li * LP_WTP + 128 * wave + 8 * lh;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      wfh[i] = *reinterpret_cast<const rbf16x8*>(brow + 16 * i);
+      wfl[i] = *reinterpret_cast<const rbf16x8*>(brow + 32 * LP_WTP + 16 * i);
+    }
+  }
+  __syncthreads();
+  __bf16* Ds = Wh;                                   // [2 planes][32 sequences][LP_WTP]
   for (int step = 0; step < T; ++step) {
     const int t = dir == 0 ? T - 1 - step : step;
     const int tn = dir == 0 ? t + 1 : t - 1;
@@ -1126,22 +1160,33 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_bx3_kernel(
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     if (step > 0) {
       lp_wait(flag, 8u * (unsigned)step, err, &lp_bad);
-      // wave w contracts n in [128 w, 128 w + 128) of the 4H gate-gradient row
-      const __bf16* arow = dgx2 + ((size_t)tn * st_t + (size_t)br * st_b) * 8 * H + dir * 4 * H + 128 * wave + 8 * lh;
-      const __bf16* brow = Wh + li * LP_WTP + 128 * wave + 8 * lh;
-      rbf16x8 ah[8], al[8];
+      // the group's gate-gradient tile of step t_next: thread -> (plane, sequence, 16-byte chunk of the 2-KB row), 16 pieces
+      // each in two batches of 8 (register budget)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        ah[i] = lp_load8(arow + 16 * i);
-        al[i] = lp_load8(arow + ndg + 16 * i);
+      for (int half = 0; half < 2; ++half) {
+        rbf16x8 piece[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int c = tid + 512 * (8 * half + k), pl = c >> 12, sq = (c >> 7) & 31, ch = c & 127;
+          piece[k] = lp_load8(dgx2 + (size_t)pl * ndg +
+                              ((size_t)tn * st_t + (size_t)min(b0 + sq, B - 1) * st_b) * 8 * H + dir * 4 * H + 8 * ch);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int c = tid + 512 * (8 * half + k), pl = c >> 12, sq = (c >> 7) & 31, ch = c & 127;
+          *reinterpret_cast<rbf16x8*>(Ds + (pl * 32 + sq) * LP_WTP + 8 * ch) = piece[k];
+        }
       }
+      __syncthreads();
+      // wave w contracts n in [128 w, 128 w + 128) of the 4H gate-gradient row
+      const __bf16* arow = Ds + li * LP_WTP + 128 * wave + 8 * lh;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const rbf16x8 wh = *reinterpret_cast<const rbf16x8*>(brow + 16 * i);
-        const rbf16x8 wl = *reinterpret_cast<const rbf16x8*>(brow + 32 * LP_WTP + 16 * i);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], wh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], wl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], wh, acc, 0, 0, 0);
+        const rbf16x8 ah = *reinterpret_cast<const rbf16x8*>(arow + 16 * i);
+        const rbf16x8 al = *reinterpret_cast<const rbf16x8*>(arow + 32 * LP_WTP + 16 * i);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wfh[i], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wfl[i], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wfh[i], acc, 0, 0, 0);
       }
     }
     // fold the 8 partial tiles in a fixed order: (w + (w + 4)) per slot, then slots 0..3 in the epilogue

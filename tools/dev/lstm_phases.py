@@ -36,8 +36,8 @@ assert rc == 0, rc
 ngroups = (b + 31) // 32 * 2
 nblk = 8 * ngroups
 s = stamps.reshape(NB, NS, 8)[:nblk, :t].astype(np.int64) * 10        # ns (100 MHz wall clock)
-names = ["0>1 wait for the partners' counter + L1 invalidate + barrier", "1>2 h(t-1) rows: 16 x 16-byte loads from L2",
-         "2>3 24 MFMAs + 16 LDS fragment reads", "3>4 fold the two K halves through LDS (2 barriers)",
+names = ["0>1 wait for the partners' counter + L1 invalidate + barrier", "1>2 h(t-1) tile: 4 coalesced 16-byte loads per thread -> LDS + barrier",
+         "2>3 16 LDS fragment reads (h) + 24 MFMAs (W fragments in registers)", "3>4 fold the two K halves through LDS (2 barriers)",
          "4>5 gates / c / h + payload staged in LDS (2 barriers)", "5>6 payload stores issued (8 B per thread)",
          "6>7 barrier + RELEASE increment (agent scope: L2 write-back)"]
 print("persistent LSTM forward, T = %d, B = %d: %d blocks in %d groups of 8; XCC ids per group: %s"
