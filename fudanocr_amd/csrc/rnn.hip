@@ -863,7 +863,14 @@ __device__ __forceinline__ void lp_wait(unsigned* flag, unsigned target, unsigne
   }
   __syncthreads();
 }
-__device__ __forceinline__ void lp_arrive(unsigned* flag) {
+// fast (round 5, wave-uniform per block): ALL 8 partners of this block's group run on ITS XCD (checked at run time, see
+// lp_same_xcd below).  The payload then only has to be in the XCD's L2 before the counter moves: every storing wave waits
+// for its stores' acknowledgement (vmcnt(0)), barrier, RELAXED increment -- the workgroup-scope release of a
+// threadgroup-split workgroup (CUs behind one L2) -- instead of the agent-scope release, whose L2 write-back was 1.1-1.3 us
+// of every step (profiles/r05_lstm_phases_*.txt).  The consumer side is unchanged (relaxed poll, one agent-scope acquire).
+// Any other placement (B != 128: the groups' ids are not congruent mod 8; CU masks; partition modes) keeps the agent-scope
+// release: with it forced on mixed placements the scan goes stale (tools/gpu/r05_call7.sh, as round 4 had found).
+__device__ __forceinline__ void lp_arrive(unsigned* flag, bool fast) {
 #ifdef LSTM_ABL_NOSYNC
   __syncthreads();
   return;
@@ -873,9 +880,25 @@ __device__ __forceinline__ void lp_arrive(unsigned* flag) {
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
-  __syncthreads();                      // every thread's rows of this step are written (and acknowledged by L2)
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (fast) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // EVERY storing wave: its payload stores are in the shared L2
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    __syncthreads();                    // every thread's rows of this step are written (and acknowledged by L2)
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
 #endif
+}
+// XCD census of a group: before its FIRST arrive (an agent-scope release, which orders it) thread 0 of every block ORs
+// 1 << XCC_ID into the group's mask word; after the first wait all 8 contributions are visible.  -> true iff the mask is
+// exactly this block's own bit.  Called by thread 0 only.
+__device__ __forceinline__ unsigned lp_xcc_bit() { return 1u << (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u); }
+__device__ __forceinline__ void lp_census_vote(unsigned* mask_word) {
+  __hip_atomic_fetch_or(mask_word, lp_xcc_bit(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool lp_same_xcd(unsigned* mask_word) {
+  return __hip_atomic_load(mask_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == lp_xcc_bit();
 }
 // 8 bf16 (16 bytes) of a partner's payload row
 __device__ __forceinline__ rbf16x8 lp_load8(const __bf16* p) {
@@ -936,7 +959,7 @@ extern "C" int focr_lstm_trace_dump(unsigned long long* host_stamps, unsigned* h
 __global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
     const float* __restrict__ gx, const __bf16* __restrict__ whh2, const float* __restrict__ bhh,
     float* __restrict__ hseq, __bf16* __restrict__ hseq2, float* __restrict__ gates, float* __restrict__ cseq,
-    unsigned* __restrict__ flags, int T, int B, int st_t, int st_b, int ngroups) {
+    unsigned* __restrict__ flags, int T, int B, int st_t, int st_b, int ngroups, int allow_fast) {
   constexpr int H = 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char lp_smem[];
   __bf16* Wh = reinterpret_cast<__bf16*>(lp_smem);              // [128][LP_WP]
@@ -950,8 +973,14 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
   const long nw = (long)2 * 4 * H * H;
   unsigned* flag = flags + group;
   unsigned* err = flags + ngroups;
-  __shared__ unsigned lp_bad;
-  if (threadIdx.x == 0) lp_bad = 0u;
+  __shared__ unsigned lp_bad, lp_fast;
+  unsigned* const xmask = flags + ngroups + 1 + group;      // the group's XCD census word (see lp_census_vote)
+  if (threadIdx.x == 0) {
+    lp_bad = 0u;
+    lp_fast = 0u;
+    lp_census_vote(xmask);
+  }
+  bool fast = false;
   for (int i = tid; i < 128 * 32; i += 512) {                   // 16-byte pieces of the 128 rows x 256 k slice
     const int row = i >> 5, ch = i & 31, gg = row >> 5, u = row & 31;
     const __bf16* src = whh2 + ((size_t)dir * 4 * H + gg * H + j0 + u) * H + 8 * ch;
@@ -1003,6 +1032,11 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     if (step > 0) {
       lp_wait(flag, 8u * (unsigned)step, err, &lp_bad);
+      if (step == 1 && allow_fast) {                    // all 8 partners have voted: may the releases stay inside the XCD?
+        if (threadIdx.x == 0) lp_fast = lp_same_xcd(xmask) ? 1u : 0u;
+        __syncthreads();
+        fast = lp_fast != 0u;
+      }
       LP_STAMP(1);
       // the group's h_{t-1} tile: thread -> (plane, sequence, 16-byte chunk of the 512-byte row), 4 pieces each
       rbf16x8 piece[4];
@@ -1081,7 +1115,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
                   *reinterpret_cast<const unsigned long long*>(&pay[pl * 1024 + sq * 32 + 4 * ch]));
     }
     LP_STAMP(6);
-    if (step + 1 < T) lp_arrive(flag);          // (the barrier inside also protects `part` for the next step)
+    if (step + 1 < T) lp_arrive(flag, fast);    // (the barrier inside also protects `part` for the next step)
     LP_STAMP(7);
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -1102,7 +1136,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
 __global__ __launch_bounds__(512) void lstm_bwd_persist_bx3_kernel(
     const float* __restrict__ dhseq, const __bf16* __restrict__ whhT2, const float* __restrict__ gates,
     const float* __restrict__ cseq, float* __restrict__ dgx, __bf16* __restrict__ dgx2, unsigned* __restrict__ flags,
-    int T, int B, int st_t, int st_b, long ndg, int ngroups) {
+    int T, int B, int st_t, int st_b, long ndg, int ngroups, int allow_fast) {
   constexpr int H = 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char lp_smem[];
   __bf16* Wh = reinterpret_cast<__bf16*>(lp_smem);              // [32 units][LP_WTP]  (W_hh^T rows: n over 4H)
@@ -1115,8 +1149,14 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_bx3_kernel(
   const long nwt = (long)2 * H * 4 * H;
   unsigned* flag = flags + group;
   unsigned* err = flags + ngroups;
-  __shared__ unsigned lp_bad;
-  if (threadIdx.x == 0) lp_bad = 0u;
+  __shared__ unsigned lp_bad, lp_fast;
+  unsigned* const xmask = flags + ngroups + 1 + group;      // the group's XCD census word (see lp_census_vote)
+  if (threadIdx.x == 0) {
+    lp_bad = 0u;
+    lp_fast = 0u;
+    lp_census_vote(xmask);
+  }
+  bool fast = false;
   for (int i = tid; i < 32 * 128; i += 512) {                   // 16-byte pieces of 32 rows x 1024 n
     const int row = i >> 7, ch = i & 127;
     const __bf16* src = whhT2 + ((size_t)dir * H + j0 + row) * 4 * H + 8 * ch;
@@ -1160,6 +1200,11 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_bx3_kernel(
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     if (step > 0) {
       lp_wait(flag, 8u * (unsigned)step, err, &lp_bad);
+      if (step == 1 && allow_fast) {                    // all 8 partners have voted: may the releases stay inside the XCD?
+        if (threadIdx.x == 0) lp_fast = lp_same_xcd(xmask) ? 1u : 0u;
+        __syncthreads();
+        fast = lp_fast != 0u;
+      }
       // the group's gate-gradient tile of step t_next: thread -> (plane, sequence, 16-byte chunk of the 2-KB row), 16 pieces
       // each in two batches of 8 (register budget)
 #pragma unroll
@@ -1240,7 +1285,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_bx3_kernel(
                       4 * ch,
                   *reinterpret_cast<const unsigned long long*>(&pay[pl * 4096 + (sq * 4 + q) * 32 + 4 * ch]));
     }
-    if (step + 1 < T) lp_arrive(flag);          // partners read the bf16 copies only; the fp32 result follows
+    if (step + 1 < T) lp_arrive(flag, fast);    // partners read the bf16 copies only; the fp32 result follows
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int eb = b0 + (tid >> 5) + 16 * e;
@@ -1270,7 +1315,7 @@ static int lp_resident_blocks(const void* kern, size_t lds) {
 }
 static bool lp_usable(int B, int H) {
   if (!(H == 256 && 8 * cdiv(B, 32) * 2 <= 256 && focr_get_tuning(FOCR_TUNE_LSTM_PERSISTENT) != 0 &&
-        cdiv(B, 32) * 2 + 1 <= LP_FLAG_BYTES / 4))
+        2 * (cdiv(B, 32) * 2) + 1 <= LP_FLAG_BYTES / 4))
     return false;
   static std::atomic<int> resident_dev[64];          // min over the two kernels + 1 (0 = not asked yet), per device
   std::atomic<int>& slot = resident_dev[focr_cur_device()];
@@ -1310,7 +1355,8 @@ int focr_lstm_fwd_bx3(const float* gx, const float* whh, const float* bhh, float
     (void)hipMemsetAsync(flags, 0, LP_FLAG_BYTES, stream);
     const int ngroups = cdiv(B, 32) * 2;
     hipLaunchKernelGGL(lstm_fwd_persist_bx3_kernel, dim3(8 * ngroups), 512, LP_FWD_LDS, stream, gx,
-                       (const __bf16*)whh2, bhh, hseq, hseq2, gates, cseq, flags, T, B, st_t, st_b, ngroups);
+                       (const __bf16*)whh2, bhh, hseq, hseq2, gates, cseq, flags, T, B, st_t, st_b, ngroups,
+                       focr_get_tuning(FOCR_TUNE_LSTM_PERSISTENT) != 2);
     return 0;
   }
   dim3 grid(H / 32, (B + 31) / 32, 2);
@@ -1339,7 +1385,8 @@ int focr_lstm_bwd_bx3(const float* dhseq, const float* whh, const float* gates, 
     (void)hipMemsetAsync(flags, 0, LP_FLAG_BYTES, stream);
     const int ngroups = cdiv(B, 32) * 2;
     hipLaunchKernelGGL(lstm_bwd_persist_bx3_kernel, dim3(8 * ngroups), 512, LP_BWD_LDS, stream, dhseq,
-                       (const __bf16*)whhT2, gates, cseq, dgx, dgx2, flags, T, B, st_t, st_b, ndg, ngroups);
+                       (const __bf16*)whhT2, gates, cseq, dgx, dgx2, flags, T, B, st_t, st_b, ndg, ngroups,
+                       focr_get_tuning(FOCR_TUNE_LSTM_PERSISTENT) != 2);
     return 0;
   }
   dim3 grid(H / 32, (B + 31) / 32, 2);

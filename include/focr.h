@@ -46,7 +46,8 @@ int focr_set_precision(int mode);
 /* A/B kernel-selection switches for measurements (results do not depend on them; defaults are the production
  * kernels).  key 0: transformer-linear weight gradients on the streaming kernel (1, default) or the generic split
  * kernel (0); key 1: attention forward with 256-query (1, default) / 128-query (0) blocks / look-ahead scores (2);
- * key 2: persistent LSTM scan, one launch per layer (1, default) or one launch per time step (0);
+ * key 2: persistent LSTM scan, one launch per layer (1, default; 2 = the same with the agent-scope release in every step even
+ * when a group's 8 blocks share an XCD) or one launch per time step (0);
  * key 3: attention backward: 2 (default) = single pass, dQ / dK / dV from one S / dP evaluation (precision modes 2 / 3
  * and Ntok % 256 == 0, otherwise as 1); 1 = two passes (dK/dV, then dQ with 256-query blocks); 0 = two passes,
  * 128-query dQ blocks; key 4: keep-word schedule of the 256-query attention forward: 1 (default) = scalar mask requests

@@ -827,7 +827,11 @@ def test_lstm(b, precision):
 def test_lstm_persistent_scan_equals_per_step_launches(b, monkeypatch):
     """rnn.hip persistent kernels (one launch walks all T steps; the 8 blocks that share a sequence block meet at a
     global counter every step) against the per-step launches of the same arithmetic: forward h and the data gradient
-    agree to rounding (the K reduction is folded 2-way instead of 4-way), run twice = bit-identical (deterministic)"""
+    agree to rounding (the K reduction is folded 2-way instead of 4-way), run twice = bit-identical (deterministic).
+    b = 128: the 8 blocks of a group have the same id mod 8 = one XCD, so from the second step on their releases stay inside
+    that XCD's L2 (round 5: no agent-scope write-back; decided at run time by the XCD census in the flag words); tuning value 2
+    forces the agent-scope release in every step -- same bits.  b = 70: mixed placement, always the agent-scope release.
+    Repeated five times: a stale exchange would show up as a run-to-run difference."""
     from fudanocr_amd import _lib
     monkeypatch.setenv("FOCR_LSTM_CHECK", "1")           # read the scan's time-out word after every launch
     k = K()
@@ -849,6 +853,15 @@ def test_lstm_persistent_scan_equals_per_step_launches(b, monkeypatch):
     close(outs[1][0], outs[0][0], 1e-5, what="persistent lstm fwd")
     close(outs[1][1], outs[0][1], 1e-5, what="persistent lstm bwd")
     assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])
+    for variant in (2, 1, 1, 2, 1):
+        _lib.call("focr_set_tuning", 2, variant)
+        try:
+            gx = gx0.clone().requires_grad_(True)
+            y = k.lstm_recurrence(gx, whh, bhh, t, b, b, 1)
+            y.backward(gy)
+            assert torch.equal(y.detach().cpu(), outs[1][0]) and torch.equal(gx.grad.cpu(), outs[1][1]), variant
+        finally:
+            _lib.call("focr_set_tuning", 2, 1)
 
 
 def test_ctc():

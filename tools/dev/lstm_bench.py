@@ -10,7 +10,7 @@ gx = (torch.rand(t * b, 8 * hid, generator=g) - 0.5).cuda().requires_grad_(True)
 whh = ((torch.rand(2, 4 * hid, hid, generator=g) - 0.5) / 8).cuda()
 bhh = ((torch.rand(2, 4 * hid, generator=g) - 0.5) / 8).cuda()
 gy = (torch.rand(t, b, 2 * hid, generator=g) - 0.5).cuda()
-for persistent in (1, 0, 1):
+for persistent in (1, 2, 0, 1):       # 1 = default (releases inside the XCD when a group shares one), 2 = always agent scope
     _lib.call("focr_set_tuning", 2, persistent)
     for phase in ("fwd", "fwd+bwd"):
         for _ in range(3):

@@ -39,15 +39,15 @@ s = stamps.reshape(NB, NS, 8)[:nblk, :t].astype(np.int64) * 10        # ns (100 
 names = ["0>1 wait for the partners' counter + L1 invalidate + barrier", "1>2 h(t-1) tile: 4 coalesced 16-byte loads per thread -> LDS + barrier",
          "2>3 16 LDS fragment reads (h) + 24 MFMAs (W fragments in registers)", "3>4 fold the two K halves through LDS (2 barriers)",
          "4>5 gates / c / h + payload staged in LDS (2 barriers)", "5>6 payload stores issued (8 B per thread)",
-         "6>7 barrier + RELEASE increment (agent scope: L2 write-back)"]
+         "6>7 barrier + counter increment (XCD-local when the census allows, else agent-scope release = L2 write-back)"]
 print("persistent LSTM forward, T = %d, B = %d: %d blocks in %d groups of 8; XCC ids per group: %s"
       % (t, b, nblk, ngroups, [sorted(set(int(x) & 15 for x in xcc[gi:nblk:ngroups])) for gi in range(ngroups)]))
 d = np.diff(s[:, 1:, :], axis=2)                                       # steps >= 1: [blk, step, 7]
 for k, n in enumerate(names):
     v = d[:, :, k].ravel() / 1e3
-    print("  %-66s mean %5.2f us  median %5.2f  p90 %5.2f" % (n, v.mean(), np.median(v), np.percentile(v, 90)))
+    print("  %-78s mean %5.2f us  median %5.2f  p90 %5.2f" % (n, v.mean(), np.median(v), np.percentile(v, 90)))
 tail = (s[:, 2:, 0] - s[:, 1:-1, 7]).ravel() / 1e3                     # end of step k (stamp 7) -> begin of step k + 1
-print("  %-66s mean %5.2f us  median %5.2f  p90 %5.2f" % ("7>0' fp32 outputs (gates, c, h) stored, next step's gx requested",
+print("  %-78s mean %5.2f us  median %5.2f  p90 %5.2f" % ("7>0' fp32 outputs (gates, c, h) stored, next step's gx requested",
                                                           tail.mean(), np.median(tail), np.percentile(tail, 90)))
 period = np.diff(s[:, 1:, 0], axis=1).ravel() / 1e3
 print("  step period %.2f us (median %.2f); whole scan %.1f us" % (period.mean(), np.median(period),
