@@ -213,21 +213,35 @@ __global__ __launch_bounds__(64 * WAVES9) void conv9x9_out_fwd_bx3_kernel(
   __bf16* Wl = Wh + 9 * 32 * WBP;
   float* Zall = reinterpret_cast<float*>(Wl + 9 * 32 * WBP);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-  for (int i = tid; i < 9 * 32 * 16; i += 64 * WAVES9) {
-    const int c4 = i & 15, j = (i >> 4) & 31, kh = i >> 9;
-    const int co = j / 9, kw = j - co * 9;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (j < Cout * 9) v = *reinterpret_cast<const float4*>(Wt + (((size_t)co * 9 + kh) * 9 + kw) * C9 + c4 * 4);
-    const float a[4] = {v.x, v.y, v.z, v.w};
-    obf16x4 h, l;
+  {   // two-phase staging (round 5): the twelve float4 of a thread are requested together (clamped address + select
+      // instead of a branch), then split and stored -- the one-pass loop cost one L2 round trip per iteration
+    constexpr int IT = 9 * 32 * 16 / (64 * WAVES9);
+    static_assert(9 * 32 * 16 % (64 * WAVES9) == 0, "staging trip count");
+    float4 wv[IT];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      __bf16 hh = (__bf16)a[e];
-      h[e] = hh;
-      l[e] = (__bf16)(a[e] - (float)hh);
+    for (int k = 0; k < IT; ++k) {
+      const int i = tid + k * 64 * WAVES9;
+      const int c4 = i & 15, j = (i >> 4) & 31, kh = i >> 9;
+      const int jc = j < Cout * 9 ? j : 0;
+      const int co = jc / 9, kw = jc - co * 9;
+      wv[k] = *reinterpret_cast<const float4*>(Wt + (((size_t)co * 9 + kh) * 9 + kw) * C9 + c4 * 4);
     }
-    *reinterpret_cast<obf16x4*>(&Wh[(kh * 32 + j) * WBP + c4 * 4]) = h;
-    *reinterpret_cast<obf16x4*>(&Wl[(kh * 32 + j) * WBP + c4 * 4]) = l;
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+      const int i = tid + k * 64 * WAVES9;
+      const int c4 = i & 15, j = (i >> 4) & 31, kh = i >> 9;
+      const bool ok = j < Cout * 9;
+      const float a[4] = {ok ? wv[k].x : 0.f, ok ? wv[k].y : 0.f, ok ? wv[k].z : 0.f, ok ? wv[k].w : 0.f};
+      obf16x4 h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        __bf16 hh = (__bf16)a[e];
+        h[e] = hh;
+        l[e] = (__bf16)(a[e] - (float)hh);
+      }
+      *reinterpret_cast<obf16x4*>(&Wh[(kh * 32 + j) * WBP + c4 * 4]) = h;
+      *reinterpret_cast<obf16x4*>(&Wl[(kh * 32 + j) * WBP + c4 * 4]) = l;
+    }
   }
   __syncthreads();
   const int unit = blockIdx.x * WAVES9 + wave;

@@ -46,42 +46,88 @@ __device__ __forceinline__ int fc_perm(int c) {            // column -> k positi
 }
 
 // ---- weight staging ---------------------------------------------------------------------------------------------
+// Round 5: every staging routine is TWO-PHASE -- all of a thread's global loads of ALL matrices and vectors of the
+// prologue are issued first (compile-time trip counts, straight-line code), then converted and stored.  The one-pass
+// loops they replace (load -> split -> LDS store per iteration, one iteration per L2 round trip, a branch per vector)
+// made the prologue 12-39 us of EVERY launch: the chains measured 22-39 us on 2 048 rows and 53-103 us on 131 072
+// (profiles/r05_fe_prologue.txt), i.e. their streaming part already ran at 5.5-6 TB/s and a fifth to a third of each
+// launch was this prologue.
 // Wg [N][K] row-major fp32 -> LDS rows n (pitch K + 8 bf16), k permuted, hi / lo planes.  4 consecutive columns map to
 // 4 consecutive k positions (fc_perm), so every thread converts a float4 and stores two 8-byte vectors.
-template <int K>
-__device__ __forceinline__ void fc_stage_w(const float* __restrict__ Wg, int N, __bf16* Wh, __bf16* Wl) {
-  constexpr int KP = K + 8, Q = K / 4;
-  for (int i = threadIdx.x; i < N * Q; i += FC_THREADS) {
-    const int n = i / Q, c = 4 * (i - n * Q);
-    const float4 v = *reinterpret_cast<const float4*>(Wg + (size_t)n * K + c);
-    fc_bf16x4 h, l;
-    focr_split4(v, h, l);
-    const int kk = fc_perm(c);
-    *reinterpret_cast<fc_bf16x4*>(&Wh[n * KP + kk]) = h;
-    *reinterpret_cast<fc_bf16x4*>(&Wl[n * KP + kk]) = l;
-  }
-}
-// Transposed: Wg [N][ldw] (columns c0 .. c0 + C - 1 used) -> LDS rows c (C rows, pitch N + 8), k = permuted n.  The data
-// gradient y = dy W contracts over the weight's OUTPUT index.
-template <int N>
-__device__ __forceinline__ void fc_stage_wt(const float* __restrict__ Wg, int ldw, int C, __bf16* Wh, __bf16* Wl) {
-  constexpr int KP = N + 8;
-  const int Q = C / 4;
-  for (int i = threadIdx.x; i < N * Q; i += FC_THREADS) {
-    const int n = i / Q, c = 4 * (i - n * Q);
-    const float4 v = *reinterpret_cast<const float4*>(Wg + (size_t)n * ldw + c);
-    const int kk = fc_perm(n);
-    fc_bf16x4 h, l;
-    focr_split4(v, h, l);
+template <int K, int N, int THREADS = FC_THREADS>
+struct FcStageW {
+  static constexpr int KP = K + 8, Q = K / 4, IT = N * Q / THREADS;
+  static_assert(N * Q % THREADS == 0, "staging trip count");
+  float4 v[IT];
+  __device__ __forceinline__ void load(const float* __restrict__ Wg) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      Wh[(c + e) * KP + kk] = h[e];
-      Wl[(c + e) * KP + kk] = l[e];
+    for (int j = 0; j < IT; ++j) {
+      const int i = threadIdx.x + j * THREADS, n = i / Q, c = 4 * (i - n * Q);
+      v[j] = *reinterpret_cast<const float4*>(Wg + (size_t)n * K + c);
     }
   }
+  __device__ __forceinline__ void store(__bf16* Wh, __bf16* Wl) const {
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+      const int i = threadIdx.x + j * THREADS, n = i / Q, c = 4 * (i - n * Q);
+      fc_bf16x4 h, l;
+      focr_split4(v[j], h, l);
+      const int kk = fc_perm(c);
+      *reinterpret_cast<fc_bf16x4*>(&Wh[n * KP + kk]) = h;
+      *reinterpret_cast<fc_bf16x4*>(&Wl[n * KP + kk]) = l;
+    }
+  }
+};
+// Transposed: Wg [N][ldw] (columns 0 .. C - 1 used) -> LDS rows c (C rows, pitch N + 8), k = permuted n.  The data
+// gradient y = dy W contracts over the weight's OUTPUT index.
+// A thread owns 4 x 4 blocks (rows 4 n4 .. + 3, columns 4 c4 .. + 3): four float4 loads, transposed in registers, and --
+// fc_perm keeps four consecutive n together -- ONE 8-byte store per column and plane.  Lanes run over n4, so the 32
+// stores of a half-wave fill one LDS row contiguously (no bank conflicts); the element-wise form it replaces (eight
+// 2-byte stores per float4, lanes four LDS rows apart = 8-way conflicts) made the backward chains' prologue 6-17 us
+// longer than the forward chains' (profiles/r05_fe_prologue.txt).
+template <int N, int C>
+struct FcStageWt {
+  static constexpr int KP = N + 8, N4 = N / 4, C4 = C / 4, IT = N4 * C4 / FC_THREADS;
+  static_assert(N4 * C4 % FC_THREADS == 0, "staging trip count");
+  float4 v[IT][4];
+  __device__ __forceinline__ static void item(int it, int& n4, int& c4) {
+    n4 = it % N4;
+    c4 = it / N4;
+  }
+  __device__ __forceinline__ void load(const float* __restrict__ Wg, int ldw) {
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+      int n4, c4;
+      item(threadIdx.x + j * FC_THREADS, n4, c4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[j][r] = *reinterpret_cast<const float4*>(Wg + (size_t)(4 * n4 + r) * ldw + 4 * c4);
+    }
+  }
+  __device__ __forceinline__ void store(__bf16* Wh, __bf16* Wl) const {
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+      int n4, c4;
+      item(threadIdx.x + j * FC_THREADS, n4, c4);
+      const int kk = fc_perm(4 * n4);
+      const float a[4][4] = {{v[j][0].x, v[j][0].y, v[j][0].z, v[j][0].w}, {v[j][1].x, v[j][1].y, v[j][1].z, v[j][1].w},
+                             {v[j][2].x, v[j][2].y, v[j][2].z, v[j][2].w}, {v[j][3].x, v[j][3].y, v[j][3].z, v[j][3].w}};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        fc_bf16x4 h, l;
+        focr_split4(a[0][e], a[1][e], a[2][e], a[3][e], h, l);
+        *reinterpret_cast<fc_bf16x4*>(&Wh[(4 * c4 + e) * KP + kk]) = h;
+        *reinterpret_cast<fc_bf16x4*>(&Wl[(4 * c4 + e) * KP + kk]) = l;
+      }
+    }
+  }
+};
+// n <= THREADS floats of a bias / LayerNorm vector: one unconditional (clamped) load per thread, stored under a predicate
+template <int THREADS = FC_THREADS>
+__device__ __forceinline__ float fc_vec_load(const float* __restrict__ g, int n) {
+  return g ? g[min((int)threadIdx.x, n - 1)] : 0.f;
 }
-__device__ __forceinline__ void fc_stage_vec(const float* __restrict__ g, float* s, int n) {
-  for (int i = threadIdx.x; i < n; i += FC_THREADS) s[i] = g ? g[i] : 0.f;
+__device__ __forceinline__ void fc_vec_store(float* s, int n, float x) {
+  if ((int)threadIdx.x < n) s[threadIdx.x] = x;
 }
 
 // ---- rows in the lane layout ------------------------------------------------------------------------------------
@@ -287,12 +333,18 @@ __global__ __launch_bounds__(FC_THREADS, 1) void fe_fwd_a_kernel(
   float* va1 = vbo + FC_D;
   float* vb1 = va1 + FC_D;
   float* vbb1 = vb1 + FC_D;
-  fc_stage_w<FC_D>(Wo, FC_D, Woh, Wol);
-  fc_stage_w<FC_D>(W1, FC_D, W1h, W1l);
-  fc_stage_vec(bo, vbo, FC_D);
-  fc_stage_vec(a1, va1, FC_D);
-  fc_stage_vec(b1, vb1, FC_D);
-  fc_stage_vec(bb1, vbb1, FC_D);
+  {
+    FcStageW<FC_D, FC_D> s0, s1;
+    s0.load(Wo);
+    s1.load(W1);
+    const float x0 = fc_vec_load(bo, FC_D), x1 = fc_vec_load(a1, FC_D), x2 = fc_vec_load(b1, FC_D), x3 = fc_vec_load(bb1, FC_D);
+    s0.store(Woh, Wol);
+    s1.store(W1h, W1l);
+    fc_vec_store(vbo, FC_D, x0);
+    fc_vec_store(va1, FC_D, x1);
+    fc_vec_store(vb1, FC_D, x2);
+    fc_vec_store(vbb1, FC_D, x3);
+  }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
   for (int t = blockIdx.x * 8 + wave; t < ntiles; t += gridDim.x * 8) {
@@ -364,14 +416,22 @@ __global__ __launch_bounds__(FC_THREADS, 1) void fe_fwd_b_kernel(
   float* va3 = vbb2 + FC_D;
   float* vb3 = va3 + FC_D;
   float* vbl = vb3 + FC_D;               // 64
-  fc_stage_w<FC_D>(W2, FC_D, W2h, W2l);
-  fc_stage_w<FC_D>(Wl, 64, Wlh, Wll);
-  fc_stage_vec(a1, va1, FC_D);
-  fc_stage_vec(b1, vb1, FC_D);
-  fc_stage_vec(bb2, vbb2, FC_D);
-  fc_stage_vec(a3, va3, FC_D);
-  fc_stage_vec(b3, vb3, FC_D);
-  fc_stage_vec(bl, vbl, 64);
+  {
+    FcStageW<FC_D, FC_D> s0;
+    FcStageW<FC_D, 64> s1;
+    s0.load(W2);
+    s1.load(Wl);
+    const float x0 = fc_vec_load(a1, FC_D), x1 = fc_vec_load(b1, FC_D), x2 = fc_vec_load(bb2, FC_D), x3 = fc_vec_load(a3, FC_D),
+                x4 = fc_vec_load(b3, FC_D), x5 = fc_vec_load(bl, 64);
+    s0.store(W2h, W2l);
+    s1.store(Wlh, Wll);
+    fc_vec_store(va1, FC_D, x0);
+    fc_vec_store(vb1, FC_D, x1);
+    fc_vec_store(vbb2, FC_D, x2);
+    fc_vec_store(va3, FC_D, x3);
+    fc_vec_store(vb3, FC_D, x4);
+    fc_vec_store(vbl, 64, x5);
+  }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
   for (int t = blockIdx.x * 8 + wave; t < ntiles; t += gridDim.x * 8) {
@@ -423,9 +483,16 @@ __global__ __launch_bounds__(FC_THREADS, 1) void fe_bwd_a_kernel(
   __bf16* W2th = Wltl + FC_D * KP64;                      // [128][136]: W2^T
   __bf16* W2tl = W2th + WSZ128;
   float* va3 = reinterpret_cast<float*>(W2tl + WSZ128);
-  fc_stage_wt<64>(Wl, FC_D, FC_D, Wlth, Wltl);
-  fc_stage_wt<FC_D>(W2, FC_D, FC_D, W2th, W2tl);
-  fc_stage_vec(a3, va3, FC_D);
+  {
+    FcStageWt<64, FC_D> s0;
+    FcStageWt<FC_D, FC_D> s1;
+    s0.load(Wl, FC_D);
+    s1.load(W2, FC_D);
+    const float x0 = fc_vec_load(a3, FC_D);
+    s0.store(Wlth, Wltl);
+    s1.store(W2th, W2tl);
+    fc_vec_store(va3, FC_D, x0);
+  }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
   for (int t = blockIdx.x * 8 + wave; t < ntiles; t += gridDim.x * 8) {
@@ -474,9 +541,15 @@ __global__ __launch_bounds__(FC_THREADS, 1) void fe_bwd_b_kernel(
   __bf16* Woth = W1tl + WSZ128;
   __bf16* Wotl = Woth + WSZ128;
   float* va1 = reinterpret_cast<float*>(Wotl + WSZ128);
-  fc_stage_wt<FC_D>(W1, FC_D, FC_D, W1th, W1tl);
-  fc_stage_wt<FC_D>(Wo, FC_D, FC_D, Woth, Wotl);
-  fc_stage_vec(a1, va1, FC_D);
+  {
+    FcStageWt<FC_D, FC_D> s0, s1;
+    s0.load(W1, FC_D);
+    s1.load(Wo, FC_D);
+    const float x0 = fc_vec_load(a1, FC_D);
+    s0.store(W1th, W1tl);
+    s1.store(Woth, Wotl);
+    fc_vec_store(va1, FC_D, x0);
+  }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
   for (int t = blockIdx.x * 8 + wave; t < ntiles; t += gridDim.x * 8) {
@@ -536,27 +609,23 @@ __global__ __launch_bounds__(256, 2) void fe_qkv_fwd_kernel(const float* __restr
   __bf16* Wl = Wh + WSZ128;
   float* vb = reinterpret_cast<float*>(Wl + WSZ128);
   float* vbn = vb + FC_D;                                  // bn_gamma != nullptr: gamma | mean | invstd | beta, 64 each
-  if (bn_gamma)
-    for (int i = threadIdx.x; i < 64; i += 256) {
-      vbn[i] = bn_gamma[i];
-      vbn[64 + i] = bn_mean[i];
-      vbn[128 + i] = bn_invstd[i];
-      vbn[192 + i] = bn_beta[i];
-    }
   const int y = blockIdx.y;
-  {  // stage with 256 threads (fc_stage_* assume FC_THREADS)
-    constexpr int KP = KP128, Q = FC_D / 4;
-    const float* Wg = Wqkv + (size_t)y * FC_D * FC_D;
-    for (int i = threadIdx.x; i < FC_D * Q; i += 256) {
-      const int n = i / Q, c = 4 * (i - n * Q);
-      const float4 v = *reinterpret_cast<const float4*>(Wg + (size_t)n * FC_D + c);
-      fc_bf16x4 h, l;
-      focr_split4(v, h, l);
-      const int kk = fc_perm(c);
-      *reinterpret_cast<fc_bf16x4*>(&Wh[n * KP + kk]) = h;
-      *reinterpret_cast<fc_bf16x4*>(&Wl[n * KP + kk]) = l;
+  {  // two-phase staging with this kernel's 256 threads: the weight block's 16 float4 per thread, the bias and the four
+     // BatchNorm vectors are requested together
+    FcStageW<FC_D, FC_D, 256> s0;
+    s0.load(Wqkv + (size_t)y * FC_D * FC_D);
+    const int i4 = min((int)threadIdx.x, FC_D - 1), i6 = min((int)threadIdx.x, 63);
+    const float xb = bqkv ? bqkv[y * FC_D + i4] : 0.f;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+    if (bn_gamma) { g0 = bn_gamma[i6]; g1 = bn_mean[i6]; g2 = bn_invstd[i6]; g3 = bn_beta[i6]; }
+    s0.store(Wh, Wl);
+    if (threadIdx.x < FC_D) vb[threadIdx.x] = xb;
+    if (bn_gamma && threadIdx.x < 64) {
+      vbn[threadIdx.x] = g0;
+      vbn[64 + threadIdx.x] = g1;
+      vbn[128 + threadIdx.x] = g2;
+      vbn[192 + threadIdx.x] = g3;
     }
-    for (int i = threadIdx.x; i < FC_D; i += 256) vb[i] = bqkv ? bqkv[y * FC_D + i] : 0.f;
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
@@ -608,7 +677,11 @@ __global__ __launch_bounds__(FC_THREADS, 1) void fe_bwd_qkv_kernel(const float* 
   extern __shared__ __attribute__((aligned(16))) unsigned char fc_smem[];
   __bf16* Wth = reinterpret_cast<__bf16*>(fc_smem);        // [64][392]
   __bf16* Wtl = Wth + 64 * KP384;
-  fc_stage_wt<384>(Wqkv, FC_D, 64, Wth, Wtl);
+  {
+    FcStageWt<384, 64> s0;
+    s0.load(Wqkv, FC_D);
+    s0.store(Wth, Wtl);
+  }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
   for (int t = blockIdx.x * 8 + wave; t < ntiles; t += gridDim.x * 8) {

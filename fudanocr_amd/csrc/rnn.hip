@@ -981,11 +981,21 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
     lp_census_vote(xmask);
   }
   bool fast = false;
-  for (int i = tid; i < 128 * 32; i += 512) {                   // 16-byte pieces of the 128 rows x 256 k slice
-    const int row = i >> 5, ch = i & 31, gg = row >> 5, u = row & 31;
-    const __bf16* src = whh2 + ((size_t)dir * 4 * H + gg * H + j0 + u) * H + 8 * ch;
-    *reinterpret_cast<uint4*>(Wh + row * LP_WP + 8 * ch) = *reinterpret_cast<const uint4*>(src);
-    *reinterpret_cast<uint4*>(Wl + row * LP_WP + 8 * ch) = *reinterpret_cast<const uint4*>(src + nw);
+  {   // 16-byte pieces of the 128 rows x 256 k slice: all sixteen requests of a thread in flight, then the LDS stores
+    uint4 wv[8][2];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = tid + 512 * k, row = i >> 5, ch = i & 31, gg = row >> 5, u = row & 31;
+      const __bf16* src = whh2 + ((size_t)dir * 4 * H + gg * H + j0 + u) * H + 8 * ch;
+      wv[k][0] = *reinterpret_cast<const uint4*>(src);
+      wv[k][1] = *reinterpret_cast<const uint4*>(src + nw);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = tid + 512 * k, row = i >> 5, ch = i & 31;
+      *reinterpret_cast<uint4*>(Wh + row * LP_WP + 8 * ch) = wv[k][0];
+      *reinterpret_cast<uint4*>(Wl + row * LP_WP + 8 * ch) = wv[k][1];
+    }
   }
   // the two cell elements of this thread: (sequence ebl, unit eu), ebl = e >> 5 for e = tid, tid + 512
   float cprev[2] = {0.f, 0.f};
@@ -1157,11 +1167,21 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_bx3_kernel(
     lp_census_vote(xmask);
   }
   bool fast = false;
-  for (int i = tid; i < 32 * 128; i += 512) {                   // 16-byte pieces of 32 rows x 1024 n
-    const int row = i >> 7, ch = i & 127;
-    const __bf16* src = whhT2 + ((size_t)dir * H + j0 + row) * 4 * H + 8 * ch;
-    *reinterpret_cast<uint4*>(Wh + row * LP_WTP + 8 * ch) = *reinterpret_cast<const uint4*>(src);
-    *reinterpret_cast<uint4*>(Wl + row * LP_WTP + 8 * ch) = *reinterpret_cast<const uint4*>(src + nwt);
+  {   // 16-byte pieces of 32 rows x 1024 n: all sixteen requests of a thread in flight, then the LDS stores
+    uint4 wv[8][2];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = tid + 512 * k, row = i >> 7, ch = i & 127;
+      const __bf16* src = whhT2 + ((size_t)dir * H + j0 + row) * 4 * H + 8 * ch;
+      wv[k][0] = *reinterpret_cast<const uint4*>(src);
+      wv[k][1] = *reinterpret_cast<const uint4*>(src + nwt);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = tid + 512 * k, row = i >> 7, ch = i & 127;
+      *reinterpret_cast<uint4*>(Wh + row * LP_WTP + 8 * ch) = wv[k][0];
+      *reinterpret_cast<uint4*>(Wl + row * LP_WTP + 8 * ch) = wv[k][1];
+    }
   }
   float carry[2] = {0.f, 0.f};
   const int eu = tid & 31;
