@@ -187,5 +187,13 @@ int main(int argc, char** argv) {
   printf("fe_bwd_b   %7.1f us  %.2f TB/s (6 row matrices, incl. D)\n", t, 6 * T / t * 1e-6);
   t = timeit([&] { hipLaunchKernelGGL(fe_bwd_qkv_kernel, dim3(fc_blocks(M / 32)), FC_THREADS, FC_LDS_BWD_QKV, 0, dqkv, p.wqkv, (const float*)ds1, dfeat, (int)(M / 32), D); });
   printf("fe_bwd_qkv %7.1f us  %.2f TB/s (4 row matrices)\n", t, 4 * T / t * 1e-6);
+  // ---- launch + prologue only (ntiles = 0: weights staged into LDS, no row tile), full grid
+  {
+    const int nb = fc_blocks(M / 32);
+    float ta = timeit([&] { hipLaunchKernelGGL(fe_fwd_a_kernel, dim3(nb), FC_THREADS, FC_LDS_FWD_A, 0, ctx, tok, p.wo, p.bo, p.a1, p.b1, p.w1, p.bb1, xhat1, rinv1, h, 0, eps, 58982u, ks, 7u); });
+    float tb = timeit([&] { hipLaunchKernelGGL(fe_bwd_b_kernel, dim3(nb), FC_THREADS, FC_LDS_BWD_B, 0, (const float*)dhpre, (const float*)ds2, p.w1, rxhat1, rrinv1, p.a1, p.wo, ds1, dctx, 0, eps, (const float*)ctx, dwk, 1024, (__bf16*)nullptr, 0L, 1.f); });
+    float tq = timeit([&] { hipLaunchKernelGGL(fe_bwd_qkv_kernel, dim3(nb), FC_THREADS, FC_LDS_BWD_QKV, 0, dqkv, p.wqkv, (const float*)ds1, dfeat, 0, D); });
+    printf("launch + prologue only (%d blocks): fe_fwd_a %.1f us  fe_bwd_b %.1f us  fe_bwd_qkv %.1f us\n", nb, ta, tb, tq);
+  }
   return 0;
 }
