@@ -56,7 +56,9 @@ class STNHead(nn.Module):
         """x: NHWC image -> (img_feat [B,512], control points [B,n,2])."""
         for m in self.stn_convnet:
             if isinstance(m, nn.Sequential):
-                x = m[1](m[0](x), act=K.ACT_RELU)
+                # conv -> BatchNorm -> ReLU; where the convolution runs on the halo kernel (the 64 -> 128 layer on 4 x 16 maps)
+                # its epilogue hands the BatchNorm the per-tile sums: no statistics passes over the 8192-row output
+                x = K.conv_bn(x, m[0], m[1], act=K.ACT_RELU)
             else:
                 x = m(x)
         b = x.shape[0]
