@@ -77,6 +77,10 @@ SIGNATURES = {
     "focr_bicubic_gray_bwd": [P, P, I, I, I, I, I, P],
     "focr_lstm_bidir_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, P],
     "focr_lstm_bidir_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, P],
+    "focr_lstm_bidir_fwd_pw": [P, P, P, P, P, P, P, P, I, I, I, I, I, P],
+    "focr_lstm_bidir_bwd_pw": [P, P, P, P, P, P, P, P, I, I, I, I, I, P],
+    "focr_lstm_prepare_weights": [P, P, I, I, P],
+    "focr_lstm_split_bytes": [I],
     "focr_gru_bidir_fwd": [P, P, P, P, P, I, I, I, I, I, I, P],
     "focr_gru_bidir_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     "focr_conv9x9_small_cout_fwd": [P, P, P, P, I, I, I, I, I, P],
@@ -149,6 +153,7 @@ def load():
     lib.focr_bn_ws_floats.restype = ctypes.c_long
     lib.focr_bn_bwd_ws_floats.restype = ctypes.c_long
     lib.focr_lstm_ws_bytes.restype = ctypes.c_long
+    lib.focr_lstm_split_bytes.restype = ctypes.c_long
     lib.focr_grad_sumsq_ws_floats.restype = ctypes.c_long
     lib.focr_conv2d_wgrad_ws_floats.restype = ctypes.c_long
     lib.focr_conv9x9_small_cout_wgrad_ws_floats.restype = ctypes.c_long

@@ -415,6 +415,43 @@ int focr_linear_stream_bx3(const float* x, const float* w, const float* bias, co
                            float drop_scale, uint32_t drop_seed, float mask_scale, hipStream_t stream);
 extern "C" int focr_dropout(const float* x, float* y, long n, float p, uint64_t seed, hipStream_t stream);
 
+// Tiny 1x1 layers whose contraction is not a multiple of 32 (the STN head's fc2 data gradient: [128 x 40] . [40 x 512], on
+// the critical path at the end of the backward): the tiled fp32-MFMA kernel above spent 60 us on eight blocks with
+// scalar loads and a barrier per 32-deep chunk.  Plain VALU: a thread owns 4 rows x 1 output column, float4 along k,
+// weights and rows come from L1 / L2 (the whole problem is a few hundred KB).  fp32 fma chain in k order.
+__global__ __launch_bounds__(256) void tiny_linear_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, const float* __restrict__ res,
+                                                          float* __restrict__ y, int M, int K, int Cout, int ldx, int ldy,
+                                                          int ldr, float alpha, int relu) {
+  const int co = blockIdx.x * 256 + threadIdx.x, m0 = blockIdx.y * 4;
+  if (co >= Cout) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* wr = w + (size_t)co * K;
+  const float* xr[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) xr[r] = x + (size_t)min(m0 + r, M - 1) * ldx;
+  for (int k = 0; k < K; k += 4) {
+    const float4 wv = *reinterpret_cast<const float4*>(wr + k);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float4 xv = *reinterpret_cast<const float4*>(xr[r] + k);
+      acc[r] = fmaf(xv.x, wv.x, acc[r]);
+      acc[r] = fmaf(xv.y, wv.y, acc[r]);
+      acc[r] = fmaf(xv.z, wv.z, acc[r]);
+      acc[r] = fmaf(xv.w, wv.w, acc[r]);
+    }
+  }
+  const float b = bias ? bias[co] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (m0 + r >= M) break;
+    float v = alpha * acc[r] + b;
+    if (res) v += res[(size_t)(m0 + r) * ldr + co];
+    if (relu) v = fmaxf(v, 0.f);
+    y[(size_t)(m0 + r) * ldy + co] = v;
+  }
+}
+
 static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, const float* residual, float* y, int N,
                            int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW, float alpha, int relu,
                            int ldy, int ldr, int ldx, float* ws, long ws_floats, hipStream_t stream) {
@@ -441,6 +478,13 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, co
   if (vec && focr_get_precision() != 0) {
     focr_conv_fwd_bx3(x, w, bias, residual, y, N, H, W, Cin, g.OH, g.OW, Cout, KH, KW, padH, padW, g.M, g.ldy,
                       g.ldr, g.ldx, alpha, relu, ws, ws_floats, stream);
+    FOCR_LAUNCH_CHECK();
+    return FOCR_OK;
+  }
+  if (!vec && KH == 1 && KW == 1 && padH == 0 && padW == 0 && Cin % 4 == 0 && g.ldx % 4 == 0 && Cin <= 256 &&
+      (long)g.M * Cout <= (1l << 20) && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+    hipLaunchKernelGGL(tiny_linear_kernel, dim3(cdiv(Cout, 256), cdiv(g.M, 4)), 256, 0, stream, x, w, bias, residual, y, g.M,
+                       Cin, Cout, g.ldx, g.ldy, g.ldr, alpha, relu);
     FOCR_LAUNCH_CHECK();
     return FOCR_OK;
   }

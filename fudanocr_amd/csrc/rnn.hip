@@ -148,18 +148,23 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(
 
 // whh: [2][4H][H] (forward direction then reverse), bhh: [2][4H]
 int focr_lstm_fwd_bx3(const float* gx, const float* whh, const float* bhh, float* hseq, float* gates, float* cseq,
-                      void* ws, int T, int B, int H, int st_t, int st_b, hipStream_t stream);
+                      void* ws, const void* wsplit, int T, int B, int H, int st_t, int st_b, hipStream_t stream);
 int focr_lstm_bwd_bx3(const float* dhseq, const float* whh, const float* gates, const float* cseq, float* dgx,
-                      float* dc_carry, void* ws, int T, int B, int H, int st_t, int st_b, hipStream_t stream);
+                      float* dc_carry, void* ws, const void* wsplit, int T, int B, int H, int st_t, int st_b,
+                      hipStream_t stream);
+int focr_lstm_split_weights(const float* whh, void* out, int H, int backward, hipStream_t stream);
 
 // ws: focr_lstm_ws_bytes(T,B,H,0) bytes (bf16 operand copies; only used in bf16x3 mode, may be null in fp32 mode)
-extern "C" int focr_lstm_bidir_fwd(const float* gx, const float* whh, const float* bhh, float* hseq,
-                                   float* gates, float* cseq, void* ws, int T, int B, int H, int st_t,
-                                   int st_b, hipStream_t stream) {
+// wsplit (the _pw entries; may be null): focr_lstm_split_bytes(H) bytes filled by focr_lstm_prepare_weights(whh, ...,
+// backward) -- a caller whose recurrent weights do not change between calls (the frozen recognizer of the training step)
+// prepares them once; the call then skips its weight-split launch.
+extern "C" int focr_lstm_bidir_fwd_pw(const float* gx, const float* whh, const float* bhh, float* hseq,
+                                      float* gates, float* cseq, void* ws, const void* wsplit, int T, int B, int H,
+                                      int st_t, int st_b, hipStream_t stream) {
   FOCR_CHECK_ARG(gx && whh && bhh && hseq && gates && cseq, "null pointer");
   FOCR_CHECK_ARG(T > 0 && B > 0 && H % 32 == 0, "need H % 32 == 0");
   if (focr_get_precision() != 0 && ws && H == 256) {
-    focr_lstm_fwd_bx3(gx, whh, bhh, hseq, gates, cseq, ws, T, B, H, st_t, st_b, stream);
+    focr_lstm_fwd_bx3(gx, whh, bhh, hseq, gates, cseq, ws, wsplit, T, B, H, st_t, st_b, stream);
     FOCR_LAUNCH_CHECK();
     return FOCR_OK;
   }
@@ -170,15 +175,20 @@ extern "C" int focr_lstm_bidir_fwd(const float* gx, const float* whh, const floa
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }
+extern "C" int focr_lstm_bidir_fwd(const float* gx, const float* whh, const float* bhh, float* hseq,
+                                   float* gates, float* cseq, void* ws, int T, int B, int H, int st_t,
+                                   int st_b, hipStream_t stream) {
+  return focr_lstm_bidir_fwd_pw(gx, whh, bhh, hseq, gates, cseq, ws, nullptr, T, B, H, st_t, st_b, stream);
+}
 
 // dc_carry: 2*B*H floats of workspace.  dgx is fully overwritten.
-extern "C" int focr_lstm_bidir_bwd(const float* dhseq, const float* whh, const float* gates,
-                                   const float* cseq, float* dgx, float* dc_carry, void* ws, int T, int B,
-                                   int H, int st_t, int st_b, hipStream_t stream) {
+extern "C" int focr_lstm_bidir_bwd_pw(const float* dhseq, const float* whh, const float* gates,
+                                      const float* cseq, float* dgx, float* dc_carry, void* ws, const void* wsplit,
+                                      int T, int B, int H, int st_t, int st_b, hipStream_t stream) {
   FOCR_CHECK_ARG(dhseq && whh && gates && cseq && dgx && dc_carry, "null pointer");
   FOCR_CHECK_ARG(T > 0 && B > 0 && H % 32 == 0, "need H % 32 == 0");
   if (focr_get_precision() != 0 && ws && H == 256) {
-    focr_lstm_bwd_bx3(dhseq, whh, gates, cseq, dgx, dc_carry, ws, T, B, H, st_t, st_b, stream);
+    focr_lstm_bwd_bx3(dhseq, whh, gates, cseq, dgx, dc_carry, ws, wsplit, T, B, H, st_t, st_b, stream);
     FOCR_LAUNCH_CHECK();
     return FOCR_OK;
   }
@@ -188,6 +198,20 @@ extern "C" int focr_lstm_bidir_bwd(const float* dhseq, const float* whh, const f
                        B, H, st_t, st_b);
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
+}
+extern "C" int focr_lstm_bidir_bwd(const float* dhseq, const float* whh, const float* gates,
+                                   const float* cseq, float* dgx, float* dc_carry, void* ws, int T, int B,
+                                   int H, int st_t, int st_b, hipStream_t stream) {
+  return focr_lstm_bidir_bwd_pw(dhseq, whh, gates, cseq, dgx, dc_carry, ws, nullptr, T, B, H, st_t, st_b, stream);
+}
+// hi / lo split of W_hh [2][4H][H] for the bf16x3 scans: backward = 0 -> [2][4H][H] (forward scan), 1 -> the transposed
+// [2][H][4H] (backward scan); hi plane then lo plane, focr_lstm_split_bytes(H) bytes.
+extern "C" long focr_lstm_split_bytes(int H) { return (long)2 * 2 * (2 * 4 * H * H); }
+extern "C" int focr_lstm_prepare_weights(const float* whh, void* out, int H, int backward, hipStream_t stream) {
+  FOCR_CHECK_ARG(whh && out && H > 0 && H % 32 == 0, "bad argument");
+  const int rc = focr_lstm_split_weights(whh, out, H, backward, stream);
+  FOCR_LAUNCH_CHECK();
+  return rc;
 }
 
 // =======================================================================================
@@ -1357,12 +1381,21 @@ extern "C" long focr_lstm_ws_bytes(int T, int B, int H, int backward) {
   return 2 * (w + s) + LP_FLAG_BYTES;          // + the step counters of the persistent kernels (at the end)
 }
 
+int focr_lstm_split_weights(const float* whh, void* out, int H, int backward, hipStream_t stream) {
+  const long nw = (long)2 * 4 * H * H;
+  if (backward) hipLaunchKernelGGL(split_bf16_kernel, dim3(512), 256, 0, stream, whh, reinterpret_cast<__bf16*>(out), nw, 4 * H, H, 1);
+  else hipLaunchKernelGGL(split_bf16_kernel, dim3(512), 256, 0, stream, whh, reinterpret_cast<__bf16*>(out), nw, 1, 1, 0);
+  return 0;
+}
+// wsplit (optional): the hi / lo split of W_hh prepared once by focr_lstm_prepare_weights (frozen recognizer: the same
+// every step) -- the per-call split launch is then skipped
 int focr_lstm_fwd_bx3(const float* gx, const float* whh, const float* bhh, float* hseq, float* gates, float* cseq,
-                      void* ws, int T, int B, int H, int st_t, int st_b, hipStream_t stream) {
+                      void* ws, const void* wsplit, int T, int B, int H, int st_t, int st_b, hipStream_t stream) {
   __bf16* whh2 = reinterpret_cast<__bf16*>(ws);
   long nw = (long)2 * 4 * H * H;
   __bf16* hseq2 = whh2 + 2 * nw;
-  hipLaunchKernelGGL(split_bf16_kernel, dim3(512), 256, 0, stream, whh, whh2, nw, 1, 1, 0);
+  if (wsplit) whh2 = const_cast<__bf16*>(reinterpret_cast<const __bf16*>(wsplit));
+  else hipLaunchKernelGGL(split_bf16_kernel, dim3(512), 256, 0, stream, whh, whh2, nw, 1, 1, 0);
   if (lp_usable(B, H)) {
     static focr_dev_flags attr;
     if (focr_dev_first(attr)) {
@@ -1386,13 +1419,15 @@ int focr_lstm_fwd_bx3(const float* gx, const float* whh, const float* bhh, float
   return 0;
 }
 int focr_lstm_bwd_bx3(const float* dhseq, const float* whh, const float* gates, const float* cseq, float* dgx,
-                      float* dc_carry, void* ws, int T, int B, int H, int st_t, int st_b, hipStream_t stream) {
+                      float* dc_carry, void* ws, const void* wsplit, int T, int B, int H, int st_t, int st_b,
+                      hipStream_t stream) {
   __bf16* whhT2 = reinterpret_cast<__bf16*>(ws);
   long nw = (long)2 * 4 * H * H;
   __bf16* dgx2 = whhT2 + 2 * nw;
   long ndg = (long)T * B * 8 * H;
   // whh [2][4H][H] -> whhT [2][H][4H] (hi plane then lo plane)
-  hipLaunchKernelGGL(split_bf16_kernel, dim3(512), 256, 0, stream, whh, whhT2, nw, 4 * H, H, 1);
+  if (wsplit) whhT2 = const_cast<__bf16*>(reinterpret_cast<const __bf16*>(wsplit));
+  else hipLaunchKernelGGL(split_bf16_kernel, dim3(512), 256, 0, stream, whh, whhT2, nw, 4 * H, H, 1);
   if (lp_usable(B, H)) {
     static focr_dev_flags attr;
     if (focr_dev_first(attr)) {

@@ -192,6 +192,7 @@ class TrainStep:
         # bench.py's N > 1 line: per step, the time the COMPUTE stream spends waiting for the exchange after the last
         # backward / weight-gradient kernel (event pair around the tail launches + waits) = the exposed communication
         self.comm_timing, self._comm_events = False, []
+        self._g100 = None
         self._plan_overlap(boundaries, tail)
 
     def _attach_packed_qkv(self):
@@ -396,7 +397,16 @@ class TrainStep:
                 # the zeroed flat gradient must be visible to the side stream before its kernels accumulate into it
                 c.side_enabled = True
                 c.side_stream().wait_stream(torch.cuda.current_stream())
-            (loss * 100).backward()
+            # (loss * 100).backward() of super_resolution.py:79-82, without its three scalar launches on the critical path
+            # (the multiply, the seed fill, the multiply's backward): loss = mse [+ ctc], so the same gradient -- exactly
+            # 100.0 -- is fed into the loss terms directly
+            if self._g100 is None or self._g100.device != loss.device:
+                self._g100 = torch.full((), 100.0, device=loss.device)
+            terms = [t for t in (mse, ctc) if torch.is_tensor(t) and t.requires_grad]
+            if torch.is_tensor(ctc) and loss.grad_fn is not None and len(terms) == 2:
+                torch.autograd.backward(terms, [self._g100.expand(t.shape) for t in terms])
+            else:
+                (loss * 100).backward()
             c.flush_side()             # weight gradients the last block parked (kernels.StepContext.defer_side)
             c.flush_tail()             # ... and anything still parked for the tail (no TPS warp in this model)
         finally:

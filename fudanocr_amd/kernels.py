@@ -1719,6 +1719,32 @@ def _lstm_check(ws, batch):
         raise RuntimeError("persistent LSTM scan: a step-counter wait timed out (partner blocks not resident)")
 
 
+# Frozen recurrent weights (the recognizer of the training step): their bf16 hi / lo split -- and, for the backward scan,
+# the transposed split -- is the same in every step.  Prepared once per (tensor, version) and handed to the scans
+# (focr_lstm_bidir_*_pw), which then skip their per-call split launch (4 launches + 4 dependent gaps per step).  A call
+# with TRAINABLE weights drops the entry: raw-pointer optimisers change them behind autograd's version counter.
+_LSTM_SPLIT = {}      # id(whh) -> (weakref, version, data_ptr, {backward flag: uint8 tensor})
+
+
+def _lstm_prepared(whh, backward):
+    if whh.requires_grad or not whh.is_cuda or whh.shape[-1] != 256 or _lib.get_precision() == 0:
+        _LSTM_SPLIT.pop(id(whh), None)
+        return None
+    e = _LSTM_SPLIT.get(id(whh))
+    if e is None or e[0]() is not whh or e[1] != whh._version or e[2] != whh.data_ptr():
+        if len(_LSTM_SPLIT) > 64:
+            for k_ in [k_ for k_, v_ in _LSTM_SPLIT.items() if v_[0]() is None]:
+                del _LSTM_SPLIT[k_]
+        e = (weakref.ref(whh), whh._version, whh.data_ptr(), {})
+        _LSTM_SPLIT[id(whh)] = e
+    buf = e[3].get(backward)
+    if buf is None:
+        buf = torch.empty(_lib.load().focr_lstm_split_bytes(256), device=whh.device, dtype=torch.uint8)
+        _lib.call("focr_lstm_prepare_weights", _p(whh), ctypes.c_void_p(buf.data_ptr()), 256, int(backward), _stream())
+        e[3][backward] = buf
+    return buf
+
+
 class _LSTMRecur(torch.autograd.Function):
     """gx: [rows, 2*4H] with row(t,b) = t*st_t + b*st_b;  returns hseq [T,B,2H].
     Gradients: gx always; W_hh / b_hh when they require one (trainable recognizer):
@@ -1735,8 +1761,9 @@ class _LSTMRecur(torch.autograd.Function):
         ws = torch.empty(_lib.load().focr_lstm_ws_bytes(t_len, batch, hid, 0), device=gx.device, dtype=torch.uint8)
         if ctx.needs_input_grad[0]:
             current_context().prefetch_masks_early()
-        _lib.call("focr_lstm_bidir_fwd", _p(gx), _p(whh), _p(bhh), _p(hseq), _p(gates), _p(cseq), _p(ws), t_len,
-                  batch, hid, st_t, st_b, _stream())
+        wsp = _lstm_prepared(whh, 0)
+        _lib.call("focr_lstm_bidir_fwd_pw", _p(gx), _p(whh), _p(bhh), _p(hseq), _p(gates), _p(cseq), _p(ws),
+                  ctypes.c_void_p(wsp.data_ptr()) if wsp is not None else _NULL, t_len, batch, hid, st_t, st_b, _stream())
         _lstm_check(ws, batch)
         ctx.cfg = (t_len, batch, hid, st_t, st_b, tuple(gx.shape))
         ctx.save_for_backward(whh, gates, cseq, hseq if (whh.requires_grad or bhh.requires_grad) else None)
@@ -1750,8 +1777,9 @@ class _LSTMRecur(torch.autograd.Function):
         dgx = torch.empty(gshape, device=dh.device)
         carry = torch.empty((2, batch, hid), device=dh.device)
         ws = torch.empty(_lib.load().focr_lstm_ws_bytes(t_len, batch, hid, 1), device=dh.device, dtype=torch.uint8)
-        _lib.call("focr_lstm_bidir_bwd", _p(dh), _p(whh), _p(gates), _p(cseq), _p(dgx), _p(carry), _p(ws), t_len,
-                  batch, hid, st_t, st_b, _stream())
+        wsp = _lstm_prepared(whh, 1)
+        _lib.call("focr_lstm_bidir_bwd_pw", _p(dh), _p(whh), _p(gates), _p(cseq), _p(dgx), _p(carry), _p(ws),
+                  ctypes.c_void_p(wsp.data_ptr()) if wsp is not None else _NULL, t_len, batch, hid, st_t, st_b, _stream())
         _lstm_check(ws, batch)
         dwhh = dbhh = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:

@@ -335,6 +335,17 @@ int focr_lstm_bidir_fwd(const float* gx, const float* whh, const float* bhh, flo
 int focr_lstm_bidir_bwd(const float* dhseq, const float* whh, const float* gates, const float* cseq,
                         float* dgx, float* dc_carry /*2*B*H*/, void* ws, int T, int B, int H, int st_t,
                         int st_b, focr_stream_t stream);
+/* The same scans with the hi / lo split of W_hh prepared ONCE (focr_lstm_prepare_weights: backward = 0 for the forward scan's
+ * [2][4H][H] form, 1 for the backward scan's transposed form; focr_lstm_split_bytes(H) bytes each): a caller whose recurrent
+ * weights do not change between calls -- the frozen recognizer of the training step, super_resolution.py:168-171 -- skips
+ * the per-call split launch.  wsplit == NULL: identical to the entries above. */
+long focr_lstm_split_bytes(int H);
+int focr_lstm_prepare_weights(const float* whh, void* out, int H, int backward, focr_stream_t stream);
+int focr_lstm_bidir_fwd_pw(const float* gx, const float* whh, const float* bhh, float* hseq, float* gates, float* cseq,
+                           void* ws, const void* wsplit, int T, int B, int H, int st_t, int st_b, focr_stream_t stream);
+int focr_lstm_bidir_bwd_pw(const float* dhseq, const float* whh, const float* gates, const float* cseq, float* dgx,
+                           float* dc_carry, void* ws, const void* wsplit, int T, int B, int H, int st_t, int st_b,
+                           focr_stream_t stream);
 /* nn.GRU(64, 32, bidirectional, batch_first) tsrn.py:133,141 (gate order r,z,n).  All tensors are
  * indexed by map row: row(seq n, time t) = (n/IC)*OS + (n%IC)*IS + t*TS, so both the horizontal
  * (gru2) and the vertical (gru1, reference transposes the map) scans read the NHWC map in place.

@@ -214,7 +214,10 @@ def test_conv2d_fused_epilogue(precision):
 
 
 @pytest.mark.parametrize("rows,nin,nout,alpha", [(300, 128, 128, 1.0), (7, 512, 40, 0.1), (130, 512, 37, 1.0),
-                                                 (2048, 128, 64, 1.0)])
+                                                 (2048, 128, 64, 1.0),
+                                                 # the STN head's fc2 at the bench batch: its data gradient ([128 x 40] .
+                                                 # [40 x 512], K % 32 != 0) runs on tiny_linear_kernel (round 5)
+                                                 (128, 512, 40, 0.1), (130, 512, 36, 1.0)])
 def test_linear(rows, nin, nout, alpha, precision):
     x = rnd(rows, nin, seed=1).requires_grad_(True)
     wt = rnd(nout, nin, seed=2, scale=1 / math.sqrt(nin)).requires_grad_(True)
