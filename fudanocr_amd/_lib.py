@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FOCR_LIB") or os.path.join(_HERE, "libfocr_hip.so")
 
 P, I, L, F, U = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_uint64
+U32 = ctypes.c_uint32
 
 # name -> argument types (every entry point returns int and takes the stream last)
 SIGNATURES = {
@@ -77,10 +78,11 @@ SIGNATURES = {
     "focr_bicubic_gray_bwd": [P, P, I, I, I, I, I, P],
     "focr_lstm_bidir_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, P],
     "focr_lstm_bidir_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, P],
-    "focr_lstm_bidir_fwd_pw": [P, P, P, P, P, P, P, P, I, I, I, I, I, P],
-    "focr_lstm_bidir_bwd_pw": [P, P, P, P, P, P, P, P, I, I, I, I, I, P],
+    "focr_lstm_bidir_fwd_pw": [P, P, P, P, P, P, P, P, P, U32, I, I, I, I, I, P],
+    "focr_lstm_bidir_bwd_pw": [P, P, P, P, P, P, P, P, P, U32, I, I, I, I, I, P],
     "focr_lstm_prepare_weights": [P, P, I, I, P],
     "focr_lstm_split_bytes": [I],
+    "focr_lstm_persistent_usable": [I, I],
     "focr_gru_bidir_fwd": [P, P, P, P, P, I, I, I, I, I, I, P],
     "focr_gru_bidir_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     "focr_conv9x9_small_cout_fwd": [P, P, P, P, I, I, I, I, I, P],

@@ -148,10 +148,11 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(
 
 // whh: [2][4H][H] (forward direction then reverse), bhh: [2][4H]
 int focr_lstm_fwd_bx3(const float* gx, const float* whh, const float* bhh, float* hseq, float* gates, float* cseq,
-                      void* ws, const void* wsplit, int T, int B, int H, int st_t, int st_b, hipStream_t stream);
-int focr_lstm_bwd_bx3(const float* dhseq, const float* whh, const float* gates, const float* cseq, float* dgx,
-                      float* dc_carry, void* ws, const void* wsplit, int T, int B, int H, int st_t, int st_b,
+                      void* ws, const void* wsplit, void* pflags, unsigned base, int T, int B, int H, int st_t, int st_b,
                       hipStream_t stream);
+int focr_lstm_bwd_bx3(const float* dhseq, const float* whh, const float* gates, const float* cseq, float* dgx,
+                      float* dc_carry, void* ws, const void* wsplit, void* pflags, unsigned base, int T, int B, int H,
+                      int st_t, int st_b, hipStream_t stream);
 int focr_lstm_split_weights(const float* whh, void* out, int H, int backward, hipStream_t stream);
 
 // ws: focr_lstm_ws_bytes(T,B,H,0) bytes (bf16 operand copies; only used in bf16x3 mode, may be null in fp32 mode)
@@ -159,12 +160,12 @@ int focr_lstm_split_weights(const float* whh, void* out, int H, int backward, hi
 // backward) -- a caller whose recurrent weights do not change between calls (the frozen recognizer of the training step)
 // prepares them once; the call then skips its weight-split launch.
 extern "C" int focr_lstm_bidir_fwd_pw(const float* gx, const float* whh, const float* bhh, float* hseq,
-                                      float* gates, float* cseq, void* ws, const void* wsplit, int T, int B, int H,
-                                      int st_t, int st_b, hipStream_t stream) {
+                                      float* gates, float* cseq, void* ws, const void* wsplit, void* pflags,
+                                      unsigned base, int T, int B, int H, int st_t, int st_b, hipStream_t stream) {
   FOCR_CHECK_ARG(gx && whh && bhh && hseq && gates && cseq, "null pointer");
   FOCR_CHECK_ARG(T > 0 && B > 0 && H % 32 == 0, "need H % 32 == 0");
   if (focr_get_precision() != 0 && ws && H == 256) {
-    focr_lstm_fwd_bx3(gx, whh, bhh, hseq, gates, cseq, ws, wsplit, T, B, H, st_t, st_b, stream);
+    focr_lstm_fwd_bx3(gx, whh, bhh, hseq, gates, cseq, ws, wsplit, pflags, base, T, B, H, st_t, st_b, stream);
     FOCR_LAUNCH_CHECK();
     return FOCR_OK;
   }
@@ -178,17 +179,18 @@ extern "C" int focr_lstm_bidir_fwd_pw(const float* gx, const float* whh, const f
 extern "C" int focr_lstm_bidir_fwd(const float* gx, const float* whh, const float* bhh, float* hseq,
                                    float* gates, float* cseq, void* ws, int T, int B, int H, int st_t,
                                    int st_b, hipStream_t stream) {
-  return focr_lstm_bidir_fwd_pw(gx, whh, bhh, hseq, gates, cseq, ws, nullptr, T, B, H, st_t, st_b, stream);
+  return focr_lstm_bidir_fwd_pw(gx, whh, bhh, hseq, gates, cseq, ws, nullptr, nullptr, 0u, T, B, H, st_t, st_b, stream);
 }
 
 // dc_carry: 2*B*H floats of workspace.  dgx is fully overwritten.
 extern "C" int focr_lstm_bidir_bwd_pw(const float* dhseq, const float* whh, const float* gates,
                                       const float* cseq, float* dgx, float* dc_carry, void* ws, const void* wsplit,
-                                      int T, int B, int H, int st_t, int st_b, hipStream_t stream) {
+                                      void* pflags, unsigned base, int T, int B, int H, int st_t, int st_b,
+                                      hipStream_t stream) {
   FOCR_CHECK_ARG(dhseq && whh && gates && cseq && dgx && dc_carry, "null pointer");
   FOCR_CHECK_ARG(T > 0 && B > 0 && H % 32 == 0, "need H % 32 == 0");
   if (focr_get_precision() != 0 && ws && H == 256) {
-    focr_lstm_bwd_bx3(dhseq, whh, gates, cseq, dgx, dc_carry, ws, wsplit, T, B, H, st_t, st_b, stream);
+    focr_lstm_bwd_bx3(dhseq, whh, gates, cseq, dgx, dc_carry, ws, wsplit, pflags, base, T, B, H, st_t, st_b, stream);
     FOCR_LAUNCH_CHECK();
     return FOCR_OK;
   }
@@ -202,7 +204,13 @@ extern "C" int focr_lstm_bidir_bwd_pw(const float* dhseq, const float* whh, cons
 extern "C" int focr_lstm_bidir_bwd(const float* dhseq, const float* whh, const float* gates,
                                    const float* cseq, float* dgx, float* dc_carry, void* ws, int T, int B,
                                    int H, int st_t, int st_b, hipStream_t stream) {
-  return focr_lstm_bidir_bwd_pw(dhseq, whh, gates, cseq, dgx, dc_carry, ws, nullptr, T, B, H, st_t, st_b, stream);
+  return focr_lstm_bidir_bwd_pw(dhseq, whh, gates, cseq, dgx, dc_carry, ws, nullptr, nullptr, 0u, T, B, H, st_t, st_b, stream);
+}
+// 1 when focr_lstm_bidir_* would run this shape as ONE persistent launch (tuning key 2, residency, H): only then are the
+// step counters of a caller-owned flag block touched (a caller that keeps a running `base` advances it only then).
+static bool lp_usable(int B, int H);
+extern "C" int focr_lstm_persistent_usable(int B, int H) {
+  return (focr_get_precision() != 0 && H == 256 && lp_usable(B, H)) ? 1 : 0;
 }
 // hi / lo split of W_hh [2][4H][H] for the bf16x3 scans: backward = 0 -> [2][4H][H] (forward scan), 1 -> the transposed
 // [2][H][4H] (backward scan); hi plane then lo plane, focr_lstm_split_bytes(H) bytes.
@@ -874,7 +882,7 @@ __device__ __forceinline__ void lp_wait(unsigned* flag, unsigned target, unsigne
 #endif
   if (threadIdx.x == 0) {
     int spins = 0;
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {     // (wrap-safe)
       if (++spins > LSTM_SPIN_LIMIT) {
         __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *bad = 1u;
@@ -983,7 +991,7 @@ extern "C" int focr_lstm_trace_dump(unsigned long long* host_stamps, unsigned* h
 __global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
     const float* __restrict__ gx, const __bf16* __restrict__ whh2, const float* __restrict__ bhh,
     float* __restrict__ hseq, __bf16* __restrict__ hseq2, float* __restrict__ gates, float* __restrict__ cseq,
-    unsigned* __restrict__ flags, int T, int B, int st_t, int st_b, int ngroups, int allow_fast) {
+    unsigned* __restrict__ flags, int T, int B, int st_t, int st_b, int ngroups, int allow_fast, unsigned base) {
   constexpr int H = 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char lp_smem[];
   __bf16* Wh = reinterpret_cast<__bf16*>(lp_smem);              // [128][LP_WP]
@@ -1065,7 +1073,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     if (step > 0) {
-      lp_wait(flag, 8u * (unsigned)step, err, &lp_bad);
+      lp_wait(flag, base + 8u * (unsigned)step, err, &lp_bad);
       if (step == 1 && allow_fast) {                    // all 8 partners have voted: may the releases stay inside the XCD?
         if (threadIdx.x == 0) lp_fast = lp_same_xcd(xmask) ? 1u : 0u;
         __syncthreads();
@@ -1170,7 +1178,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_persist_bx3_kernel(
 __global__ __launch_bounds__(512) void lstm_bwd_persist_bx3_kernel(
     const float* __restrict__ dhseq, const __bf16* __restrict__ whhT2, const float* __restrict__ gates,
     const float* __restrict__ cseq, float* __restrict__ dgx, __bf16* __restrict__ dgx2, unsigned* __restrict__ flags,
-    int T, int B, int st_t, int st_b, long ndg, int ngroups, int allow_fast) {
+    int T, int B, int st_t, int st_b, long ndg, int ngroups, int allow_fast, unsigned base) {
   constexpr int H = 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char lp_smem[];
   __bf16* Wh = reinterpret_cast<__bf16*>(lp_smem);              // [32 units][LP_WTP]  (W_hh^T rows: n over 4H)
@@ -1243,7 +1251,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_persist_bx3_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     if (step > 0) {
-      lp_wait(flag, 8u * (unsigned)step, err, &lp_bad);
+      lp_wait(flag, base + 8u * (unsigned)step, err, &lp_bad);
       if (step == 1 && allow_fast) {                    // all 8 partners have voted: may the releases stay inside the XCD?
         if (threadIdx.x == 0) lp_fast = lp_same_xcd(xmask) ? 1u : 0u;
         __syncthreads();
@@ -1389,8 +1397,12 @@ int focr_lstm_split_weights(const float* whh, void* out, int H, int backward, hi
 }
 // wsplit (optional): the hi / lo split of W_hh prepared once by focr_lstm_prepare_weights (frozen recognizer: the same
 // every step) -- the per-call split launch is then skipped
+// pflags (optional, with `base`): a caller-owned, never re-zeroed block of LP_FLAG_BYTES whose step counters simply keep
+// counting -- every call adds 8 (T - 1) to each of its groups' words, the caller passes the sum so far as `base` (targets
+// are compared modulo 2^32) -- instead of the workspace tail + a memset launch in front of every scan
 int focr_lstm_fwd_bx3(const float* gx, const float* whh, const float* bhh, float* hseq, float* gates, float* cseq,
-                      void* ws, const void* wsplit, int T, int B, int H, int st_t, int st_b, hipStream_t stream) {
+                      void* ws, const void* wsplit, void* pflags, unsigned base, int T, int B, int H, int st_t, int st_b,
+                      hipStream_t stream) {
   __bf16* whh2 = reinterpret_cast<__bf16*>(ws);
   long nw = (long)2 * 4 * H * H;
   __bf16* hseq2 = whh2 + 2 * nw;
@@ -1403,13 +1415,16 @@ int focr_lstm_fwd_bx3(const float* gx, const float* whh, const float* bhh, float
                                 LP_FWD_LDS);
       focr_dev_mark(attr);
     }
-    unsigned* flags = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + focr_lstm_ws_bytes(T, B, H, 0) -
-                                                  LP_FLAG_BYTES);
-    (void)hipMemsetAsync(flags, 0, LP_FLAG_BYTES, stream);
+    unsigned* flags = reinterpret_cast<unsigned*>(pflags);
+    if (!flags) {
+      flags = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + focr_lstm_ws_bytes(T, B, H, 0) - LP_FLAG_BYTES);
+      (void)hipMemsetAsync(flags, 0, LP_FLAG_BYTES, stream);
+      base = 0u;
+    }
     const int ngroups = cdiv(B, 32) * 2;
     hipLaunchKernelGGL(lstm_fwd_persist_bx3_kernel, dim3(8 * ngroups), 512, LP_FWD_LDS, stream, gx,
                        (const __bf16*)whh2, bhh, hseq, hseq2, gates, cseq, flags, T, B, st_t, st_b, ngroups,
-                       focr_get_tuning(FOCR_TUNE_LSTM_PERSISTENT) != 2);
+                       focr_get_tuning(FOCR_TUNE_LSTM_PERSISTENT) != 2, base);
     return 0;
   }
   dim3 grid(H / 32, (B + 31) / 32, 2);
@@ -1419,8 +1434,8 @@ int focr_lstm_fwd_bx3(const float* gx, const float* whh, const float* bhh, float
   return 0;
 }
 int focr_lstm_bwd_bx3(const float* dhseq, const float* whh, const float* gates, const float* cseq, float* dgx,
-                      float* dc_carry, void* ws, const void* wsplit, int T, int B, int H, int st_t, int st_b,
-                      hipStream_t stream) {
+                      float* dc_carry, void* ws, const void* wsplit, void* pflags, unsigned base, int T, int B, int H,
+                      int st_t, int st_b, hipStream_t stream) {
   __bf16* whhT2 = reinterpret_cast<__bf16*>(ws);
   long nw = (long)2 * 4 * H * H;
   __bf16* dgx2 = whhT2 + 2 * nw;
@@ -1435,13 +1450,16 @@ int focr_lstm_bwd_bx3(const float* dhseq, const float* whh, const float* gates, 
                                 LP_BWD_LDS);
       focr_dev_mark(attr);
     }
-    unsigned* flags = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + focr_lstm_ws_bytes(T, B, H, 1) -
-                                                  LP_FLAG_BYTES);
-    (void)hipMemsetAsync(flags, 0, LP_FLAG_BYTES, stream);
+    unsigned* flags = reinterpret_cast<unsigned*>(pflags);
+    if (!flags) {
+      flags = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + focr_lstm_ws_bytes(T, B, H, 1) - LP_FLAG_BYTES);
+      (void)hipMemsetAsync(flags, 0, LP_FLAG_BYTES, stream);
+      base = 0u;
+    }
     const int ngroups = cdiv(B, 32) * 2;
     hipLaunchKernelGGL(lstm_bwd_persist_bx3_kernel, dim3(8 * ngroups), 512, LP_BWD_LDS, stream, dhseq,
                        (const __bf16*)whhT2, gates, cseq, dgx, dgx2, flags, T, B, st_t, st_b, ndg, ngroups,
-                       focr_get_tuning(FOCR_TUNE_LSTM_PERSISTENT) != 2);
+                       focr_get_tuning(FOCR_TUNE_LSTM_PERSISTENT) != 2, base);
     return 0;
   }
   dim3 grid(H / 32, (B + 31) / 32, 2);

@@ -1712,9 +1712,10 @@ def _lstm_check(ws, batch):
     if os.environ.get("FOCR_LSTM_CHECK", "0") != "1":
         return
     ngroups = (batch + 31) // 32 * 2
-    if _lib.load().focr_get_tuning(2) != 1 or _lib.get_precision() == 0 or 8 * ngroups > 256:
+    if _lib.load().focr_get_tuning(2) == 0 or _lib.get_precision() == 0 or 8 * ngroups > 256:
         return                                           # per-step launches: the flag words are not used
-    flags = ws[-1024:].view(torch.int32)                 # rnn.hip LP_FLAG_BYTES at the end of the workspace
+    # rnn.hip LP_FLAG_BYTES at the end of the workspace, or the call site's persistent flag block (_lstm_flags)
+    flags = ws if ws.dtype == torch.int32 else ws[-1024:].view(torch.int32)
     if int(flags[ngroups].item()) != 0:
         raise RuntimeError("persistent LSTM scan: a step-counter wait timed out (partner blocks not resident)")
 
@@ -1745,6 +1746,25 @@ def _lstm_prepared(whh, backward):
     return buf
 
 
+def _lstm_flags(whh, backward, batch, t_len):
+    """(flags tensor, base) of the persistent scan at this call site -- (frozen weights, pass, batch, T) -- or (None, 0).
+    The step counters are zeroed ONCE and keep counting: a scan adds 8 (T - 1) to each of its groups' words, so the next
+    call's targets start at the running sum (mod 2^32) and no memset launch precedes the scan.  Calls of one site are
+    ordered by the stream; two streams scanning with the SAME weights at the same time would share the words -- the sites
+    of this library (one recognizer per engine step) never do."""
+    e = _LSTM_SPLIT.get(id(whh))
+    if e is None or e[0]() is not whh or not _lib.load().focr_lstm_persistent_usable(int(batch), 256):
+        return None, 0                      # (per-step launches do not touch the counters: the base must not advance)
+    key = ("flags", int(backward), int(batch), int(t_len), torch.cuda.current_stream().cuda_stream)
+    st = e[3].get(key)
+    if st is None:
+        st = [torch.zeros(256, device=whh.device, dtype=torch.int32), 0]
+        e[3][key] = st
+    base = st[1]
+    st[1] = (base + 8 * (t_len - 1)) & 0xFFFFFFFF
+    return st[0], base
+
+
 class _LSTMRecur(torch.autograd.Function):
     """gx: [rows, 2*4H] with row(t,b) = t*st_t + b*st_b;  returns hseq [T,B,2H].
     Gradients: gx always; W_hh / b_hh when they require one (trainable recognizer):
@@ -1762,9 +1782,12 @@ class _LSTMRecur(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             current_context().prefetch_masks_early()
         wsp = _lstm_prepared(whh, 0)
+        fl, base = _lstm_flags(whh, 0, batch, t_len) if wsp is not None else (None, 0)
         _lib.call("focr_lstm_bidir_fwd_pw", _p(gx), _p(whh), _p(bhh), _p(hseq), _p(gates), _p(cseq), _p(ws),
-                  ctypes.c_void_p(wsp.data_ptr()) if wsp is not None else _NULL, t_len, batch, hid, st_t, st_b, _stream())
-        _lstm_check(ws, batch)
+                  ctypes.c_void_p(wsp.data_ptr()) if wsp is not None else _NULL,
+                  ctypes.c_void_p(fl.data_ptr()) if fl is not None else _NULL, base, t_len, batch, hid, st_t, st_b,
+                  _stream())
+        _lstm_check(ws if fl is None else fl, batch)
         ctx.cfg = (t_len, batch, hid, st_t, st_b, tuple(gx.shape))
         ctx.save_for_backward(whh, gates, cseq, hseq if (whh.requires_grad or bhh.requires_grad) else None)
         return hseq
@@ -1778,9 +1801,12 @@ class _LSTMRecur(torch.autograd.Function):
         carry = torch.empty((2, batch, hid), device=dh.device)
         ws = torch.empty(_lib.load().focr_lstm_ws_bytes(t_len, batch, hid, 1), device=dh.device, dtype=torch.uint8)
         wsp = _lstm_prepared(whh, 1)
+        fl, base = _lstm_flags(whh, 1, batch, t_len) if wsp is not None else (None, 0)
         _lib.call("focr_lstm_bidir_bwd_pw", _p(dh), _p(whh), _p(gates), _p(cseq), _p(dgx), _p(carry), _p(ws),
-                  ctypes.c_void_p(wsp.data_ptr()) if wsp is not None else _NULL, t_len, batch, hid, st_t, st_b, _stream())
-        _lstm_check(ws, batch)
+                  ctypes.c_void_p(wsp.data_ptr()) if wsp is not None else _NULL,
+                  ctypes.c_void_p(fl.data_ptr()) if fl is not None else _NULL, base, t_len, batch, hid, st_t, st_b,
+                  _stream())
+        _lstm_check(ws if fl is None else fl, batch)
         dwhh = dbhh = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             rows = t_len * batch

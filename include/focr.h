@@ -338,14 +338,20 @@ int focr_lstm_bidir_bwd(const float* dhseq, const float* whh, const float* gates
 /* The same scans with the hi / lo split of W_hh prepared ONCE (focr_lstm_prepare_weights: backward = 0 for the forward scan's
  * [2][4H][H] form, 1 for the backward scan's transposed form; focr_lstm_split_bytes(H) bytes each): a caller whose recurrent
  * weights do not change between calls -- the frozen recognizer of the training step, super_resolution.py:168-171 -- skips
- * the per-call split launch.  wsplit == NULL: identical to the entries above. */
+ * the per-call split launch.  pflags (optional, FOCR_LSTM_FLAG_BYTES bytes, zeroed ONCE by the caller and then owned by one
+ * (weights, B, T) call site) + base: the persistent scans' step counters keep counting across calls instead of being cleared
+ * by a memset launch in front of every scan; every call advances each group's word by 8 (T - 1) and the caller passes the sum
+ * so far (mod 2^32) as `base`.  wsplit == NULL and pflags == NULL: identical to the entries above. */
+#define FOCR_LSTM_FLAG_BYTES 1024
+int focr_lstm_persistent_usable(int B, int H);  /* 1: this shape runs as one persistent launch (pflags / base are used) */
 long focr_lstm_split_bytes(int H);
 int focr_lstm_prepare_weights(const float* whh, void* out, int H, int backward, focr_stream_t stream);
 int focr_lstm_bidir_fwd_pw(const float* gx, const float* whh, const float* bhh, float* hseq, float* gates, float* cseq,
-                           void* ws, const void* wsplit, int T, int B, int H, int st_t, int st_b, focr_stream_t stream);
+                           void* ws, const void* wsplit, void* pflags, unsigned base, int T, int B, int H, int st_t,
+                           int st_b, focr_stream_t stream);
 int focr_lstm_bidir_bwd_pw(const float* dhseq, const float* whh, const float* gates, const float* cseq, float* dgx,
-                           float* dc_carry, void* ws, const void* wsplit, int T, int B, int H, int st_t, int st_b,
-                           focr_stream_t stream);
+                           float* dc_carry, void* ws, const void* wsplit, void* pflags, unsigned base, int T, int B, int H,
+                           int st_t, int st_b, focr_stream_t stream);
 /* nn.GRU(64, 32, bidirectional, batch_first) tsrn.py:133,141 (gate order r,z,n).  All tensors are
  * indexed by map row: row(seq n, time t) = (n/IC)*OS + (n%IC)*IS + t*TS, so both the horizontal
  * (gru2) and the vertical (gru1, reference transposes the map) scans read the NHWC map in place.
