@@ -605,7 +605,9 @@ class _Conv2d(torch.autograd.Function):
             # Weight gradients that land in the engine's flat buffer feed nothing inside backward: they run on the
             # side stream, concurrently with the data-gradient chain on the main stream (both kinds of kernels are
             # latency/occupancy bound, not throughput bound).  The engine joins the streams before the optimiser.
-            side = step.side_stream() if (tw is not None and (db is None or tb is not None)) else None
+            # (a layer WITHOUT a data gradient -- the first layer of a network, i.e. the last node of backward -- has nothing on
+            # the main stream to overlap with: its weight gradient runs in line, no cross-stream hand-off at the tail of the step)
+            side = step.side_stream() if (tw is not None and (db is None or tb is not None) and ctx.needs_input_grad[0]) else None
             if side is not None and residual_shares_dy:
                 # the residual's gradient IS dy4's storage and leaves this backward: autograd may accumulate into it in
                 # place on the main stream while the side-stream weight-gradient kernel still reads it -> hand out a copy
