@@ -383,15 +383,31 @@ class TrainStep:
         on_gpu = self.flat.flat_grad.is_cuda
         c = self.ctx
         c.frags = self.frags if on_gpu else None
+        flip_ev = None
         if on_gpu:
             self.frags.refresh()
             c.prefetch_masks()
+            if self.flips.built and self.flips.n_live:
+                # the flipped weights of the data-gradient GEMMs depend on the parameters only: re-flipped at the START of
+                # the step on the side stream (idle during the forward pass) instead of between loss and backward on the
+                # main stream (19 us + a dependent launch on the critical path); backward waits for the event
+                if c.side_stream_obj is None:
+                    c.side_stream_obj = torch.cuda.Stream()
+                side = c.side_stream_obj
+                side.wait_stream(torch.cuda.current_stream())      # the previous step's optimiser and backward are behind it
+                with torch.cuda.stream(side):
+                    self.flips.refresh()
+                    flip_ev = torch.cuda.Event()
+                    flip_ev.record(side)
         try:
             with K.use_context(c):
                 sr = self.model(images_lr)
                 loss, mse, _, ctc = self.crit(sr, images_hr, label_strs, encoded)
             if on_gpu:
-                self.flips.refresh()
+                if flip_ev is not None:
+                    torch.cuda.current_stream().wait_event(flip_ev)
+                else:
+                    self.flips.refresh()
                 c.flips = self.flips
             if on_gpu and self.wgrad_side_stream:
                 # the zeroed flat gradient must be visible to the side stream before its kernels accumulate into it
