@@ -198,11 +198,7 @@ __global__ __launch_bounds__(256) void tps_fwd_kernel(const float* __restrict__ 
 }
 
 // d ctrl only (the warped tensor is the input image: no parameter lives upstream of it)
-// (round 5: 1024 threads -- one pixel of a 16 x 64 map per thread -- instead of 256 x 4 pixels: the kernel is one block per
-// image on half of the CUs and sits on the step's critical path (first node of the STN head's backward): its time is the
-// dependent-load latency of a pixel times the pixels per thread)
-#define TPS_BWD_THREADS 1024
-__global__ __launch_bounds__(TPS_BWD_THREADS) void tps_bwd_kernel(const float* __restrict__ dout,   // [B,H,W,C]
+__global__ __launch_bounds__(256) void tps_bwd_kernel(const float* __restrict__ dout,   // [B,H,W,C]
                                                       const float* __restrict__ img,
                                                       const float* __restrict__ src,
                                                       const float* __restrict__ invk,
@@ -210,7 +206,7 @@ __global__ __launch_bounds__(TPS_BWD_THREADS) void tps_bwd_kernel(const float* _
                                                       float* __restrict__ dctrl,        // [B,NC,2]
                                                       int H, int W, int C, int NC) {
   __shared__ float dmap[TPS_MAXK][2];
-  __shared__ float red[TPS_BWD_THREADS / 64][TPS_MAXK][2];
+  __shared__ float red[4][TPS_MAXK][2];
   const int b = blockIdx.x, K = NC + 3;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float* im = img + (size_t)b * H * W * C;
@@ -257,10 +253,7 @@ __global__ __launch_bounds__(TPS_BWD_THREADS) void tps_bwd_kernel(const float* _
   __syncthreads();
   if (threadIdx.x < 2 * K) {
     int j = threadIdx.x >> 1, d = threadIdx.x & 1;
-    float t = 0.f;
-#pragma unroll
-    for (int w_ = 0; w_ < TPS_BWD_THREADS / 64; ++w_) t += red[w_][j][d];      // fixed order
-    dmap[j][d] = t;
+    dmap[j][d] = red[0][j][d] + red[1][j][d] + red[2][j][d] + red[3][j][d];
   }
   __syncthreads();
   if (threadIdx.x < 2 * NC) {
@@ -458,8 +451,7 @@ extern "C" int focr_tps_bwd(const float* dout, const float* img, const float* sr
                             hipStream_t stream) {
   FOCR_CHECK_ARG(dout && img && src && inv_kernel && coord_repr && dctrl, "null pointer");
   FOCR_CHECK_ARG(B > 0 && NC + 3 <= TPS_MAXK && 2 * (NC + 3) <= 256, "too many control points");
-  hipLaunchKernelGGL(tps_bwd_kernel, dim3(B), TPS_BWD_THREADS, 0, stream, dout, img, src, inv_kernel, coord_repr, dctrl, H, W, C,
-                     NC);
+  hipLaunchKernelGGL(tps_bwd_kernel, dim3(B), 256, 0, stream, dout, img, src, inv_kernel, coord_repr, dctrl, H, W, C, NC);
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }
