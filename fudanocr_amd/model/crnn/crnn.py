@@ -52,6 +52,8 @@ class BidirectionalLSTM(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.rnn.parameters()):
             # trainable recognizer (optimise the CRNN together with the SR net): pack through autograd so
             # the gradients of the packed operands flow back to the eight nn.LSTM parameters
+            self._packed = None        # an engine may rewrite them through raw pointers (no version bump): the frozen-path
+            #                            pack -- and with it kernels._lstm_prepared's split, keyed by that tensor -- is void
             r = self.rnn
             wih = torch.cat([r.weight_ih_l0, r.weight_ih_l0_reverse], 0)
             whh = torch.stack([r.weight_hh_l0, r.weight_hh_l0_reverse], 0)
