@@ -355,3 +355,35 @@ def test_bench_self_launch_plumbing():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--check-launch"],
                        env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE=2" in (p.stdout + p.stderr)
+
+
+def test_bench_cpu_baseline_legs_are_guarded_and_merged(monkeypatch):
+    """bench.cpu_baseline_guarded: the CPU oracle is timed at 32 threads AND at all host threads in separate child
+    processes (SURVEY 8d names os.cpu_count(); on the 256-thread GPU host that leg does not finish a batch-4 step in its
+    guard).  A leg that times out is reported under `by_threads` with its reason, `value` / `cores` are the better of the
+    legs that finished, and a host with <= 32 threads runs one leg."""
+    import json
+    import bench
+    calls = []
+
+    class R:
+        def __init__(self, out):
+            self.stdout = out.encode()
+
+    def fake_run(cmd, timeout=None, stdout=None, stderr=None):
+        threads = int(cmd[cmd.index("--cpu-baseline-only") + 2])
+        calls.append((threads, timeout))
+        if threads > 32:
+            raise subprocess.TimeoutExpired(cmd, timeout)
+        return R(json.dumps({"value": 3.5, "unit": "images/sec", "cores": threads, "kind": "port", "sample": "x"}) + "\n")
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(os, "cpu_count", lambda: 256)
+    r = bench.cpu_baseline_guarded("c3")
+    assert [c[0] for c in calls] == [32, 256] and calls[1][1] <= 70
+    assert r["value"] == 3.5 and r["cores"] == 32 and r["by_threads"]["32"] == 3.5
+    assert "did not finish" in r["by_threads"]["256"]
+    calls.clear()
+    monkeypatch.setattr(os, "cpu_count", lambda: 8)
+    r = bench.cpu_baseline_guarded("c3")
+    assert [c[0] for c in calls] == [8] and r["cores"] == 8 and list(r["by_threads"]) == ["8"]
