@@ -50,8 +50,10 @@ int focr_set_precision(int mode);
  * when a group's 8 blocks share an XCD) or one launch per time step (0);
  * key 3: attention backward: 2 (default) = single pass, dQ / dK / dV from one S / dP evaluation (precision modes 2 / 3
  * and Ntok % 256 == 0, otherwise as 1); 1 = two passes (dK/dV, then dQ with 256-query blocks); 0 = two passes,
- * 128-query dQ blocks; key 4: keep-word schedule of the 256-query attention forward: 1 (default) = scalar mask requests
- * behind the K-fragment reads, travelling under the score MFMAs; 0 = in front of them (round 1-4 schedule). */
+ * 128-query dQ blocks; key 4: the 256-query attention forward: 2 (default) = keep-word scalar requests behind the K-fragment
+ * reads (travelling under the score MFMAs) + softmax on scores relative to the running reference (cross-half max exchange
+ * only in the rescale branch); 1 = the keep-word schedule alone; 0 = requests in front of the fragment reads (round 1-4).
+ * Values 0 and 1 are bit-identical; 2 agrees with them to rounding whenever a rescale happens. */
 int focr_set_tuning(int key, int value);
 int focr_get_tuning(int key);
 int focr_get_precision(void);
