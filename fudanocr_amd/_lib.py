@@ -148,6 +148,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.argtypes = args
         fn.restype = ctypes.c_int
+        _FN[name] = fn
     lib.focr_last_error.restype = ctypes.c_char_p
     lib.focr_last_error.argtypes = []
     lib.focr_version.restype = ctypes.c_int
@@ -219,7 +220,15 @@ def get_precision():
     return load().focr_get_precision()
 
 
+_FN = {}          # name -> bound ctypes function (filled by load(): no attribute lookup per call)
+
+
 def call(name, *args):
+    if _timed is None and _lib is not None:          # the hot path: 360 calls per training step
+        rc = _FN[name](*args)
+        if rc != 0:
+            raise RuntimeError("%s failed (%d): %s" % (name, rc, _lib.focr_last_error().decode()))
+        return
     lib = load()
     if _timed is not None and name in _timed:
         import torch

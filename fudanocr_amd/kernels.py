@@ -20,16 +20,17 @@ import torch
 from . import _lib
 
 ACT_NONE, ACT_RELU, ACT_MISH = 0, 1, 4
-_NULL = ctypes.c_void_p(0)
+_NULL = None          # ctypes converts None -> NULL and a Python int -> the pointer for `c_void_p` argtypes: the helpers below hand
+#                       out plain ints (no ctypes object per argument: ~600 of them per step on a host-bound path)
 
 
 def _p(t):
-    return _NULL if t is None else ctypes.c_void_p(t.data_ptr())
+    return None if t is None else t.data_ptr()
 
 
 def _po(t, off):
     """device pointer `off` floats into tensor t"""
-    return ctypes.c_void_p(t.data_ptr() + 4 * off)
+    return t.data_ptr() + 4 * off
 
 
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -39,8 +40,8 @@ def _stream():
     """the current HIP stream of the current device as a C pointer.  (torch.cuda.current_stream() builds a Stream object
     through three Python layers: ~9 us, 270 times per step; the raw getter is one C call.)"""
     if _RAW_STREAM is not None:
-        return ctypes.c_void_p(_RAW_STREAM(torch.cuda.current_device()))
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return _RAW_STREAM(torch.cuda.current_device())
+    return torch.cuda.current_stream().cuda_stream
 
 
 def _chk(*ts):
