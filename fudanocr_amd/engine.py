@@ -418,8 +418,12 @@ class TrainStep:
             # 100.0 -- is fed into the loss terms directly
             if self._g100 is None or self._g100.device != loss.device:
                 self._g100 = torch.full((), 100.0, device=loss.device)
+            # Only a criterion that DECLARES loss == mse + recognition term takes the shortcut (CTCFocusLoss.LOSS_IS_MSE_PLUS_REC);
+            # TextFocusLoss / StrokeFocusLoss weight their terms (mse + 10 * attention + 0.0005 * recognition,
+            # text_focus_loss.py:84-99) and go through (loss * 100).backward()
             terms = [t for t in (mse, ctc) if torch.is_tensor(t) and t.requires_grad]
-            if torch.is_tensor(ctc) and loss.grad_fn is not None and len(terms) == 2:
+            if (getattr(self.crit, "LOSS_IS_MSE_PLUS_REC", False) and torch.is_tensor(ctc) and loss.grad_fn is not None
+                    and len(terms) == 2):
                 torch.autograd.backward(terms, [self._g100.expand(t.shape) for t in terms])
             else:
                 (loss * 100).backward()

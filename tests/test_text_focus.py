@@ -176,6 +176,71 @@ def test_harness_trains_with_text_focus(tmp_path, monkeypatch):
         M.main(cfg, M.parse(["--arch", "tbsrn", "--STN", "--exp_name", "tf2", "--batch_size", "4", "--text_focus"]))
 
 
+@pytest.mark.gpu
+def test_trainstep_text_focus_gradient_is_loss_times_100():
+    """engine.TrainStep with TextFocusLoss (loss = mse + 10 * attention + 0.0005 * recognition, reference
+    loss/text_focus_loss.py:84-99; step tail interfaces/super_resolution.py:79-82): the flat gradient the engine
+    produces equals plain autograd's (loss * 100).backward() on a twin network.  The engine's 'feed 100 into mse and the
+    recognition term' shortcut is only valid for CTCFocusLoss (loss = mse + ctc) and must not be taken here -- forcing it
+    gives a different gradient, which this test also demonstrates."""
+    import types
+    from fudanocr_amd import _lib
+    from fudanocr_amd.engine import TrainStep
+    from fudanocr_amd.loss.text_focus_loss import TextFocusLoss
+    from fudanocr_amd.loss.transformer import Transformer
+    from fudanocr_amd.model import tbsrn
+    from fudanocr_amd.utils.weight_fill import fill_module_
+    _lib.load()
+    dev = torch.device("cuda", 0)
+    tr = fill_module_(Transformer()).to(dev).eval()
+    for p in tr.parameters():
+        p.requires_grad = False
+    lr_img, hr, labels = make_batch(4, 1234)
+    lr_img, hr = lr_img.to(dev), hr.to(dev)
+
+    def crit_():
+        return TextFocusLoss(types.SimpleNamespace(text_focus=True), transformer=tr)
+
+    def flat_grad(force_shortcut):
+        net = fill_module_(tbsrn.TBSRN(STN=True)).to(dev)
+        crit = crit_()
+        assert not getattr(crit, "LOSS_IS_MSE_PLUS_REC", False)
+        if force_shortcut:
+            crit.LOSS_IS_MSE_PLUS_REC = True
+        step = TrainStep(net, crit, lr=0.0, dropout=False)
+        out = step(lr_img, hr, labels)
+        torch.cuda.synchronize()
+        names = [n for n, p in net.named_parameters() if p.requires_grad]
+        return {n: dict(net.named_parameters())[n].grad.detach().clone() for n in names}, out
+
+    g_engine, out = flat_grad(False)
+    # twin network, no engine: torch autograd end to end
+    net = fill_module_(tbsrn.TBSRN(STN=True)).to(dev).train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.eval()
+    crit = crit_()
+    loss, mse, att, rec = crit(net(lr_img), hr, labels)
+    assert abs(loss.item() - out["loss"].item()) <= 1e-6 * abs(loss.item())
+    assert abs(loss.item() - (mse + 10 * att + 0.0005 * rec).item()) <= 1e-5 * abs(loss.item())
+    (loss * 100).backward()
+    torch.cuda.synchronize()
+    worst, num, den = 0.0, 0.0, 0.0
+    for n, p in net.named_parameters():
+        if p.grad is None:
+            assert float(g_engine[n].abs().max()) == 0.0, n
+            continue
+        d = (p.grad - g_engine[n]).double()
+        num += float((d * d).sum())
+        den += float((p.grad.double() ** 2).sum())
+        worst = max(worst, float(d.abs().max()) / (float(p.grad.abs().max()) + 1e-30))
+    assert (num / den) ** 0.5 < 1e-5 and worst < 1e-3, ((num / den) ** 0.5, worst)
+    g_short, _ = flat_grad(True)
+    n0 = "block8.0.weight" if "block8.0.weight" in g_short else next(iter(g_short))
+    diff = float((g_short[n0] - g_engine[n0]).norm()) / float(g_engine[n0].norm())
+    assert diff > 1e-2, "the shortcut would have been indistinguishable (%g): test is vacuous" % diff
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # text-gestalt half of row N1: StrokeFocusLoss + the stroke-level recognizer (fixture tools/make_golden_sfl.py)
 # ---------------------------------------------------------------------------------------------------------------------
