@@ -125,6 +125,18 @@ SIGNATURES = {
     "focr_get_precision": [],
     "focr_clip_adam": [P, P, P, P, P, L, F, F, F, F, I, F, F, P],
     "focr_zero": [P, L, P],
+    "focr_step_state_bytes": [],
+    "focr_step_advance": [P, ctypes.c_double, ctypes.c_double, P],
+    "focr_clip_adam_state": [P, P, P, P, P, L, F, F, F, F, P, F, F, P],
+    "focr_set_seed_epoch": [P],
+    "focr_replay_build": [P, P, I, P],
+    "focr_replay_info": [P, P],
+    "focr_replay_lanes": [P, P, I],
+    "focr_replay_launch": [P, P],
+    "focr_replay_node_name": [P, I, P, I],
+    "focr_replay_probe": [P, ctypes.c_char_p],
+    "focr_replay_probe_read": [P, P, P, I],
+    "focr_replay_destroy": [P],
 }
 
 _lib = None

@@ -323,7 +323,9 @@ __global__ __launch_bounds__(FC_THREADS, 1) void fe_fwd_a_kernel(
     const float* __restrict__ ctx, const float* __restrict__ tok, const float* __restrict__ Wo,
     const float* __restrict__ bo, const float* __restrict__ a1, const float* __restrict__ b1,
     const float* __restrict__ W1, const float* __restrict__ bb1, float* __restrict__ xhat1, float* __restrict__ rinv1,
-    float* __restrict__ hbuf, int ntiles, float eps, uint32_t drop_k, float drop_scale, uint32_t drop_seed) {
+    float* __restrict__ hbuf, int ntiles, float eps, uint32_t drop_k, float drop_scale, uint32_t drop_seed,
+    const uint64_t* __restrict__ epoch) {
+  drop_seed = focr_epoch_seed32(drop_seed, epoch);
   extern __shared__ __attribute__((aligned(16))) unsigned char fc_smem[];
   __bf16* Woh = reinterpret_cast<__bf16*>(fc_smem);
   __bf16* Wol = Woh + WSZ128;
@@ -856,7 +858,7 @@ extern "C" int focr_fe_post_fwd(const float* ctx, const float* tok, const float*
   }
   const int ntiles = (int)(rows / 32), nb = fc_blocks(ntiles);
   hipLaunchKernelGGL(fe_fwd_a_kernel, dim3(nb), FC_THREADS, FC_LDS_FWD_A, stream, ctx, tok, wo, bo, a1, b1, w1, bb1,
-                     xhat1, rinv1, h, ntiles, eps, kq, *keep_scale, (uint32_t)(seed ^ (seed >> 32)));
+                     xhat1, rinv1, h, ntiles, eps, kq, *keep_scale, (uint32_t)(seed ^ (seed >> 32)), focr_seed_epoch());
   hipLaunchKernelGGL(fe_fwd_b_kernel, dim3(nb), FC_THREADS, FC_LDS_FWD_B, stream, (const float*)h, (const float*)xhat1,
                      a1, b1, w2, bb2, a3, b3, wl, bl, xin, xhat2, rinv2, out, ntiles, eps);
   FOCR_LAUNCH_CHECK();

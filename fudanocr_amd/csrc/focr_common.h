@@ -142,6 +142,16 @@ __device__ __forceinline__ uint32_t rng_rowkey(uint64_t seed, uint32_t row) {
 __device__ __forceinline__ uint32_t rng_elem(uint32_t rowkey, uint32_t col) {
   return hash32(rowkey ^ (col * 0x9E3779B1U));
 }
+// Step epoch (focr_core.hip focr_set_seed_epoch): when the host has registered a device-resident step state, every
+// dropout seed is folded with the state's epoch word ON THE DEVICE, so a launch whose scalar arguments never change (a
+// replayed recording, replay.hip) still draws fresh keep bits in every step.  epoch == NULL: the seed as passed.
+extern "C" const uint64_t* focr_seed_epoch(void);
+__device__ __forceinline__ uint64_t focr_epoch_seed(uint64_t seed, const uint64_t* __restrict__ epoch) {
+  return epoch ? seed + epoch[0] * 0xD1B54A32D192ED03ull : seed;
+}
+__device__ __forceinline__ uint32_t focr_epoch_seed32(uint32_t seed, const uint64_t* __restrict__ epoch) {
+  return epoch ? seed ^ hash32((uint32_t)epoch[0] * 0x9E3779B1U + 0x85EBCA6BU) : seed;
+}
 
 // Attention block order: 1-D grid of BH * nqb blocks.  Workgroups are dispatched round-robin over the
 // 8 XCDs (block id % 8), so ids {x, x+8, x+16, ...} share an XCD and its L2: give those consecutive

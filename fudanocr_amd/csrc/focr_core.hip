@@ -62,3 +62,19 @@ extern "C" int focr_set_tuning(int key, int value) {
   return FOCR_OK;
 }
 extern "C" int focr_get_tuning(int key) { return (key >= 0 && key < FOCR_TUNING_COUNT) ? g_tuning[key].load(std::memory_order_relaxed) : -1; }
+
+// ---- device-resident step state (include/focr.h focr_step_*): 64 bytes of caller-owned device memory
+//   [0] u64 epoch   -- dropout epoch, folded into every dropout seed on the device (focr_common.h focr_epoch_seed)
+//   [1] i64 t       -- optimiser step count (1-based after the first focr_step_advance)
+//   [2] f32 c1, f32 c2s -- Adam bias corrections 1 - beta1^t and sqrt(1 - beta2^t) of step t, evaluated in double
+// so that a launch sequence with constant scalar arguments (a replayed recording, replay.hip) is still a correct NEXT step.
+// The registered pointer is process-wide like the precision word: an engine registers its state for the duration of its
+// step (launchers read the pointer when they LAUNCH; kernels read the state when they run).
+static std::atomic<const void*> g_seed_epoch{nullptr};
+extern "C" int focr_set_seed_epoch(const void* state) {
+  g_seed_epoch.store(state, std::memory_order_relaxed);
+  return FOCR_OK;
+}
+extern "C" const uint64_t* focr_seed_epoch(void) {
+  return reinterpret_cast<const uint64_t*>(g_seed_epoch.load(std::memory_order_relaxed));
+}

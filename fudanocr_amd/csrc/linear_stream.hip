@@ -31,7 +31,9 @@ __global__ __launch_bounds__(256, 2) void linear_stream_bx3_kernel(const float* 
                                                                    int M, int Cout, int ldx, int ldy, int ldr,
                                                                    float alpha, int relu, uint32_t drop_k,
                                                                    float drop_scale, uint32_t drop_seed,
-                                                                   float mask_scale) {
+                                                                   float mask_scale,
+                                                                   const uint64_t* __restrict__ epoch) {
+  if (HAS_DROP) drop_seed = focr_epoch_seed32(drop_seed, epoch);
   constexpr int KP = K + 8;            // bf16 pitch: conflict-free ds_read_b128 fragment reads
   constexpr int Q = K / 4;             // float4 per weight row
   constexpr int KS = K / 16;           // MFMA k-steps
@@ -175,7 +177,7 @@ static int launch_ls_(const float* x, const float* w, const float* bias, const f
   if (nb > cdiv(ntiles, 4)) nb = cdiv(ntiles, 4);
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL((linear_stream_bx3_kernel<K, NT, HAS_RES, HAS_DROP>), dim3(nb, ny), 256, lds, stream, x, w, bias,
-                     r, y, M, Cout, ldx, ldy, ldr, alpha, relu, drop_k, drop_scale, drop_seed, mask_scale);
+                     r, y, M, Cout, ldx, ldy, ldr, alpha, relu, drop_k, drop_scale, drop_seed, mask_scale, focr_seed_epoch());
   return 1;
 }
 

@@ -578,7 +578,9 @@ __global__ __launch_bounds__(256) void slice_cols_kernel(const float* __restrict
 
 // y = keep ? x / (1-p) : 0, mask from rng_hash(seed, element index)
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                      long n, float p, uint64_t seed) {
+                                                      long n, float p, uint64_t seed,
+                                                      const uint64_t* __restrict__ epoch) {
+  seed = focr_epoch_seed(seed, epoch);
   const uint32_t thr = (uint32_t)(p * 4294967296.0);
   const float ik = 1.f / (1.f - p);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
@@ -1112,7 +1114,7 @@ extern "C" int focr_slice_cols(const float* x, const float* add, float* out, lon
 }
 extern "C" int focr_dropout(const float* x, float* y, long n, float p, uint64_t seed, hipStream_t stream) {
   FOCR_CHECK_ARG(x && y && n > 0 && p >= 0.f && p < 1.f, "bad argument");
-  hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n)), 256, 0, stream, x, y, n, p, seed);
+  hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n)), 256, 0, stream, x, y, n, p, seed, focr_seed_epoch());
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }

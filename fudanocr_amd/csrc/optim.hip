@@ -72,6 +72,56 @@ extern "C" int focr_grad_sumsq(const float* g, float* sumsq, long n, float gscal
   return FOCR_OK;
 }
 
+// ---- step state (focr_core.hip): advance = epoch + 1, t + 1, bias corrections of the new t
+__global__ void step_advance_kernel(unsigned long long* __restrict__ st, double beta1, double beta2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    st[0] += 1ull;
+    const long long t = (long long)st[1] + 1;
+    st[1] = (unsigned long long)t;
+    float* f = reinterpret_cast<float*>(st + 2);
+    f[0] = (float)(1.0 - pow(beta1, (double)t));
+    f[1] = (float)sqrt(1.0 - pow(beta2, (double)t));
+  }
+}
+extern "C" int focr_step_state_bytes(void) { return 64; }
+extern "C" int focr_step_advance(void* state, double beta1, double beta2, hipStream_t stream) {
+  FOCR_CHECK_ARG(state && (reinterpret_cast<size_t>(state) & 7) == 0, "needs an 8-byte aligned 64-byte state block");
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), 64, 0, stream, reinterpret_cast<unsigned long long*>(state), beta1, beta2);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+__global__ __launch_bounds__(256) void clip_adam_state_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                              float* __restrict__ m, float* __restrict__ v,
+                                                              const float* __restrict__ sumsq, long n, float lr,
+                                                              float b1, float b2, float eps,
+                                                              const float* __restrict__ corr, float max_norm,
+                                                              float gscale) {
+  const float c1 = corr[0], c2s = corr[1];
+  float norm = sqrtf(sumsq[0]);
+  float coef = max_norm > 0.f ? fminf(max_norm / (norm + 1e-6f), 1.f) : 1.f;
+  const float k = coef * gscale;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i] * k;
+    float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= (lr / c1) * mi / (sqrtf(vi) / c2s + eps);
+  }
+}
+// focr_clip_adam with the step count / bias corrections read from the device-resident step state (after focr_step_advance)
+extern "C" int focr_clip_adam_state(float* p, const float* g, float* m, float* v, const float* sumsq, long n, float lr,
+                                    float beta1, float beta2, float eps, const void* state, float max_norm, float gscale,
+                                    hipStream_t stream) {
+  FOCR_CHECK_ARG(p && g && m && v && sumsq && n > 0 && state, "bad argument");
+  long gsz = (n + 255) / 256;
+  if (gsz > 2048) gsz = 2048;
+  hipLaunchKernelGGL(clip_adam_state_kernel, dim3((int)gsz), 256, 0, stream, p, g, m, v, sumsq, n, lr, beta1, beta2, eps,
+                     reinterpret_cast<const float*>(reinterpret_cast<const char*>(state) + 16), max_norm, gscale);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+
 // step: 1-based Adam step count.  max_norm <= 0 disables clipping.
 extern "C" int focr_clip_adam(float* p, const float* g, float* m, float* v, const float* sumsq, long n,
                               float lr, float beta1, float beta2, float eps, int step, float max_norm,

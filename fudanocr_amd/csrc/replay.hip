@@ -1,0 +1,429 @@
+// Step replay: the launch sequence of one whole optimisation step, recorded ONCE by HIP stream capture and re-issued from a
+// C loop inside the library -- one host call per step instead of ~360 launches from Python / autograd / ATen.
+//
+// Why not hipGraphLaunch: measured on this runtime (tools/dev/graph_probe.py) an instantiated graph of
+// the step costs as much host time per launch as enqueueing the step from Python and serialises the two queues.  What the
+// step needs from a graph is only its CONTENT: which kernels, with which arguments, in which order, with which cross-stream
+// edges.  focr_replay_build reads exactly that out of the captured (never instantiated) hipGraph_t through the public node
+// getters and lays the nodes out on a few in-order "lanes" (HIP streams the caller hands over); focr_replay_launch walks the
+// list: hipLaunchKernel / hipMemsetAsync / hipMemcpyAsync on the node's lane, hipStreamWaitEvent in front of a node for every
+// dependency that lives on another lane and is not already ordered before it, hipEventRecord behind a node somebody waits
+// for.  Lane 0 is the caller's stream: every lane starts behind it and is joined back into it at the end, so a replay is
+// ordered against the caller's other work exactly like one kernel launch on that stream.
+//
+// Ownership (include/focr.h conventions): no device memory is allocated; the graph stays the caller's (it owns the kernel
+// argument storage the node getters point into and must outlive the handle); the handle owns only HIP events.
+#include "focr_common.h"
+#include <vector>
+#include <algorithm>
+#include <cstring>
+#include <cstdint>
+typedef void* focr_stream_t;
+
+namespace {
+
+struct RNode {
+  hipGraphNodeType type;
+  hipKernelNodeParams kp;
+  hipMemsetParams ms;
+  hipMemcpy3DParms mc;
+  int lane = 0;
+  int module_launch = 0;          // kp.func is a hipFunction_t (captured hipModuleLaunchKernel), not a host stub
+  std::vector<int> waits;         // node indices whose event this node's lane waits for first
+  int event = -1;                 // index into Replay::events recorded behind this node
+  int probe = -1;                 // index into Replay::probes: timing event pair around this node (focr_replay_probe)
+};
+
+struct Replay {
+  std::vector<RNode> nodes;
+  std::vector<hipStream_t> lanes;
+  std::vector<hipEvent_t> events;
+  std::vector<hipEvent_t> lane_end;
+  std::vector<int> lane_used;
+  hipEvent_t start = nullptr;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> probes;
+  int counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long launches = 0;
+};
+
+struct Bits {
+  std::vector<uint64_t> w;
+  explicit Bits(size_t n = 0) : w((n + 63) / 64, 0) {}
+  void set(int i) { w[i >> 6] |= 1ull << (i & 63); }
+  bool get(int i) const { return (w[i >> 6] >> (i & 63)) & 1; }
+  void orin(const Bits& o) { for (size_t i = 0; i < w.size(); ++i) w[i] |= o.w[i]; }
+};
+
+#define RP_HIP(call)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      focr_set_error("%s: %s failed: %s", __func__, #call, hipGetErrorString(e_));        \
+      return FOCR_EHIP;                                                                   \
+    }                                                                                     \
+  } while (0)
+
+void destroy(Replay* r) {
+  if (!r) return;
+  for (hipEvent_t e : r->events) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : r->lane_end) if (e) (void)hipEventDestroy(e);
+  if (r->start) (void)hipEventDestroy(r->start);
+  for (auto& p : r->probes) { if (p.first) (void)hipEventDestroy(p.first); if (p.second) (void)hipEventDestroy(p.second); }
+  delete r;
+}
+
+}  // namespace
+
+// graph: a hipGraph_t produced by stream capture (hipStreamEndCapture / torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph()),
+// NOT instantiated.  lanes[0] is the stream replays are ordered on; lanes[1..] carry the captured cross-stream concurrency.
+// Kernel, memset, linear memcpy and empty nodes are understood; anything else (host callbacks, child graphs, external
+// events, allocations) is refused with FOCR_EUNSUPPORTED and the caller keeps launching eagerly.
+extern "C" int focr_replay_build(void* graph_, void* const* lanes, int n_lanes, void** handle) {
+  FOCR_CHECK_ARG(graph_ && lanes && n_lanes >= 1 && handle, "null graph / lanes / handle");
+  hipGraph_t graph = (hipGraph_t)graph_;
+  size_t n = 0;
+  RP_HIP(hipGraphGetNodes(graph, nullptr, &n));
+  FOCR_CHECK_ARG(n > 0, "the captured graph is empty");
+  std::vector<hipGraphNode_t> gn(n);
+  RP_HIP(hipGraphGetNodes(graph, gn.data(), &n));
+  gn.resize(n);
+  // index of every node handle; dependencies must point BACKWARDS in the order we launch in.  The runtime hands the nodes
+  // out in creation (= capture) order, which is a topological order; verified below and repaired by a stable topological
+  // sort if a runtime ever does not.
+  std::vector<std::vector<int>> deps(n);
+  {
+    std::vector<std::pair<hipGraphNode_t, int>> idx(n);
+    for (size_t i = 0; i < n; ++i) idx[i] = {gn[i], (int)i};
+    std::sort(idx.begin(), idx.end());
+    auto find = [&](hipGraphNode_t h) -> int {
+      auto it = std::lower_bound(idx.begin(), idx.end(), std::make_pair(h, -1));
+      return (it != idx.end() && it->first == h) ? it->second : -1;
+    };
+    bool ordered = true;
+    for (size_t i = 0; i < n; ++i) {
+      size_t nd = 0;
+      RP_HIP(hipGraphNodeGetDependencies(gn[i], nullptr, &nd));
+      if (!nd) continue;
+      std::vector<hipGraphNode_t> d(nd);
+      RP_HIP(hipGraphNodeGetDependencies(gn[i], d.data(), &nd));
+      for (size_t k = 0; k < nd; ++k) {
+        int j = find(d[k]);
+        FOCR_CHECK_ARG(j >= 0, "a dependency is not a node of the graph");
+        deps[i].push_back(j);
+        if (j >= (int)i) ordered = false;
+      }
+    }
+    if (!ordered) {                       // Kahn, smallest original index first
+      std::vector<int> indeg(n, 0), order, pos(n);
+      std::vector<std::vector<int>> succ(n);
+      for (size_t i = 0; i < n; ++i) for (int j : deps[i]) { succ[j].push_back((int)i); ++indeg[i]; }
+      std::vector<int> ready;
+      for (size_t i = 0; i < n; ++i) if (!indeg[i]) ready.push_back((int)i);
+      while (!ready.empty()) {
+        auto it = std::min_element(ready.begin(), ready.end());
+        int v = *it;
+        ready.erase(it);
+        order.push_back(v);
+        for (int s : succ[v]) if (--indeg[s] == 0) ready.push_back(s);
+      }
+      FOCR_CHECK_ARG(order.size() == n, "the captured graph has a cycle");
+      for (size_t i = 0; i < n; ++i) pos[order[i]] = (int)i;
+      std::vector<hipGraphNode_t> gn2(n);
+      std::vector<std::vector<int>> deps2(n);
+      for (size_t i = 0; i < n; ++i) {
+        gn2[i] = gn[order[i]];
+        for (int j : deps[order[i]]) deps2[i].push_back(pos[j]);
+      }
+      gn.swap(gn2);
+      deps.swap(deps2);
+    }
+  }
+  Replay* r = new Replay();
+  r->nodes.resize(n);
+  r->lanes.assign((hipStream_t*)lanes, (hipStream_t*)lanes + n_lanes);
+  r->lane_used.assign(n_lanes, 0);
+  r->lane_end.assign(n_lanes, nullptr);
+  for (size_t i = 0; i < n; ++i) {
+    RNode& nd = r->nodes[i];
+    hipError_t e = hipGraphNodeGetType(gn[i], &nd.type);
+    if (e == hipSuccess) {
+      switch (nd.type) {
+        case hipGraphNodeTypeKernel:
+          e = hipGraphKernelNodeGetParams(gn[i], &nd.kp);
+          r->counts[1]++;
+          break;
+        case hipGraphNodeTypeMemset:
+          e = hipGraphMemsetNodeGetParams(gn[i], &nd.ms);
+          r->counts[2]++;
+          break;
+        case hipGraphNodeTypeMemcpy: {
+          memset(&nd.mc, 0, sizeof(nd.mc));
+          e = hipGraphMemcpyNodeGetParams(gn[i], &nd.mc);
+          r->counts[3]++;
+          // (a node captured from hipMemcpyAsync is a 1-D node whose parameters this getter does not fill on every
+          // runtime: both pointers must be addresses the runtime knows, or the node is refused)
+          hipPointerAttribute_t pa;
+          if (e == hipSuccess && nd.mc.srcPtr.ptr && nd.mc.dstPtr.ptr && nd.mc.extent.width > 0 &&
+              nd.mc.extent.width < (1ull << 40) &&
+              (hipPointerGetAttributes(&pa, nd.mc.srcPtr.ptr) != hipSuccess ||
+               hipPointerGetAttributes(&pa, nd.mc.dstPtr.ptr) != hipSuccess)) {
+            (void)hipGetLastError();
+            nd.mc.srcPtr.ptr = nullptr;
+          }
+          if (e == hipSuccess && (nd.mc.extent.width == 0 || nd.mc.extent.width >= (1ull << 40) || nd.mc.srcArray || nd.mc.dstArray || nd.mc.extent.height > 1 || nd.mc.extent.depth > 1 ||
+                                  nd.mc.srcPos.x || nd.mc.srcPos.y || nd.mc.srcPos.z || nd.mc.dstPos.x || nd.mc.dstPos.y ||
+                                  nd.mc.dstPos.z || !nd.mc.srcPtr.ptr || !nd.mc.dstPtr.ptr)) {
+            focr_set_error("focr_replay_build: node %zu is a memcpy whose parameters cannot be read back (hipMemcpyAsync captures a 1-D node the "
+                           "public getter does not describe) or is not a linear pointer-to-pointer copy: copy with a kernel inside a recorded step", i);
+            destroy(r);
+            return FOCR_EUNSUPPORTED;
+          }
+          break;
+        }
+        case hipGraphNodeTypeEmpty:
+          r->counts[4]++;
+          break;
+        default:
+          focr_set_error("focr_replay_build: node %zu has type %d (only kernel / memset / memcpy / empty nodes are replayed)", i,
+                         (int)nd.type);
+          destroy(r);
+          return FOCR_EUNSUPPORTED;
+      }
+    }
+    if (e != hipSuccess) {
+      focr_set_error("focr_replay_build: reading node %zu (type %d) failed: %s", i, (int)nd.type, hipGetErrorString(e));
+      destroy(r);
+      return FOCR_EHIP;
+    }
+  }
+  // ---- lanes.  A node goes (1) behind a direct dependency that is still the last node of its lane (lowest lane first, so
+  // the main chain stays on lane 0), else (2) behind the last node of any lane that is an ANCESTOR of it (stream order then
+  // adds no ordering the graph did not have), else (3) on an unused lane, else (4) behind its latest dependency's lane.
+  std::vector<Bits> anc(n, Bits(n)), lane_anc(n_lanes, Bits(n));
+  std::vector<int> tail(n_lanes, -1);
+  for (size_t i = 0; i < n; ++i) {
+    for (int d : deps[i]) { anc[i].orin(anc[d]); anc[i].set(d); }
+    int lane = -1;
+    for (int L = 0; L < n_lanes && lane < 0; ++L)
+      if (tail[L] >= 0 && std::find(deps[i].begin(), deps[i].end(), tail[L]) != deps[i].end()) lane = L;
+    for (int L = 0; L < n_lanes && lane < 0; ++L)
+      if (tail[L] >= 0 && anc[i].get(tail[L])) lane = L;
+    for (int L = 0; L < n_lanes && lane < 0; ++L)
+      if (tail[L] < 0) lane = L;
+    if (lane < 0) lane = deps[i].empty() ? 0 : r->nodes[*std::max_element(deps[i].begin(), deps[i].end())].lane;
+    RNode& nd = r->nodes[i];
+    nd.lane = lane;
+    r->lane_used[lane] = 1;
+    // waits: dependencies on other lanes not yet ordered before this lane's tail; per foreign lane only the latest one
+    std::vector<int> need(n_lanes, -1);
+    for (int d : deps[i]) {
+      int dl = r->nodes[d].lane;
+      if (dl == lane || lane_anc[lane].get(d)) continue;
+      need[dl] = std::max(need[dl], d);
+    }
+    for (int L = 0; L < n_lanes; ++L) {
+      // (a later node of lane L than need[L] that is already ordered before us makes the wait redundant)
+      if (need[L] < 0) continue;
+      bool covered = false;
+      for (int t = tail[L]; t > need[L] && !covered; --t)
+        if (r->nodes[t].lane == L && lane_anc[lane].get(t)) covered = true;
+      if (!covered) nd.waits.push_back(need[L]);
+    }
+    for (int w : nd.waits) {
+      if (r->nodes[w].event < 0) {
+        r->nodes[w].event = (int)r->events.size();
+        r->events.push_back(nullptr);
+      }
+      lane_anc[lane].orin(anc[w]);
+      lane_anc[lane].set(w);
+      r->counts[6]++;
+    }
+    lane_anc[lane].orin(anc[i]);
+    lane_anc[lane].set((int)i);
+    tail[lane] = (int)i;
+  }
+  // the longest chain becomes lane 0 (the caller's stream), the next one lane 1, ...: which captured stream a chain came
+  // from is not visible in a graph, its length is -- the step's main chain is the long one
+  {
+    std::vector<int> cnt(n_lanes, 0), order(n_lanes), to(n_lanes);
+    for (const RNode& nd : r->nodes) cnt[nd.lane]++;
+    for (int L = 0; L < n_lanes; ++L) order[L] = L;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cnt[a] > cnt[b]; });
+    for (int L = 0; L < n_lanes; ++L) to[order[L]] = L;
+    for (RNode& nd : r->nodes) nd.lane = to[nd.lane];
+    std::vector<int> used(n_lanes, 0);
+    for (int L = 0; L < n_lanes; ++L) used[to[L]] = r->lane_used[L];
+    r->lane_used.swap(used);
+  }
+  for (hipEvent_t& e : r->events) {
+    hipError_t err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    if (err != hipSuccess) {
+      focr_set_error("focr_replay_build: hipEventCreate failed: %s", hipGetErrorString(err));
+      destroy(r);
+      return FOCR_EHIP;
+    }
+  }
+  for (int L = 1; L < n_lanes; ++L)
+    if (r->lane_used[L] && hipEventCreateWithFlags(&r->lane_end[L], hipEventDisableTiming) != hipSuccess) {
+      focr_set_error("focr_replay_build: hipEventCreate failed");
+      destroy(r);
+      return FOCR_EHIP;
+    }
+  if (hipEventCreateWithFlags(&r->start, hipEventDisableTiming) != hipSuccess) {
+    focr_set_error("focr_replay_build: hipEventCreate failed");
+    destroy(r);
+    return FOCR_EHIP;
+  }
+  r->counts[0] = (int)n;
+  r->counts[5] = (int)std::count(r->lane_used.begin(), r->lane_used.end(), 1);
+  r->counts[7] = (int)r->events.size();
+  *handle = r;
+  return FOCR_OK;
+}
+
+// out[8]: nodes, kernel nodes, memset nodes, memcpy nodes, empty nodes, lanes used, cross-lane waits, events recorded
+extern "C" int focr_replay_info(void* handle, int* out) {
+  FOCR_CHECK_ARG(handle && out, "null handle / out");
+  memcpy(out, ((Replay*)handle)->counts, sizeof(int) * 8);
+  return FOCR_OK;
+}
+
+// per-node table for tools (which lane every node landed on): lane[i] for i < min(n, nodes); returns FOCR_OK
+extern "C" int focr_replay_lanes(void* handle, int* lane, int n) {
+  FOCR_CHECK_ARG(handle && lane, "null handle / lane");
+  Replay* r = (Replay*)handle;
+  for (int i = 0; i < n && i < (int)r->nodes.size(); ++i) lane[i] = r->nodes[i].lane;
+  return FOCR_OK;
+}
+
+// stream: the stream this replay is ordered on (it takes the place of lanes[0] of focr_replay_build for this launch); NULL =
+// lanes[0] itself.
+extern "C" int focr_replay_launch(void* handle, focr_stream_t stream) {
+  FOCR_CHECK_ARG(handle, "null handle");
+  Replay* r = (Replay*)handle;
+  const int n_lanes = (int)r->lanes.size();
+  hipStream_t lane0_saved = r->lanes[0];
+  if (stream) r->lanes[0] = (hipStream_t)stream;
+  struct Restore { Replay* r; hipStream_t s; ~Restore() { r->lanes[0] = s; } } restore{r, lane0_saved};
+  RP_HIP(hipEventRecord(r->start, r->lanes[0]));
+  for (int L = 1; L < n_lanes; ++L)
+    if (r->lane_used[L]) RP_HIP(hipStreamWaitEvent(r->lanes[L], r->start, 0));
+  const size_t n = r->nodes.size();
+  for (size_t i = 0; i < n; ++i) {
+    RNode& nd = r->nodes[i];
+    hipStream_t s = r->lanes[nd.lane];
+    for (int w : nd.waits) RP_HIP(hipStreamWaitEvent(s, r->events[r->nodes[w].event], 0));
+    if (nd.probe >= 0) RP_HIP(hipEventRecord(r->probes[nd.probe].first, s));
+    switch (nd.type) {
+      case hipGraphNodeTypeKernel: {
+        hipError_t e;
+        if (!nd.module_launch) {
+          e = hipLaunchKernel(nd.kp.func, nd.kp.gridDim, nd.kp.blockDim, nd.kp.kernelParams, nd.kp.sharedMemBytes, s);
+          if (e == hipErrorInvalidDeviceFunction && r->launches == 0) {      // decided once, during the first replay
+            (void)hipGetLastError();
+            nd.module_launch = 1;
+          } else if (e != hipSuccess) {
+            focr_set_error("focr_replay_launch: node %zu: hipLaunchKernel failed: %s", i, hipGetErrorString(e));
+            return FOCR_EHIP;
+          }
+        }
+        if (nd.module_launch) {
+          e = hipModuleLaunchKernel((hipFunction_t)nd.kp.func, nd.kp.gridDim.x, nd.kp.gridDim.y, nd.kp.gridDim.z,
+                                    nd.kp.blockDim.x, nd.kp.blockDim.y, nd.kp.blockDim.z, nd.kp.sharedMemBytes, s,
+                                    nd.kp.kernelParams, nd.kp.kernelParams ? nullptr : nd.kp.extra);
+          if (e != hipSuccess) {
+            focr_set_error("focr_replay_launch: node %zu: hipModuleLaunchKernel failed: %s", i, hipGetErrorString(e));
+            return FOCR_EHIP;
+          }
+        }
+        break;
+      }
+      case hipGraphNodeTypeMemset:
+        if (nd.ms.height <= 1) {
+          if (nd.ms.elementSize == 4) RP_HIP(hipMemsetD32Async((hipDeviceptr_t)nd.ms.dst, (int)nd.ms.value, nd.ms.width, s));
+          else if (nd.ms.elementSize == 2) RP_HIP(hipMemsetD16Async((hipDeviceptr_t)nd.ms.dst, (unsigned short)nd.ms.value, nd.ms.width, s));
+          else RP_HIP(hipMemsetD8Async((hipDeviceptr_t)nd.ms.dst, (unsigned char)nd.ms.value, nd.ms.width, s));
+        } else {
+          RP_HIP(hipMemset2DAsync(nd.ms.dst, nd.ms.pitch, (int)nd.ms.value, nd.ms.width * nd.ms.elementSize, nd.ms.height, s));
+        }
+        break;
+      case hipGraphNodeTypeMemcpy:
+        RP_HIP(hipMemcpyAsync(nd.mc.dstPtr.ptr, nd.mc.srcPtr.ptr, nd.mc.extent.width, nd.mc.kind, s));
+        break;
+      default:
+        break;                   // empty node: only its edges matter
+    }
+    if (nd.probe >= 0) RP_HIP(hipEventRecord(r->probes[nd.probe].second, s));
+    if (nd.event >= 0) RP_HIP(hipEventRecord(r->events[nd.event], s));
+  }
+  for (int L = 1; L < n_lanes; ++L)
+    if (r->lane_used[L]) {
+      RP_HIP(hipEventRecord(r->lane_end[L], r->lanes[L]));
+      RP_HIP(hipStreamWaitEvent(r->lanes[0], r->lane_end[L], 0));
+    }
+  r->launches++;
+  return FOCR_OK;
+}
+
+static const char* node_name(const RNode& nd) {
+  if (nd.type == hipGraphNodeTypeMemset) return "(memset)";
+  if (nd.type == hipGraphNodeTypeMemcpy) return "(memcpy)";
+  if (nd.type != hipGraphNodeTypeKernel) return "(empty)";
+  const char* nm = nd.module_launch ? hipKernelNameRef((hipFunction_t)nd.kp.func) : hipKernelNameRefByPtr(nd.kp.func, nullptr);
+  return nm ? nm : "(unknown kernel)";
+}
+
+// (mangled) kernel name of node i, for tools and for choosing probe patterns; "(memset)" / "(memcpy)" / "(empty)" otherwise
+extern "C" int focr_replay_node_name(void* handle, int i, char* buf, int n) {
+  FOCR_CHECK_ARG(handle && buf && n > 0, "null handle / buf");
+  Replay* r = (Replay*)handle;
+  FOCR_CHECK_ARG(i >= 0 && i < (int)r->nodes.size(), "node index out of range");
+  snprintf(buf, n, "%s", node_name(r->nodes[i]));
+  return FOCR_OK;
+}
+
+// Timing probes: every kernel node whose name contains `pattern` gets a timing-enabled event pair recorded on its lane
+// directly around its launch in every later replay (bench.py's roofline leg: the dominant kernel's duration measured inside
+// the timed region, on the stream it runs on).  Returns the number of nodes probed by this call (>= 0) or an error (< 0).
+extern "C" int focr_replay_probe(void* handle, const char* pattern) {
+  FOCR_CHECK_ARG(handle && pattern && *pattern, "null handle / pattern");
+  Replay* r = (Replay*)handle;
+  int hit = 0;
+  for (RNode& nd : r->nodes) {
+    if (nd.type != hipGraphNodeTypeKernel || nd.probe >= 0 || !strstr(node_name(nd), pattern)) continue;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+      focr_set_error("focr_replay_probe: hipEventCreate failed");
+      return FOCR_EHIP;
+    }
+    nd.probe = (int)r->probes.size();
+    r->probes.push_back({a, b});
+    ++hit;
+  }
+  return hit;
+}
+
+// elapsed milliseconds of the LAST replay for probe k = 0 .. n-1 (in node order over all focr_replay_probe calls); the
+// caller synchronises first.  node[k] (optional) receives the node index of probe k.  Returns the number of probes.
+extern "C" int focr_replay_probe_read(void* handle, float* ms, int* node, int n) {
+  FOCR_CHECK_ARG(handle, "null handle");
+  Replay* r = (Replay*)handle;
+  for (size_t i = 0; i < r->nodes.size(); ++i) {
+    int k = r->nodes[i].probe;
+    if (k < 0 || k >= n) continue;
+    if (node) node[k] = (int)i;
+    if (ms) {
+      hipError_t e = hipEventElapsedTime(&ms[k], r->probes[k].first, r->probes[k].second);
+      if (e != hipSuccess) {
+        focr_set_error("focr_replay_probe_read: probe %d: %s", k, hipGetErrorString(e));
+        return FOCR_EHIP;
+      }
+    }
+  }
+  return (int)r->probes.size();
+}
+
+extern "C" int focr_replay_destroy(void* handle) {
+  destroy((Replay*)handle);
+  return FOCR_OK;
+}

@@ -240,7 +240,8 @@ __global__ __launch_bounds__(256) void small_attn_fwd_kernel(const float* __rest
                                                              float* __restrict__ P, float* __restrict__ Pd, int H,
                                                              int Lq, int Lk, int ldq, int ldk, int ldo, float scale,
                                                              int causal, uint32_t drop_thr, float keep_scale,
-                                                             uint64_t seed) {
+                                                             uint64_t seed, const uint64_t* __restrict__ epoch) {
+  seed = focr_epoch_seed(seed, epoch);
   __shared__ float qs[DK];
   __shared__ float ps[SA_LKMAX];
   __shared__ float red[4];
@@ -375,10 +376,10 @@ extern "C" int focr_small_attention_fwd(const float* q, const float* k, const fl
   const float ks = thr ? 65536.f / (65536.f - (float)thr) : 1.f;
   if (Dk == 64)
     hipLaunchKernelGGL((small_attn_fwd_kernel<64>), dim3(B * H, Lq), 256, 0, stream, q, k, v, o, p, pd, H, Lq, Lk, ldq,
-                       ldk, ldo, scale, causal, thr, ks, seed);
+                       ldk, ldo, scale, causal, thr, ks, seed, focr_seed_epoch());
   else
     hipLaunchKernelGGL((small_attn_fwd_kernel<256>), dim3(B * H, Lq), 256, 0, stream, q, k, v, o, p, pd, H, Lq, Lk, ldq,
-                       ldk, ldo, scale, causal, thr, ks, seed);
+                       ldk, ldo, scale, causal, thr, ks, seed, focr_seed_epoch());
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }

@@ -104,19 +104,24 @@ class FusedClipAdam:
     """clip_grad_norm_(max_norm) + Adam on flat buffers (HIP on CUDA tensors).  `world` folds the
     data-parallel averaging into the kernels."""
 
-    def __init__(self, flat, lr=1e-4, betas=(0.5, 0.999), eps=1e-8, max_norm=0.25):
+    def __init__(self, flat, lr=1e-4, betas=(0.5, 0.999), eps=1e-8, max_norm=0.25, state=None):
         self.flat, self.lr, self.betas, self.eps, self.max_norm = flat, lr, betas, eps, max_norm
         self.m = torch.zeros_like(flat.flat_param)
         self.v = torch.zeros_like(flat.flat_param)
         self.sumsq = K.sumsq_workspace(flat.flat_param.device)
         self.t = 0
+        self.state = state        # kernels.StepState: step count / bias corrections live on the device (the owner advances it)
 
     def step(self, world=1):
         self.t += 1
         g = 1.0 / world
         K.grad_sumsq(self.flat.flat_grad, self.sumsq, g)
-        K.clip_adam(self.flat.flat_param, self.flat.flat_grad, self.m, self.v, self.sumsq, self.lr,
-                    self.betas[0], self.betas[1], self.eps, self.t, self.max_norm, g)
+        if self.state is not None:
+            K.clip_adam_state(self.flat.flat_param, self.flat.flat_grad, self.m, self.v, self.sumsq, self.lr,
+                              self.betas[0], self.betas[1], self.eps, self.state.buf, self.max_norm, g)
+        else:
+            K.clip_adam(self.flat.flat_param, self.flat.flat_grad, self.m, self.v, self.sumsq, self.lr,
+                        self.betas[0], self.betas[1], self.eps, self.t, self.max_norm, g)
 
     def grad_norm(self):
         return self.sumsq[:1].sqrt()
@@ -146,21 +151,36 @@ class TrainStep:
     backward has passed that boundary; the remainder goes out after backward.  RCCL runs on its own
     stream, so these collectives overlap the remaining backward kernels."""
 
+    REPLAY_WARMUP = 2      # eager steps per input signature before the step is recorded (lazy tables, workspaces)
+
     def __init__(self, model, crit, lr=1e-4, betas=(0.5, 0.999), max_norm=0.25, process_group=None,
                  wgrad_side_stream=True, n_buckets=4, dropout=True, boundaries=("block3", "block6"),
-                 tail=("stn_head",)):
+                 tail=("stn_head",), replay=None, seed=None):
         self.model, self.crit = model, crit
         self.dropout = dropout        # False: nn.Dropout slots stay in eval (parity runs)
         self.flat = FlatBuffers(_qkv_adjacent_order(model))
         self._attach_packed_qkv()
         self._attach_packed_gru()
-        self.opt = FusedClipAdam(self.flat, lr, betas, 1e-8, max_norm)
+        on_gpu = self.flat.flat_grad.is_cuda
+        # per-step scalars (dropout epoch, Adam step count + bias corrections) live in device memory and are advanced by the
+        # first launch of every step: the host passes the same arguments in every step, which is what lets a step be
+        # RECORDED once and re-issued from C (replay.py, csrc/replay.hip)
+        self.state = K.StepState(self.flat.flat_grad.device, betas[0], betas[1]) if on_gpu else None
+        self.opt = FusedClipAdam(self.flat, lr, betas, 1e-8, max_norm, state=self.state)
+        # replay: None -> FOCR_REPLAY (default on).  Effective on one GPU per process group of size 1 with a criterion that
+        # declares REPLAY_SAFE (no host-side work per step beyond label encoding); everything else steps eagerly.
+        self.replay = (os.environ.get("FOCR_REPLAY", "1") != "0") if replay is None else bool(replay)
+        self._recs, self._seen, self.recorded = {}, {}, None
         self.pg = process_group
         self.wgrad_side_stream = bool(wgrad_side_stream)
         self.flips = K.FlipTable()               # one batched weight flip per step for all data-gradient GEMMs
         self.frags = K.FragTable(managed=True)   # pre-split fragment-ordered weights of the halo-kernel layers: one
                                                  # batched preparation launch per step (forward + data-gradient forms)
         self.ctx = K.StepContext()
+        # dropout: fixed per-site seeds + the device-resident epoch (same keep bits whether a step is launched eagerly or
+        # replayed; `seed` makes runs repeatable)
+        self.ctx.seed_base = (int(seed) if seed is not None else
+                              int(torch.randint(0, 2 ** 62, (1,), device="cpu").item())) if on_gpu else None
         self.ctx.mask_prefetch = True            # attention keep bits of step k + 1 are drawn on the side stream
         #                                          this engine's deferred gradients / tables / side stream (the autograd
                                                  # nodes recorded during its forward carry it into their backward)
@@ -376,7 +396,110 @@ class TrainStep:
                     m.eval()
         self._modes_set = True
 
+    # ---- recorded step --------------------------------------------------------------------------------------------------
+    def _replay_ok(self):
+        from . import _lib
+        return (self.replay and self.world == 1 and self.flat.flat_grad.is_cuda and _lib._timed is None
+                and getattr(self.crit, "REPLAY_SAFE", False) and not torch.cuda.is_current_stream_capturing())
+
+    def _rec_key(self, lr, hr, encoded):
+        from . import _lib
+        lib = _lib.load()
+        return (tuple(lr.shape), tuple(hr.shape), encoded is not None, lib.focr_get_precision(),
+                tuple(lib.focr_get_tuning(k) for k in range(5)), bool(self.dropout), bool(self.wgrad_side_stream))
+
+    @staticmethod
+    def _fill(st, lr, hr, encoded):
+        if lr is not st["lr"]:
+            st["lr"].copy_(lr, non_blocking=True)
+        if hr is not st["hr"]:
+            st["hr"].copy_(hr, non_blocking=True)
+        if encoded is not None and encoded is not st["enc"]:
+            t, l, o = encoded[0], encoded[1], encoded[2]
+            st["enc"][0][:t.numel()].copy_(t, non_blocking=True)
+            st["enc"][1].copy_(l, non_blocking=True)
+            st["enc"][2].copy_(o, non_blocking=True)
+
+    def _record(self, key, lr, hr, encoded):
+        """capture one step on static copies of the inputs and build its launch list (replay.record)"""
+        import warnings
+        from . import replay
+        st = {"lr": torch.empty_like(lr), "hr": torch.empty_like(hr), "enc": None}
+        if encoded is not None:
+            cap = max(int(encoded[0].numel()), lr.shape[0] * 32)
+            st["enc"] = (torch.zeros(cap, device=lr.device, dtype=encoded[0].dtype), torch.zeros_like(encoded[1]),
+                         torch.zeros_like(encoded[2]))
+        self._fill(st, lr, hr, encoded)
+        if self.ctx.side_stream_obj is None:
+            self.ctx.side_stream_obj = torch.cuda.Stream()
+        t_host = self.opt.t
+        try:
+            rec, out = replay.record(lambda: self._step(st["lr"], st["hr"], None, st["enc"]),
+                                     lanes=[torch.cuda.current_stream(), self.ctx.side_stream_obj])
+        except Exception as e:                                   # noqa: BLE001
+            warnings.warn("fudanocr_amd: recording the training step failed (%s: %s); stepping eagerly from here on"
+                          % (type(e).__name__, str(e)[:300]))
+            self.replay = False
+            self.ctx.deferred.clear()
+            self.ctx.premasked.clear()
+            return None
+        finally:
+            self.opt.t = t_host              # the captured step did not run
+        st["rec"], st["out"] = rec, out
+        # eval-mode BatchNorm caches of this model's layers are dropped by the train-mode forward in Python
+        # (kernels._BatchNormAct); a replay runs no Python, so the engine drops them after every launch
+        st["rvars"] = [id(m.running_var) for m in self.model.modules()
+                       if isinstance(getattr(m, "running_var", None), torch.Tensor)]
+        self._recs[key] = st
+        return st
+
+    def recorded_inputs(self, images_lr, images_hr, encoded=None):
+        """the static input tensors of the recording that serves these shapes (or None): a loader that writes the next batch
+        straight into them -- and passes them back in -- saves the per-step input copies"""
+        st = self._recs.get(self._rec_key(images_lr, images_hr, encoded))
+        return None if st is None else (st["lr"], st["hr"], st["enc"])
+
+    def _call_recorded(self, images_lr, images_hr, label_strs, encoded):
+        if encoded is None and label_strs is not None and getattr(self.crit, "recognizer", [None])[0] is not None:
+            encoded = self.crit.encode(label_strs, images_lr.device)
+        key = self._rec_key(images_lr, images_hr, encoded)
+        st = self._recs.get(key)
+        if st is None:
+            n = self._seen[key] = self._seen.get(key, 0) + 1
+            if n <= self.REPLAY_WARMUP:
+                return self._step(images_lr, images_hr, label_strs, encoded)
+            st = self._record(key, images_lr, images_hr, encoded)
+            if st is None:
+                return self._step(images_lr, images_hr, label_strs, encoded)
+        if encoded is not None and encoded is not st["enc"] and encoded[0].numel() > st["enc"][0].numel():
+            return self._step(images_lr, images_hr, label_strs, encoded)       # more label characters than the static buffer
+        self._fill(st, images_lr, images_hr, encoded)
+        st["rec"].launch()
+        self.recorded = st["rec"]
+        self.opt.t += 1
+        K.bump_weight_epoch()                              # parameters changed behind autograd's version counters
+        for i in st["rvars"]:
+            K._EVAL_INVSTD.pop(i, None)
+        return st["out"]
+
     def __call__(self, images_lr, images_hr, label_strs=None, encoded=None):
+        """one optimisation step.  With replay active the returned tensors are STATIC (overwritten by the next step)."""
+        self._set_modes()
+        if self._replay_ok():
+            return self._call_recorded(images_lr, images_hr, label_strs, encoded)
+        return self._step(images_lr, images_hr, label_strs, encoded)
+
+    def _step(self, images_lr, images_hr, label_strs=None, encoded=None):
+        if self.state is not None:
+            self.state.bind()
+            self.state.advance()           # epoch + 1, t + 1, bias corrections of t: the first launch of the step
+        try:
+            return self._step_body(images_lr, images_hr, label_strs, encoded)
+        finally:
+            if self.state is not None:
+                self.state.unbind()
+
+    def _step_body(self, images_lr, images_hr, label_strs=None, encoded=None):
         self._set_modes()
         self.flat.zero_grad()
         self._works, self._sent = [], []

@@ -69,8 +69,18 @@ def _target(param):
     return getattr(param, "_focr_grad", None) if param is not None else None
 
 
-def _new_seed():
-    return int(torch.randint(0, 2 ** 62, (1,), device="cpu").item())
+def _new_seed(ctx=None):
+    """dropout seed of the next dropout site: the owning StepContext's deterministic per-site sequence when it has a
+    `seed_base` (engine steps: the per-STEP variation then comes from the device-resident epoch word, focr_set_seed_epoch),
+    a host random number otherwise"""
+    return (ctx or current_context()).next_seed()
+
+
+def _mix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return x ^ (x >> 31)
 
 
 # ----------------------------------------------------------------------------------------
@@ -109,6 +119,14 @@ class StepContext:
         self._fe_bwd_i = 0
         self._parking = False
         self.tail_ready = False          # the step has a TPS warp with a trainable STN head behind it (release point)
+        self.seed_base = None            # engine-owned contexts: site seeds are a fixed sequence, the step's epoch lives on
+        self._seed_i = 0                 # the device (replayed recordings carry constant scalar arguments)
+
+    def next_seed(self):
+        if self.seed_base is None:
+            return int(torch.randint(0, 2 ** 62, (1,), device="cpu").item())
+        self._seed_i += 1
+        return _mix64(self.seed_base + self._seed_i) >> 2
 
     # -- attention dropout keep bits.  They depend on (shape, p, seed) only, so the engine draws the bits of ALL
     # attention layers at the start of the step on the side stream (idle during the forward pass) instead of in front
@@ -157,7 +175,7 @@ class StepContext:
         with torch.cuda.stream(s):
             for m in entries:
                 b, heads, t, p, _ = m["key"]
-                _lib.call("focr_attention_dropout_mask", _p(m[buf]), b, heads, t, p, _new_seed(), _stream())
+                _lib.call("focr_attention_dropout_mask", _p(m[buf]), b, heads, t, p, _new_seed(self), _stream())
                 ev = torch.cuda.Event()
                 ev.record(s)
                 m[evt] = ev
@@ -255,6 +273,7 @@ class StepContext:
             self._tail_side.pop(0)()
 
     def new_step(self):
+        self._seed_i = 0
         self._fe_fwd_n = self._fe_bwd_i = 0
         self._parking = False
         self.tail_ready = False
@@ -1758,6 +1777,10 @@ def _lstm_flags(whh, backward, batch, t_len):
     e = _LSTM_SPLIT.get(id(whh))
     if e is None or e[0]() is not whh or not _lib.load().focr_lstm_persistent_usable(int(batch), 256):
         return None, 0                      # (per-step launches do not touch the counters: the base must not advance)
+    if torch.cuda.is_current_stream_capturing():
+        # a recorded step (engine.TrainStep replay) re-issues this launch with the SAME scalar arguments every time: the
+        # counters must start from zero in every replay, i.e. the workspace flag block + its memset (both recorded)
+        return None, 0
     key = ("flags", int(backward), int(batch), int(t_len), torch.cuda.current_stream().cuda_stream)
     st = e[3].get(key)
     if st is None:
@@ -1917,3 +1940,37 @@ def grad_sumsq(flat_grad, out, gscale=1.0):
 def clip_adam(p, g, m, v, sumsq, lr, beta1, beta2, eps, step, max_norm, gscale=1.0):
     _lib.call("focr_clip_adam", _p(p), _p(g), _p(m), _p(v), _p(sumsq), p.numel(), float(lr), float(beta1),
               float(beta2), float(eps), int(step), float(max_norm), float(gscale), _stream())
+
+
+def clip_adam_state(p, g, m, v, sumsq, lr, beta1, beta2, eps, state, max_norm, gscale=1.0):
+    """clip + Adam with the step count / bias corrections read from the device-resident step state (focr_step_advance)"""
+    _lib.call("focr_clip_adam_state", _p(p), _p(g), _p(m), _p(v), _p(sumsq), p.numel(), float(lr), float(beta1),
+              float(beta2), float(eps), _p(state), float(max_norm), float(gscale), _stream())
+
+
+class StepState:
+    """64 bytes of device memory an engine owns (csrc/focr_core.hip): dropout epoch, optimiser step count and the Adam
+    bias corrections of that step.  Advanced by ONE tiny launch at the start of every step, read by the kernels -- so
+    the host passes no per-step scalar, and a recorded launch sequence (replay.py) is a correct next step."""
+
+    def __init__(self, device, beta1, beta2):
+        self.buf = torch.zeros(_lib.load().focr_step_state_bytes() // 8, device=device, dtype=torch.int64)
+        self.betas = (float(beta1), float(beta2))
+
+    def advance(self):
+        _lib.call("focr_step_advance", _p(self.buf), self.betas[0], self.betas[1], _stream())
+
+    def set_counts(self, epoch, t):
+        """(checkpoint resume) the next advance() makes these epoch + 1 / t + 1"""
+        self.buf[:2].copy_(torch.tensor([int(epoch), int(t)], dtype=torch.int64))
+
+    def counts(self):
+        e, t = self.buf[:2].tolist()        # synchronises
+        return int(e), int(t)
+
+    def bind(self):
+        _lib.call("focr_set_seed_epoch", _p(self.buf))
+
+    @staticmethod
+    def unbind():
+        _lib.call("focr_set_seed_epoch", None)

@@ -16,6 +16,7 @@ class CTCFocusLoss(nn.Module):
         self.recognizer = [recognizer]          # not registered: stays out of state_dict/parameters
         self.converter = strLabelConverter(alphabet)
 
+    REPLAY_SAFE = True              # forward(sr, hr, None, encoded) launches kernels only: engine.TrainStep may record it
     LOSS_IS_MSE_PLUS_REC = True     # forward returns loss = mse + ctc exactly: engine.TrainStep may feed d(loss*100) = 100 into both
     MAX_LABEL_LEN = 31      # csrc/ctc.hip: one lane per extended-label position, 2L+1 <= 64
     T_STEPS = 26            # CRNN output length for 32 x 100 inputs (crnn.py:65-80)

@@ -380,6 +380,19 @@ int focr_grad_sumsq(const float* g, float* sumsq, long n, float gscale, focr_str
 int focr_clip_adam(float* p, const float* g, float* m, float* v, const float* sumsq, long n, float lr,
                    float beta1, float beta2, float eps, int step, float max_norm, float gscale,
                    focr_stream_t stream);
+/* ---- device-resident step state: 64 bytes of caller-owned, zero-initialised device memory holding what changes from one
+ * optimisation step to the next (interfaces/super_resolution.py:79-84 runs these as host-side Python state: nn.Dropout's
+ * generator, Adam's `state['step']`): u64 dropout epoch, i64 optimiser step count t, f32 1 - beta1^t, f32 sqrt(1 - beta2^t)
+ * (evaluated in double).  focr_step_advance: epoch + 1, t + 1, corrections of the new t -- the first launch of a step.
+ * focr_clip_adam_state: focr_clip_adam with t / the corrections read from the state.  focr_set_seed_epoch: process-wide
+ * registration (NULL to clear): every launch that takes a dropout seed (focr_attention_dropout_mask, focr_fe_post_fwd,
+ * focr_linear_relu_dropout_fwd, focr_dropout, focr_small_attention_fwd) hands the pointer to its kernel, which folds the
+ * epoch word into the seed ON THE DEVICE.  With both, a step's launches carry the same scalar arguments in every step. */
+int focr_step_state_bytes(void);
+int focr_step_advance(void* state, double beta1, double beta2, focr_stream_t stream);
+int focr_clip_adam_state(float* p, const float* g, float* m, float* v, const float* sumsq, long n, float lr, float beta1,
+                         float beta2, float eps, const void* state, float max_norm, float gscale, focr_stream_t stream);
+int focr_set_seed_epoch(const void* state);
 /* optimizer.zero_grad() on the flat gradient buffer (interfaces/super_resolution.py:82); p 16-byte aligned, n floats */
 int focr_zero(float* p, long n, focr_stream_t stream);
 
@@ -456,6 +469,27 @@ int focr_comm_rccl_version(void);
 int focr_comm_async_error(void);
 int focr_comm_wait(focr_stream_t stream, int timeout_ms);
 int focr_comm_destroy(void);
+
+/* ---- recorded step (csrc/replay.hip): the launches of one whole optimisation step -- TextSR.train's loop body,
+ * interfaces/super_resolution.py:66-84 -- captured once into a hipGraph_t by the caller (HIP stream capture; the graph is
+ * never instantiated) and re-issued from a loop inside the library: ONE host call per step.
+ * focr_replay_build: graph = hipGraph_t; lanes = n_lanes hipStream_t the captured chains are laid out on (longest chain on
+ *   lanes[0]); kernel / memset / linear-memcpy / empty nodes only, else FOCR_EUNSUPPORTED.  The graph (it owns the kernel
+ *   argument storage) must outlive the handle; the handle owns HIP events only.
+ * focr_replay_launch: re-issue everything, ordered on `stream` (NULL: lanes[0]) like one launch on that stream.
+ * focr_replay_info: out[8] = nodes, kernel / memset / memcpy / empty nodes, lanes used, cross-lane waits, events.
+ * focr_replay_lanes / focr_replay_node_name: per-node lane and (mangled) kernel name, for tools.
+ * focr_replay_probe: timing event pair around every kernel node whose name contains `pattern` in later launches; returns
+ *   the number of nodes matched (>= 0).  focr_replay_probe_read: milliseconds of the last launch per probe (caller has
+ *   synchronised); returns the number of probes. */
+int focr_replay_build(void* graph, void* const* lanes, int n_lanes, void** handle);
+int focr_replay_launch(void* handle, focr_stream_t stream);
+int focr_replay_info(void* handle, int* out);
+int focr_replay_lanes(void* handle, int* lane, int n);
+int focr_replay_node_name(void* handle, int i, char* buf, int n);
+int focr_replay_probe(void* handle, const char* pattern);
+int focr_replay_probe_read(void* handle, float* ms, int* node, int n);
+int focr_replay_destroy(void* handle);
 
 #ifdef __cplusplus
 }
