@@ -334,17 +334,48 @@ def main():
     step_.comm_timing = world > 1
     conv_steps = min(2, args.steps)      # the conv / linear launches are event-timed in the last steps only (each event
                                          # pair costs host time: keeps the perturbation of `value` < 0.5 %)
+    GEMM_CALLS = ["focr_conv3x3_frag_fwd", "focr_conv2d_fwd", "focr_conv2d_fwd_ws", "focr_conv2d_wgrad",
+                  "focr_fe_post_fwd", "focr_fe_post_bwd", "focr_fe_qkv_dgrad"]
+    ATTN_CALLS = ["focr_attention_fwd", "focr_attention_fwd_premasked", "focr_attention_bwd"]
+    # Recorded step (engine.TrainStep replay, csrc/replay.hip): after its eager warm-up steps the engine captured the whole
+    # step and now re-issues it with ONE library call per step.  The inputs are the recording's static tensors (resident
+    # in HBM before the timed region starts); the attention kernels are event-timed INSIDE the timed region by probes the
+    # library records around their launches on their own stream (one event pair per launch and step).
+    rec = getattr(step_, "recorded", None) if cfg != "c5" else None
+    launch_info = None
+    if rec is not None:
+        st_in = step_.recorded_inputs(lr, hr, enc)
+        if st_in is not None:
+            lr, hr, enc = st_in
+        n_bwd = rec.probe("attn_bwd", depth=args.steps)
+        n_fwd = rec.probe("attn_fwd", depth=args.steps)
+        launch_info = dict(rec.info, host_calls_per_step=1)
     sync()
-    _lib.start_timing(["focr_attention_fwd", "focr_attention_fwd_premasked", "focr_attention_bwd"])
+    if rec is None:
+        _lib.start_timing(ATTN_CALLS)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if i == args.steps - conv_steps:
-            _lib.add_timing(["focr_conv3x3_frag_fwd", "focr_conv2d_fwd", "focr_conv2d_fwd_ws", "focr_conv2d_wgrad",
-                             "focr_fe_post_fwd", "focr_fe_post_bwd", "focr_fe_qkv_dgrad"])
+        if rec is None and i == args.steps - conv_steps:
+            _lib.add_timing(GEMM_CALLS)
         out = step()
     sync()
     dt = time.perf_counter() - t0
-    kt = _lib.stop_timing_with_args()
+    if rec is None:
+        kt = _lib.stop_timing_with_args()
+        attn_live = None
+    else:
+        # probes: (node, mean ms over the timed steps, steps held); backward / forward nodes by kernel name
+        names = rec.node_names()
+        pr = rec.probe_read()
+        attn_live = {"bwd": [ms for nd, ms, c in pr if "attn_bwd" in names[nd] for _ in range(c)],
+                     "fwd": [ms for nd, ms, c in pr if "attn_fwd" in names[nd] for _ in range(c)]}
+        # the remaining rows (`also`): per-call events on two EAGER steps after the timed region -- the same kernels with
+        # the same arguments, launched from Python one call at a time
+        _lib.start_timing(GEMM_CALLS)
+        for _ in range(conv_steps):
+            step()
+        sync()
+        kt = _lib.stop_timing_with_args()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -447,8 +478,11 @@ def main():
                             3 if bx3 else 1))
         # (keep bits are drawn ahead of time on the side stream from the second step on: the forward is then the
         # `premasked` entry = the attention kernel alone)
-        fwd = [t for t, _ in kt.get("focr_attention_fwd", []) + kt.get("focr_attention_fwd_premasked", [])]
-        bwd = [t for t, _ in kt.get("focr_attention_bwd", [])]
+        if attn_live is not None:
+            fwd, bwd = attn_live["fwd"], attn_live["bwd"]
+        else:
+            fwd = [t for t, _ in kt.get("focr_attention_fwd", []) + kt.get("focr_attention_fwd_premasked", [])]
+            bwd = [t for t, _ in kt.get("focr_attention_bwd", [])]
         if fwd:
             fa = 4.0 * batch * 4 * 1024 * 1024 * 32
             r = row("attn_fwd2_bx3_kernel (fused QK^T-softmax-dropout-PV; keep bits pre-drawn on the side stream)",
@@ -526,6 +560,13 @@ def main():
                        "parallelism": "dp%d" % world, "arch": arch if cfg != "c5" else "sld-transformer",
                        "collective_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
                        "arithmetic": arith,
+                       # how the step reaches the GPU: the recorded step's node / lane counts (one library call per step),
+                       # or null = every launch issued from Python
+                       "recorded_step": launch_info,
+                       "roofline_timing": ("attention rows: library probes (HIP event pairs on the kernel's own stream) in "
+                                           "every timed step; other rows: per-call events on %d eager steps after the "
+                                           "timed region" % conv_steps) if launch_info else
+                                          "per-call HIP events inside the timed region",
                        # mode 1 = split products at every site of forward AND backward (fp32-equivalent everywhere)
                        "mode1_ms_per_step": None if mode1_ms is None else round(mode1_ms, 3),
                        # c1 / c2 / c5 of BASELINE.json at one GPU (short runs in subprocesses; `--all-configs` prints their

@@ -134,8 +134,8 @@ SIGNATURES = {
     "focr_replay_lanes": [P, P, I],
     "focr_replay_launch": [P, P],
     "focr_replay_node_name": [P, I, P, I],
-    "focr_replay_probe": [P, ctypes.c_char_p],
-    "focr_replay_probe_read": [P, P, P, I],
+    "focr_replay_probe": [P, ctypes.c_char_p, I],
+    "focr_replay_probe_read": [P, P, P, P, I],
     "focr_replay_destroy": [P],
 }
 

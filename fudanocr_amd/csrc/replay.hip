@@ -41,7 +41,8 @@ struct Replay {
   std::vector<hipEvent_t> lane_end;
   std::vector<int> lane_used;
   hipEvent_t start = nullptr;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> probes;
+  struct Probe { std::vector<std::pair<hipEvent_t, hipEvent_t>> slots; long first_launch; };
+  std::vector<Probe> probes;
   int counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long launches = 0;
 };
@@ -68,7 +69,8 @@ void destroy(Replay* r) {
   for (hipEvent_t e : r->events) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : r->lane_end) if (e) (void)hipEventDestroy(e);
   if (r->start) (void)hipEventDestroy(r->start);
-  for (auto& p : r->probes) { if (p.first) (void)hipEventDestroy(p.first); if (p.second) (void)hipEventDestroy(p.second); }
+  for (auto& p : r->probes)
+    for (auto& e : p.slots) { if (e.first) (void)hipEventDestroy(e.first); if (e.second) (void)hipEventDestroy(e.second); }
   delete r;
 }
 
@@ -313,7 +315,10 @@ extern "C" int focr_replay_launch(void* handle, focr_stream_t stream) {
     RNode& nd = r->nodes[i];
     hipStream_t s = r->lanes[nd.lane];
     for (int w : nd.waits) RP_HIP(hipStreamWaitEvent(s, r->events[r->nodes[w].event], 0));
-    if (nd.probe >= 0) RP_HIP(hipEventRecord(r->probes[nd.probe].first, s));
+    if (nd.probe >= 0) {
+      Replay::Probe& p = r->probes[nd.probe];
+      RP_HIP(hipEventRecord(p.slots[(r->launches - p.first_launch) % (long)p.slots.size()].first, s));
+    }
     switch (nd.type) {
       case hipGraphNodeTypeKernel: {
         hipError_t e;
@@ -353,7 +358,10 @@ extern "C" int focr_replay_launch(void* handle, focr_stream_t stream) {
       default:
         break;                   // empty node: only its edges matter
     }
-    if (nd.probe >= 0) RP_HIP(hipEventRecord(r->probes[nd.probe].second, s));
+    if (nd.probe >= 0) {
+      Replay::Probe& p = r->probes[nd.probe];
+      RP_HIP(hipEventRecord(p.slots[(r->launches - p.first_launch) % (long)p.slots.size()].second, s));
+    }
     if (nd.event >= 0) RP_HIP(hipEventRecord(r->events[nd.event], s));
   }
   for (int L = 1; L < n_lanes; ++L)
@@ -382,42 +390,59 @@ extern "C" int focr_replay_node_name(void* handle, int i, char* buf, int n) {
   return FOCR_OK;
 }
 
-// Timing probes: every kernel node whose name contains `pattern` gets a timing-enabled event pair recorded on its lane
-// directly around its launch in every later replay (bench.py's roofline leg: the dominant kernel's duration measured inside
-// the timed region, on the stream it runs on).  Returns the number of nodes probed by this call (>= 0) or an error (< 0).
-extern "C" int focr_replay_probe(void* handle, const char* pattern) {
-  FOCR_CHECK_ARG(handle && pattern && *pattern, "null handle / pattern");
+// Timing probes: every kernel node whose name contains `pattern` gets `depth` timing-enabled event pairs; launch k records
+// pair k % depth on the node's lane directly around its launch (bench.py's roofline leg: the dominant kernel's duration
+// measured inside the timed region, on the stream it runs on).  Returns the number of nodes probed by this call (>= 0) or an
+// error (< 0).
+extern "C" int focr_replay_probe(void* handle, const char* pattern, int depth) {
+  FOCR_CHECK_ARG(handle && pattern && *pattern && depth >= 1 && depth <= 4096, "null handle / pattern, or depth outside 1..4096");
   Replay* r = (Replay*)handle;
   int hit = 0;
   for (RNode& nd : r->nodes) {
     if (nd.type != hipGraphNodeTypeKernel || nd.probe >= 0 || !strstr(node_name(nd), pattern)) continue;
-    hipEvent_t a = nullptr, b = nullptr;
-    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
-      focr_set_error("focr_replay_probe: hipEventCreate failed");
-      return FOCR_EHIP;
+    Replay::Probe p;
+    p.first_launch = r->launches;
+    for (int k = 0; k < depth; ++k) {
+      hipEvent_t a = nullptr, b = nullptr;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+        focr_set_error("focr_replay_probe: hipEventCreate failed");
+        return FOCR_EHIP;
+      }
+      p.slots.push_back({a, b});
     }
     nd.probe = (int)r->probes.size();
-    r->probes.push_back({a, b});
+    r->probes.push_back(std::move(p));
     ++hit;
   }
   return hit;
 }
 
-// elapsed milliseconds of the LAST replay for probe k = 0 .. n-1 (in node order over all focr_replay_probe calls); the
-// caller synchronises first.  node[k] (optional) receives the node index of probe k.  Returns the number of probes.
-extern "C" int focr_replay_probe_read(void* handle, float* ms, int* node, int n) {
+// per probe k = 0 .. n-1 (node order over all focr_replay_probe calls): MEAN elapsed milliseconds over the launches its
+// event pairs still hold (the last min(launches since the probe was set, depth)); the caller synchronises first.  node[k]
+// (optional) receives the node index, count[k] (optional) the number of launches averaged.  Returns the number of probes.
+extern "C" int focr_replay_probe_read(void* handle, float* ms, int* node, int* count, int n) {
   FOCR_CHECK_ARG(handle, "null handle");
   Replay* r = (Replay*)handle;
   for (size_t i = 0; i < r->nodes.size(); ++i) {
     int k = r->nodes[i].probe;
     if (k < 0 || k >= n) continue;
+    Replay::Probe& p = r->probes[k];
     if (node) node[k] = (int)i;
+    long have = r->launches - p.first_launch;
+    if (have > (long)p.slots.size()) have = (long)p.slots.size();
+    if (count) count[k] = (int)have;
     if (ms) {
-      hipError_t e = hipEventElapsedTime(&ms[k], r->probes[k].first, r->probes[k].second);
-      if (e != hipSuccess) {
-        focr_set_error("focr_replay_probe_read: probe %d: %s", k, hipGetErrorString(e));
-        return FOCR_EHIP;
+      double sum = 0.0;
+      for (long j = 0; j < have; ++j) {
+        float t = 0.f;
+        hipError_t e = hipEventElapsedTime(&t, p.slots[j].first, p.slots[j].second);
+        if (e != hipSuccess) {
+          focr_set_error("focr_replay_probe_read: probe %d: %s", k, hipGetErrorString(e));
+          return FOCR_EHIP;
+        }
+        sum += t;
       }
+      ms[k] = have ? (float)(sum / have) : 0.f;
     }
   }
   return (int)r->probes.size();

@@ -46,24 +46,25 @@ class Recorded:
         _lib.call("focr_replay_lanes", self._h, arr, self.info["nodes"])
         return list(arr)
 
-    def probe(self, pattern):
-        """time every kernel node whose (mangled) name contains `pattern` in all later launches -> number of nodes"""
-        n = _lib.load().focr_replay_probe(self._h, pattern.encode())
+    def probe(self, pattern, depth=1):
+        """time every kernel node whose (mangled) name contains `pattern` in all later launches, keeping the last `depth`
+        launches -> number of nodes"""
+        n = _lib.load().focr_replay_probe(self._h, pattern.encode(), int(depth))
         if n < 0:
             raise RuntimeError("focr_replay_probe failed: " + _lib.load().focr_last_error().decode())
         return n
 
     def probe_read(self):
-        """[(node index, ms)] of the last launch (synchronises)"""
+        """[(node index, mean ms over the launches held, launches held)] (synchronises)"""
         torch.cuda.synchronize()
         lib = _lib.load()
-        n = lib.focr_replay_probe_read(self._h, None, None, 0)
+        n = lib.focr_replay_probe_read(self._h, None, None, None, 0)
         if n <= 0:
             return []
-        ms, node = (ctypes.c_float * n)(), (ctypes.c_int * n)()
-        if lib.focr_replay_probe_read(self._h, ms, node, n) < 0:
+        ms, node, cnt = (ctypes.c_float * n)(), (ctypes.c_int * n)(), (ctypes.c_int * n)()
+        if lib.focr_replay_probe_read(self._h, ms, node, cnt, n) < 0:
             raise RuntimeError("focr_replay_probe_read failed: " + lib.focr_last_error().decode())
-        return [(int(node[i]), float(ms[i])) for i in range(n)]
+        return [(int(node[i]), float(ms[i]), int(cnt[i])) for i in range(n)]
 
     def close(self):
         if self.handle:

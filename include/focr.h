@@ -479,16 +479,17 @@ int focr_comm_destroy(void);
  * focr_replay_launch: re-issue everything, ordered on `stream` (NULL: lanes[0]) like one launch on that stream.
  * focr_replay_info: out[8] = nodes, kernel / memset / memcpy / empty nodes, lanes used, cross-lane waits, events.
  * focr_replay_lanes / focr_replay_node_name: per-node lane and (mangled) kernel name, for tools.
- * focr_replay_probe: timing event pair around every kernel node whose name contains `pattern` in later launches; returns
- *   the number of nodes matched (>= 0).  focr_replay_probe_read: milliseconds of the last launch per probe (caller has
- *   synchronised); returns the number of probes. */
+ * focr_replay_probe: `depth` timing event pairs around every kernel node whose name contains `pattern` (launch k records
+ *   pair k % depth); returns the number of nodes matched (>= 0).  focr_replay_probe_read: per probe the MEAN milliseconds
+ *   over the launches its pairs hold (caller has synchronised), the node index and that launch count; returns the number
+ *   of probes. */
 int focr_replay_build(void* graph, void* const* lanes, int n_lanes, void** handle);
 int focr_replay_launch(void* handle, focr_stream_t stream);
 int focr_replay_info(void* handle, int* out);
 int focr_replay_lanes(void* handle, int* lane, int n);
 int focr_replay_node_name(void* handle, int i, char* buf, int n);
-int focr_replay_probe(void* handle, const char* pattern);
-int focr_replay_probe_read(void* handle, float* ms, int* node, int n);
+int focr_replay_probe(void* handle, const char* pattern, int depth);
+int focr_replay_probe_read(void* handle, float* ms, int* node, int* count, int n);
 int focr_replay_destroy(void* handle);
 
 #ifdef __cplusplus

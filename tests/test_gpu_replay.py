@@ -66,11 +66,12 @@ def test_replay_multi_stream_graph():
         torch.cuda.synchronize()
         assert torch.equal(res, expect(x)), i
     # timing probes: one event pair around every node that matches
-    n = rec.probe("elementwise")
+    n = rec.probe("elementwise", depth=3)
     assert n >= 5
-    rec.launch()
+    for _ in range(5):
+        rec.launch()
     times = rec.probe_read()
-    assert len(times) == n and all(ms > 0 for _, ms in times)
+    assert len(times) == n and all(ms > 0 and cnt == 3 for _, ms, cnt in times)
     rec.close()
 
     def with_copy():
@@ -130,7 +131,8 @@ def test_recorded_step_equals_eager(arch, with_crnn):
     assert torch.equal(a[:2], c[:2]) or float(got[:2].max()) <= float(4 * noise[:2].max() + 1e-6)     # both eager there
     for s in range(7):
         for j, name in enumerate(("loss", "grad-norm")):
-            assert float(got[s, j]) <= 4 * float(noise[:s + 1, j].max()) + 2e-6, (s, name, got[s, j], noise[s, j])
+            # (one eager pair is a coarse sample of a spread that grows chaotically with the step index)
+            assert float(got[s, j]) <= 10 * float(noise[:s + 1, j].max()) + 2e-5 * (s + 1), (s, name, got[s, j], noise[s, j])
         assert float(got[s, 2]) <= 0.01 + 4 * float(noise[s, 2]), (s, "mean displacement", a[s, 2], c[s, 2])
         assert float(got[s, 3]) <= 0.05 + 4 * float(noise[s, 3]), (s, "max displacement", a[s, 3], c[s, 3])
     # the first replayed step (index 2) starts from bit-identical state up to that noise: dropout masks of (seed, epoch 3)

@@ -49,7 +49,7 @@ with open(os.path.join(os.environ.get("OUT", "."), "replay_nodes.txt"), "w") as 
         f.write("%4d lane %d %s\n" % (i, l_, n_[:160]))
 nk = r.probe("attn_bwd1")
 for _ in range(3): r.launch()
-print("probes on attn_bwd1:", nk, ["%.1f us" % (ms * 1e3) for _, ms in r.probe_read()])
+print("probes on attn_bwd1:", nk, ["%.1f us" % (ms * 1e3) for _, ms, _ in r.probe_read()])
 if os.environ.get("GRAPH_LAUNCH", "1") == "1":
     try:
         h, t = timed(r.graph.replay)
