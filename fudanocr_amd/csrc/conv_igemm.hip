@@ -482,7 +482,7 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, co
     return FOCR_OK;
   }
   if (!vec && KH == 1 && KW == 1 && padH == 0 && padW == 0 && Cin % 4 == 0 && g.ldx % 4 == 0 && Cin <= 256 &&
-      (long)g.M * Cout <= (1l << 20) && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+      (long)g.M * Cout <= (1l << 20) && cdiv(g.M, 4) <= 65535 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
     hipLaunchKernelGGL(tiny_linear_kernel, dim3(cdiv(Cout, 256), cdiv(g.M, 4)), 256, 0, stream, x, w, bias, residual, y, g.M,
                        Cin, Cout, g.ldx, g.ldy, g.ldr, alpha, relu);
     FOCR_LAUNCH_CHECK();

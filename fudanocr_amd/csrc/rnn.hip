@@ -1381,6 +1381,27 @@ static bool lp_usable(int B, int H) {
   return 8 * cdiv(B, 32) * 2 <= resident;
 }
 
+// The XCD-local release (lp_arrive `fast`) rests on two facts of THIS chip that the HIP memory model does not promise: plain
+// stores of blocks on one XCD are visible to each other in that XCD's L2 once acknowledged, and hardware register 20 read
+// through s_getreg is XCC_ID.  Both were verified on gfx950 in SPX mode (256 CUs, tools/gpu/r05_call7.sh / call8.sh); on
+// any other device -- another architecture, or a partitioned gfx950 whose CU count differs -- the agent-scope release is
+// used in every step.  Cached per device.
+static bool lp_fast_release_verified() {
+  static std::atomic<int> verdict[64];               // 0 = not asked, 1 = no, 2 = yes
+  std::atomic<int>& slot = verdict[focr_cur_device()];
+  int v = slot.load(std::memory_order_relaxed);
+  if (v == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    v = 1;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        strncmp(prop.gcnArchName, "gfx950", 6) == 0 && prop.multiProcessorCount == 256)
+      v = 2;
+    slot.store(v, std::memory_order_relaxed);
+  }
+  return v == 2;
+}
+
 // ws (forward): bf16 elements: 2*2*4H*H (whh hi/lo) + 2*T*B*2H (h hi/lo)          -> bytes = 2 * that
 // ws (backward): bf16 elements: 2*2*H*4H (whh^T hi/lo) + 2*rows*8H (dgx hi/lo)
 extern "C" long focr_lstm_ws_bytes(int T, int B, int H, int backward) {
@@ -1424,7 +1445,7 @@ int focr_lstm_fwd_bx3(const float* gx, const float* whh, const float* bhh, float
     const int ngroups = cdiv(B, 32) * 2;
     hipLaunchKernelGGL(lstm_fwd_persist_bx3_kernel, dim3(8 * ngroups), 512, LP_FWD_LDS, stream, gx,
                        (const __bf16*)whh2, bhh, hseq, hseq2, gates, cseq, flags, T, B, st_t, st_b, ngroups,
-                       focr_get_tuning(FOCR_TUNE_LSTM_PERSISTENT) != 2, base);
+                       focr_get_tuning(FOCR_TUNE_LSTM_PERSISTENT) != 2 && lp_fast_release_verified(), base);
     return 0;
   }
   dim3 grid(H / 32, (B + 31) / 32, 2);
@@ -1459,7 +1480,7 @@ int focr_lstm_bwd_bx3(const float* dhseq, const float* whh, const float* gates, 
     const int ngroups = cdiv(B, 32) * 2;
     hipLaunchKernelGGL(lstm_bwd_persist_bx3_kernel, dim3(8 * ngroups), 512, LP_BWD_LDS, stream, dhseq,
                        (const __bf16*)whhT2, gates, cseq, dgx, dgx2, flags, T, B, st_t, st_b, ndg, ngroups,
-                       focr_get_tuning(FOCR_TUNE_LSTM_PERSISTENT) != 2, base);
+                       focr_get_tuning(FOCR_TUNE_LSTM_PERSISTENT) != 2 && lp_fast_release_verified(), base);
     return 0;
   }
   dim3 grid(H / 32, (B + 31) / 32, 2);

@@ -510,10 +510,13 @@ class TrainStep:
         if on_gpu:
             self.frags.refresh()
             c.prefetch_masks()
-            if self.flips.built and self.flips.n_live:
+            if self.flips.built and self.flips.n_live and self.wgrad_side_stream:
                 # the flipped weights of the data-gradient GEMMs depend on the parameters only: re-flipped at the START of
                 # the step on the side stream (idle during the forward pass) instead of between loss and backward on the
                 # main stream (19 us + a dependent launch on the critical path); backward waits for the event
+                # INVARIANT: nothing in the forward pass reads the FlipTable's buffers (c.flips is None until the
+                # backward starts, asserted here) and nothing writes parameters between this point and the backward
+                assert c.flips is None
                 if c.side_stream_obj is None:
                     c.side_stream_obj = torch.cuda.Stream()
                 side = c.side_stream_obj

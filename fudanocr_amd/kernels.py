@@ -1784,11 +1784,36 @@ def _lstm_flags(whh, backward, batch, t_len):
     key = ("flags", int(backward), int(batch), int(t_len), torch.cuda.current_stream().cuda_stream)
     st = e[3].get(key)
     if st is None:
-        st = [torch.zeros(256, device=whh.device, dtype=torch.int32), 0]
+        # [flag words, base, calls, (pinned error copy, event) of the last health check]
+        st = [torch.zeros(256, device=whh.device, dtype=torch.int32), 0, 0, None]
         e[3][key] = st
-    base = st[1]
-    st[1] = (base + 8 * (t_len - 1)) & 0xFFFFFFFF
-    return st[0], base
+    # Health check without a synchronisation: every 16th call copies the sticky error word (set by a bounded
+    # wait that timed out: partner blocks not resident) to pinned memory; the NEXT check reads the copy if it has
+    # landed.  After a timeout the counters no longer match `base` and every later scan of this site would time out too:
+    # the flag block is zeroed and the base restarts at 0, and the caller is told once.
+    st[2] += 1
+    if st[3] is not None and st[3][1].query():
+        if int(st[3][0][0]) != 0:
+            import warnings
+            warnings.warn("persistent LSTM scan: a step-counter wait timed out (partner blocks not resident -- several "
+                          "processes on one device?); the affected step's recognizer output was NaN-poisoned, the counters "
+                          "are reset.  focr_set_tuning(2, 0) selects per-step launches.")
+            st[0].zero_()
+            st[1] = 0
+        st[3] = None
+    if st[3] is None and st[2] % 16 == 0:
+        ngroups = (int(batch) + 31) // 32 * 2
+        pin = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        pin.copy_(st[0][ngroups:ngroups + 1], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st[3] = (pin, ev)
+    return st[0], st
+
+
+def _lstm_advance(st, t_len):
+    """the scan was launched: its groups' words end 8 (T - 1) higher"""
+    st[1] = (st[1] + 8 * (t_len - 1)) & 0xFFFFFFFF
 
 
 class _LSTMRecur(torch.autograd.Function):
@@ -1808,11 +1833,13 @@ class _LSTMRecur(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             current_context().prefetch_masks_early()
         wsp = _lstm_prepared(whh, 0)
-        fl, base = _lstm_flags(whh, 0, batch, t_len) if wsp is not None else (None, 0)
+        fl, fst = _lstm_flags(whh, 0, batch, t_len) if wsp is not None else (None, 0)
         _lib.call("focr_lstm_bidir_fwd_pw", _p(gx), _p(whh), _p(bhh), _p(hseq), _p(gates), _p(cseq), _p(ws),
                   ctypes.c_void_p(wsp.data_ptr()) if wsp is not None else _NULL,
-                  ctypes.c_void_p(fl.data_ptr()) if fl is not None else _NULL, base, t_len, batch, hid, st_t, st_b,
-                  _stream())
+                  ctypes.c_void_p(fl.data_ptr()) if fl is not None else _NULL, fst[1] if fl is not None else 0, t_len,
+                  batch, hid, st_t, st_b, _stream())
+        if fl is not None:
+            _lstm_advance(fst, t_len)                      # only after the launch succeeded (a raise leaves base alone)
         _lstm_check(ws if fl is None else fl, batch)
         ctx.cfg = (t_len, batch, hid, st_t, st_b, tuple(gx.shape))
         ctx.save_for_backward(whh, gates, cseq, hseq if (whh.requires_grad or bhh.requires_grad) else None)
@@ -1827,11 +1854,13 @@ class _LSTMRecur(torch.autograd.Function):
         carry = torch.empty((2, batch, hid), device=dh.device)
         ws = torch.empty(_lib.load().focr_lstm_ws_bytes(t_len, batch, hid, 1), device=dh.device, dtype=torch.uint8)
         wsp = _lstm_prepared(whh, 1)
-        fl, base = _lstm_flags(whh, 1, batch, t_len) if wsp is not None else (None, 0)
+        fl, fst = _lstm_flags(whh, 1, batch, t_len) if wsp is not None else (None, 0)
         _lib.call("focr_lstm_bidir_bwd_pw", _p(dh), _p(whh), _p(gates), _p(cseq), _p(dgx), _p(carry), _p(ws),
                   ctypes.c_void_p(wsp.data_ptr()) if wsp is not None else _NULL,
-                  ctypes.c_void_p(fl.data_ptr()) if fl is not None else _NULL, base, t_len, batch, hid, st_t, st_b,
-                  _stream())
+                  ctypes.c_void_p(fl.data_ptr()) if fl is not None else _NULL, fst[1] if fl is not None else 0, t_len,
+                  batch, hid, st_t, st_b, _stream())
+        if fl is not None:
+            _lstm_advance(fst, t_len)
         _lstm_check(ws if fl is None else fl, batch)
         dwhh = dbhh = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:

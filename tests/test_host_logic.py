@@ -358,13 +358,15 @@ def test_bench_self_launch_plumbing():
 
 
 def test_bench_cpu_baseline_legs_are_guarded_and_merged(monkeypatch):
-    """bench.cpu_baseline_guarded: the CPU oracle is timed at 32 threads AND at all host threads in separate child
-    processes (SURVEY 8d names os.cpu_count(); on the 256-thread GPU host that leg does not finish a batch-4 step in its
-    guard).  A leg that times out is reported under `by_threads` with its reason, `value` / `cores` are the better of the
-    legs that finished, and a host with <= 32 threads runs one leg."""
+    """bench.cpu_baseline_guarded: the CPU oracle is timed at 32 threads in a guarded child process; the all-host-threads leg
+    (SURVEY 8d names os.cpu_count(); on the 256-thread GPU host it has never finished a batch-4 step inside its guard and
+    cost every default run 70 s) runs only when the 32-thread leg FAILED or on request (FOCR_CPU_ALL_THREADS=1).  A leg that
+    times out is reported under `by_threads` with its reason, `value` / `cores` are the better of the legs that finished,
+    and a host with <= 32 threads runs one leg."""
     import json
     import bench
     calls = []
+    fail32 = [False]
 
     class R:
         def __init__(self, out):
@@ -373,16 +375,27 @@ def test_bench_cpu_baseline_legs_are_guarded_and_merged(monkeypatch):
     def fake_run(cmd, timeout=None, stdout=None, stderr=None):
         threads = int(cmd[cmd.index("--cpu-baseline-only") + 2])
         calls.append((threads, timeout))
-        if threads > 32:
+        if threads > 32 or fail32[0]:
             raise subprocess.TimeoutExpired(cmd, timeout)
         return R(json.dumps({"value": 3.5, "unit": "images/sec", "cores": threads, "kind": "port", "sample": "x"}) + "\n")
 
     monkeypatch.setattr(subprocess, "run", fake_run)
     monkeypatch.setattr(os, "cpu_count", lambda: 256)
+    monkeypatch.delenv("FOCR_CPU_ALL_THREADS", raising=False)
     r = bench.cpu_baseline_guarded("c3")
-    assert [c[0] for c in calls] == [32, 256] and calls[1][1] <= 70
-    assert r["value"] == 3.5 and r["cores"] == 32 and r["by_threads"]["32"] == 3.5
-    assert "did not finish" in r["by_threads"]["256"]
+    assert [c[0] for c in calls] == [32]                    # the 32-thread leg succeeded: nothing else is run
+    assert r["value"] == 3.5 and r["cores"] == 32 and r["by_threads"] == {"32": 3.5}
+    calls.clear()
+    monkeypatch.setenv("FOCR_CPU_ALL_THREADS", "1")
+    r = bench.cpu_baseline_guarded("c3")
+    assert [c[0] for c in calls] == [32, 256] and calls[1][1] <= 40
+    assert r["value"] == 3.5 and r["cores"] == 32 and "did not finish" in r["by_threads"]["256"]
+    calls.clear()
+    monkeypatch.delenv("FOCR_CPU_ALL_THREADS", raising=False)
+    fail32[0] = True
+    r = bench.cpu_baseline_guarded("c3")
+    assert [c[0] for c in calls] == [32, 256] and r["value"] is None and "did not finish" in r["sample"]
+    fail32[0] = False
     calls.clear()
     monkeypatch.setattr(os, "cpu_count", lambda: 8)
     r = bench.cpu_baseline_guarded("c3")
