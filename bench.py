@@ -34,8 +34,11 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA = vector
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak; the bf16x3 split issues 3 MFMA flops per algorithmic flop
 # algorithmic fwd+bwd flops per image
-FLOP_PER_IMG = {"c3": 18.131e9, "c1": 5.366e9 + 2.820e9, "c2": 15.311e9, "c5": 94.667e9}
-DEFAULT_BATCH = {"c3": 128, "c1": 128, "c2": 64, "c5": 32}
+# tfl / sfl: TBSRN (15.311 G fwd + bwd) + the frozen ResNet-[1,2,5,3] transformer recognizer of the text- /
+# stroke-focus loss: 26.8 G forward per image, run on HR (forward only) and on SR (forward + data gradient = 2 x forward)
+FLOP_PER_IMG = {"c3": 18.131e9, "c1": 5.366e9 + 2.820e9, "c2": 15.311e9, "c5": 94.667e9,
+                "tfl": 15.311e9 + 3 * 26.8e9, "sfl": 15.311e9 + 3 * 26.8e9}
+DEFAULT_BATCH = {"c3": 128, "c1": 128, "c2": 64, "c5": 32, "tfl": 128, "sfl": 128}
 PMC_ARTEFACT = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
 
 
@@ -57,7 +60,28 @@ def cpu_baseline(config="c3", budget_s=25.0, threads=None):
     host = os.cpu_count() or 1
     cores = max(1, min(host, int(threads))) if threads else max(1, min(host, 32))
     torch.set_num_threads(cores)
-    if config == "c5":
+    if config in ("tfl", "sfl"):
+        from fudanocr_amd.utils.synth import make_batch
+        from oracle import sr_oracle as O
+        from oracle import tfl_oracle as T
+        P = O.make_params(O.schema_sr("tbsrn"))
+        fill_dict_({k: v.data for k, v in P.items()})
+        R = T.make_params() if config == "tfl" else T.make_stroke_params()
+        fill_dict_(R)
+        opt = O.AdamState([v for v in P.values() if v.requires_grad])
+        table = torch.rand(37, 37, generator=torch.Generator().manual_seed(3)) + 0.5
+        dic = None
+        if config == "sfl":
+            from fudanocr_amd.loss.stroke_focus_loss import standin_decomposition
+            dic = standin_decomposition()
+
+        def run(batch):
+            lr, hr, labels = make_batch(batch, 1234)
+            t0 = time.perf_counter()
+            T.train_step_focus(P, opt, R, lr, hr, labels, config, table, dic, dropout_p=0.1)
+            return time.perf_counter() - t0
+        what = "TBSRN + %s step, fp32, torch CPU oracle" % ("TextFocusLoss" if config == "tfl" else "StrokeFocusLoss")
+    elif config == "c5":
         from fudanocr_amd.sld.synth import make_sld_batch
         from oracle import sld_oracle as O
         P = O.make_params()
@@ -218,7 +242,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3", "c5"])
+    ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3", "c5", "tfl", "sfl"],
+                    help="c3 (default) = BASELINE configs[2]; c1 / c2 / c5 = its TSRN variant / configs[1] / configs[4]; tfl / "
+                         "sfl = TBSRN trained with the reference's real criteria, TextFocusLoss (scene-text-telescope "
+                         "--text_focus) / StrokeFocusLoss (text-gestalt), on name-keyed recognizer weights (SURVEY 8f N1)")
     ap.add_argument("--arch", default=None, help="tbsrn | tsrn (c1 = --arch tsrn)")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -314,6 +341,34 @@ def main():
 
         def step():
             return step_(image, length, text_input, text_gt)
+    elif cfg in ("tfl", "sfl"):
+        import types
+        from fudanocr_amd.engine import TrainStep
+        from fudanocr_amd.smoke import build_models
+        from fudanocr_amd.utils.synth import make_batch
+        from fudanocr_amd.utils.weight_fill import fill_module_
+        net, _, _ = build_models(dev, arch, with_crnn=False)
+        if cfg == "tfl":
+            from fudanocr_amd.loss.text_focus_loss import TextFocusLoss
+            from fudanocr_amd.loss.transformer import Transformer
+            tr = fill_module_(Transformer()).to(dev).eval()
+            crit = TextFocusLoss(types.SimpleNamespace(text_focus=True), transformer=tr, device=dev,
+                                 weight_table=torch.rand(37, 37, generator=torch.Generator().manual_seed(3)) + 0.5)
+        else:
+            from fudanocr_amd.loss.stroke_focus_loss import StrokeFocusLoss, standin_decomposition
+            from fudanocr_amd.loss.transformer_english_decomposition import Transformer
+            tr = fill_module_(Transformer()).to(dev).eval()
+            crit = StrokeFocusLoss(types.SimpleNamespace(text_focus=True, stroke_lambda=50), transformer=tr, device=dev,
+                                   decomposition=standin_decomposition())
+        for p_ in tr.parameters():
+            p_.requires_grad = False
+        step_ = TrainStep(net, crit, dropout=True, wgrad_side_stream=side)
+        lr, hr, labels = make_batch(batch, 1234 + rank)
+        lr, hr = lr.to(dev), hr.to(dev)
+        enc = None
+
+        def step():
+            return step_(lr, hr, labels)
     else:
         from fudanocr_amd.engine import TrainStep
         from fudanocr_amd.smoke import build_models
@@ -344,7 +399,7 @@ def main():
     # step and now re-issues it with ONE library call per step.  The inputs are the recording's static tensors (resident
     # in HBM before the timed region starts); the attention kernels are event-timed INSIDE the timed region by probes the
     # library records around their launches on their own stream (one event pair per launch and step).
-    rec = getattr(step_, "recorded", None) if cfg != "c5" else None
+    rec = getattr(step_, "recorded", None) if cfg not in ("c5", "tfl", "sfl") else None
     launch_info = None
     if rec is not None:
         st_in = step_.recorded_inputs(lr, hr, enc)
@@ -418,7 +473,7 @@ def main():
         # batch), one short subprocess each: --all-configs prints their full JSON lines BEFORE this configuration's line;
         # the default run only records ms/step and images/s under config.other_configs (bounded: 120 s per configuration)
         import subprocess
-        for other in ("c1", "c2", "c5"):
+        for other in ("c1", "c2", "c5", "tfl", "sfl"):
             if other == cfg:
                 continue
             try:
@@ -549,12 +604,20 @@ def main():
                           "CPU-plumbing form), STN on, 16x64->32x128",
                     "c2": "TBSRN SR forward-backward only (BASELINE configs[1]): MSE loss, clip + Adam, STN on, "
                           "dropout on, 16x64->32x128",
+                    "tfl": "TBSRN train step with the reference's training criterion TextFocusLoss (scene-text-telescope "
+                           "main.py --text_focus: MSE + 10 x L1 of attention maps + 0.0005 x weighted CE; frozen "
+                           "ResNet-[1,2,5,3] transformer recognizer on HR and SR, name-keyed weights), STN on, dropout on",
+                    "sfl": "TBSRN train step with text-gestalt's StrokeFocusLoss (MSE + 50 x L1 of the stroke-level "
+                           "recognizer's attention maps on HR and SR; name-keyed weights, stand-in stroke table), STN on, "
+                           "dropout on",
                     "c5": "stroke-level-decomposition transformer recognizer train step (BASELINE configs[4]): "
                           "ResNet-[3,4,6,3] encoder + attention decoder, cross-entropy over ragged stroke sequences, "
                           "Adadelta, 3x32x32 inputs"}[cfg]
         res = {
-            "metric": "training images/sec (16x64->32x128 SR+CTC step)" if cfg != "c5"
-                      else "training images/sec (stroke-level-decomposition recognizer step)",
+            "metric": "training images/sec (stroke-level-decomposition recognizer step)" if cfg == "c5" else
+                      "training images/sec (16x64->32x128 SR step, %s criterion)" % ("text-focus" if cfg == "tfl" else
+                                                                                     "stroke-focus")
+                      if cfg in ("tfl", "sfl") else "training images/sec (16x64->32x128 SR+CTC step)",
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,

@@ -183,3 +183,31 @@ def stroke_focus_loss(P, sr, hr, labels, dic, stroke_lambda=50.0):
     pred, map_pred, correct_sr = stroke_recognizer(P, to_gray(sr), length, text_input)
     att = F.l1_loss(map_gt, map_pred)
     return mse + att * stroke_lambda, mse, att, -1, pred, map_pred, correct_hr, correct_sr
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the whole optimisation step with the text-focus / stroke-focus criterion (interfaces/super_resolution.py:69-84 with
+# image_crit = TextFocusLoss, base.py:143-150): SR network of oracle/sr_oracle.py, frozen recognizer from here.  Used by
+# tests/test_text_focus.py (full-size parity) and bench.py's cpu_baseline leg of the `tfl` / `sfl` configurations.
+# ---------------------------------------------------------------------------------------------------------------------
+def filter_labels(labels):
+    """text_focus_loss.py:85: str_filt(label, 'lower') + '-' (labels of the synthetic batches are already [0-9a-z]*)"""
+    return ["".join(c for c in s.lower() if c in ALPHABET[1:]) + "-" for s in labels]
+
+
+def train_step_focus(P_sr, opt, P_rec, lr_img, hr_img, labels, kind="tfl", table=None, dic=None, stroke_lambda=50.0,
+                     arch="tbsrn", dropout_p=0.0):
+    from . import sr_oracle as O
+    for p in opt.params:
+        p.grad = None
+    sr = O.sr_forward(P_sr, arch, lr_img, True, dropout_p=dropout_p)
+    if kind == "tfl":
+        loss, mse, att, rec = text_focus_loss(P_rec, sr, hr_img, filter_labels(labels), table)[:4]
+    else:
+        loss, mse, att, rec = stroke_focus_loss(P_rec, sr, hr_img, labels, dic, stroke_lambda)[:4]
+    (loss * 100).backward()
+    grads = [p.grad for p in opt.params if p.grad is not None]
+    gnorm = O.clip_grad_norm(grads, 0.25)
+    opt.step()
+    return {"loss": float(loss.detach()), "mse": float(mse.detach()), "att": float(att.detach()),
+            "rec": float(rec.detach()) if torch.is_tensor(rec) else rec, "grad_norm": float(gnorm), "sr": sr.detach()}

@@ -249,6 +249,70 @@ def test_trainstep_text_focus_gradient_is_loss_times_100():
     assert diff > 1e-6, "the shortcut would have been indistinguishable (%g): test is vacuous" % diff
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["tfl", "sfl"])
+def test_text_focus_full_size_step_vs_oracle(kind):
+    """One whole optimisation step of TBSRN under the reference's REAL criteria at B = 32 -- TextFocusLoss
+    (loss/text_focus_loss.py:84-99, frozen recognizer loss/transformer.py:82-389 on HR and SR) and text-gestalt's
+    StrokeFocusLoss (loss/stroke_focus_loss.py:83-118) -- HIP engine against the CPU oracle (oracle/tfl_oracle.py
+    train_step_focus) on the same seeded batch and name-keyed weights: SR pixels, every loss term, the pre-clip gradient
+    norm, and the updated parameters."""
+    import types
+    from fudanocr_amd import _lib
+    from fudanocr_amd.engine import TrainStep
+    from fudanocr_amd.loss.stroke_focus_loss import StrokeFocusLoss, standin_decomposition
+    from fudanocr_amd.loss.text_focus_loss import TextFocusLoss
+    from fudanocr_amd.model import tbsrn
+    from fudanocr_amd.utils.weight_fill import fill_module_
+    from oracle import sr_oracle as SO
+    from oracle import tfl_oracle as O
+    _lib.load()
+    dev = torch.device("cuda", 0)
+    B = 32
+    lr_img, hr, labels = make_batch(B, 4321)
+    table = torch.rand(37, 37, generator=torch.Generator().manual_seed(3)) + 0.5
+    dic = standin_decomposition()
+    if kind == "tfl":
+        from fudanocr_amd.loss.transformer import Transformer
+        tr = fill_module_(Transformer()).to(dev).eval()
+        crit = TextFocusLoss(types.SimpleNamespace(text_focus=True), transformer=tr, weight_table=table)
+        R = O.make_params()
+    else:
+        from fudanocr_amd.loss.transformer_english_decomposition import Transformer
+        tr = fill_module_(Transformer()).to(dev).eval()
+        crit = StrokeFocusLoss(types.SimpleNamespace(text_focus=True, stroke_lambda=50), transformer=tr, decomposition=dic)
+        R = O.make_stroke_params()
+    for p in tr.parameters():
+        p.requires_grad = False
+    net = fill_module_(tbsrn.TBSRN(STN=True)).to(dev)
+    step = TrainStep(net, crit, dropout=False)
+    out = step(lr_img.to(dev), hr.to(dev), labels)
+    torch.cuda.synchronize()
+    # ---- oracle
+    fill_dict_(R)
+    P = SO.make_params(SO.schema_sr("tbsrn"))
+    fill_dict_({k: v.data for k, v in P.items()})
+    opt = SO.AdamState([v for v in P.values() if v.requires_grad])
+    old = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    try:
+        ref = O.train_step_focus(P, opt, R, lr_img, hr, labels, kind, table, dic, 50.0)
+    finally:
+        torch.set_num_threads(old)
+    sr_err = float((out["sr"].cpu() - ref["sr"]).abs().max() / ref["sr"].abs().max())
+    assert sr_err < 1e-3, sr_err
+    assert abs(out["loss"].item() - ref["loss"]) <= 1e-3 * abs(ref["loss"]), (out["loss"].item(), ref["loss"])
+    assert abs(out["mse"].item() - ref["mse"]) <= 1e-3 * abs(ref["mse"])
+    assert abs(step.opt.grad_norm().item() - ref["grad_norm"]) <= 2e-2 * ref["grad_norm"], (step.opt.grad_norm().item(), ref["grad_norm"])
+    # the updated parameters (Adam's normalised step: +-lr per element wherever the gradient's sign is above the noise)
+    sd = net.state_dict()
+    worst = 0.0
+    for k in ("block1.0.weight", "block2.conv1.weight", "block4.feature_enhancer.linear.weight", "block7.0.weight"):
+        d = float((sd[k].detach().cpu() - P[k].detach()).abs().max())
+        worst = max(worst, d)
+    assert worst <= 2.5e-4, worst
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # text-gestalt half of row N1: StrokeFocusLoss + the stroke-level recognizer (fixture tools/make_golden_sfl.py)
 # ---------------------------------------------------------------------------------------------------------------------
