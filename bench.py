@@ -399,14 +399,20 @@ def main():
     # step and now re-issues it with ONE library call per step.  The inputs are the recording's static tensors (resident
     # in HBM before the timed region starts); the attention kernels are event-timed INSIDE the timed region by probes the
     # library records around their launches on their own stream (one event pair per launch and step).
-    rec = getattr(step_, "recorded", None) if cfg not in ("c5", "tfl", "sfl") else None
+    rec = getattr(step_, "recorded", None)
     launch_info = None
     if rec is not None:
-        st_in = step_.recorded_inputs(lr, hr, enc)
-        if st_in is not None:
-            lr, hr, enc = st_in
-        n_bwd = rec.probe("attn_bwd", depth=args.steps)
-        n_fwd = rec.probe("attn_fwd", depth=args.steps)
+        if cfg == "c5":
+            st_in = step_.recorded_inputs(image, text_input, text_gt)
+            if st_in is not None:
+                image, length, text_input, text_gt = st_in
+        else:
+            st_in = step_.recorded_inputs(lr, hr, enc)
+            if st_in is not None:
+                lr, hr, enc = st_in
+        if cfg != "c5":
+            rec.probe("attn_bwd", depth=args.steps)
+            rec.probe("attn_fwd", depth=args.steps)
         launch_info = dict(rec.info, host_calls_per_step=1)
     sync()
     if rec is None:

@@ -8,6 +8,8 @@ reference's nn.DataParallel (train.py:28) -- an RCCL all-reduce of the flat grad
 32 MB buckets, and the buckets behind an encoder stage are launched from autograd hooks as soon as backward has left
 that stage (the flat buffer is in forward order, so everything behind a stage boundary is final), overlapping the
 remaining backward kernels."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -32,8 +34,10 @@ class SLDTrainStep:
 
     BUCKET = 8 << 20          # floats per all-reduce message (32 MB)
 
+    REPLAY_WARMUP, MAX_RECORDINGS = 2, 2
+
     def __init__(self, model, lr=1.0, rho=0.9, process_group=None, wgrad_side_stream=True, dropout=True,
-                 boundaries=("layer1", "layer2", "layer3", "layer4")):
+                 boundaries=("layer1", "layer2", "layer3", "layer4"), replay=None):
         self.model, self.dropout = model, dropout
         self.flat = FlatBuffers(list(model.parameters()))
         self.opt = FusedAdadelta(self.flat, lr, rho)
@@ -46,6 +50,15 @@ class SLDTrainStep:
         self.comm_stream = torch.cuda.Stream() if (self.world > 1 and self.flat.flat_grad.is_cuda) else None
         self._works, self._sent_lo = [], self.flat.numel
         self.comm_timing, self._comm_events = False, []       # see engine.TrainStep.exposed_comm_ms
+        # recorded step (engine.TrainStep has the long story): dropout epoch on the device, fixed per-site seeds, the step
+        # captured once per input signature and re-issued from the library.  A signature is (batch, longest label, total
+        # label length): real label batches vary, so at most MAX_RECORDINGS signatures are recorded (each holds a private
+        # memory pool of the step's temporaries); everything else steps eagerly.
+        on_gpu = self.flat.flat_grad.is_cuda
+        self.state = K.StepState(self.flat.flat_grad.device, 0.5, 0.999) if on_gpu else None
+        self.ctx.seed_base = int(torch.randint(0, 2 ** 62, (1,), device="cpu").item()) if on_gpu else None
+        self.replay = (os.environ.get("FOCR_REPLAY", "1") != "0") if replay is None else bool(replay)
+        self._recs, self._seen, self.recorded = {}, {}, None
         ids = {id(p): off for p, off in zip(self.flat.params, self.flat.offsets)}
         enc = model.encoder
         self._stage_lo = {}
@@ -84,7 +97,88 @@ class SLDTrainStep:
             else:
                 self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
+    # ---- recorded step ------------------------------------------------------------------------------------------------
+    def _replay_ok(self, length):
+        from .. import _lib
+        return (self.replay and self.world == 1 and self.flat.flat_grad.is_cuda and _lib._timed is None
+                and getattr(length, "_focr_idx", None) is not None and not torch.cuda.is_current_stream_capturing())
+
+    def _rec_key(self, image, text_input, text_gt):
+        from .. import _lib
+        lib = _lib.load()
+        return (tuple(image.shape), tuple(text_input.shape), int(text_gt.numel()), lib.focr_get_precision(),
+                tuple(lib.focr_get_tuning(k) for k in range(5)), bool(self.dropout), bool(self.wgrad_side_stream))
+
+    @staticmethod
+    def _fill(st, image, length, text_input, text_gt):
+        if image is not st["image"]:
+            st["image"].copy_(image, non_blocking=True)
+            st["length"].copy_(length, non_blocking=True)
+            st["text_input"].copy_(text_input, non_blocking=True)
+            st["text_gt"].copy_(text_gt, non_blocking=True)
+            st["length"]._focr_idx.copy_(length._focr_idx, non_blocking=True)
+
+    def _record(self, key, image, length, text_input, text_gt):
+        import warnings
+        from .. import replay
+        st = {"image": torch.empty_like(image), "length": torch.empty_like(length),
+              "text_input": torch.empty_like(text_input), "text_gt": torch.empty_like(text_gt)}
+        st["length"]._focr_idx = torch.empty_like(length._focr_idx)
+        st["length"]._focr_host = None
+        self._fill(st, image, length, text_input, text_gt)
+        if self.ctx.side_stream_obj is None:
+            self.ctx.side_stream_obj = torch.cuda.Stream()
+        try:
+            rec, out = replay.record(lambda: self._step(st["image"], st["length"], st["text_input"], st["text_gt"]),
+                                     lanes=[torch.cuda.current_stream(), self.ctx.side_stream_obj])
+        except Exception as e:                                   # noqa: BLE001
+            warnings.warn("fudanocr_amd: recording the SLD step failed (%s: %s); stepping eagerly from here on"
+                          % (type(e).__name__, str(e)[:300]))
+            self.replay = False
+            self.ctx.deferred.clear()
+            self.ctx.premasked.clear()
+            return None
+        st["rec"], st["out"] = rec, out
+        st["rvars"] = [id(m.running_var) for m in self.model.modules()
+                       if isinstance(getattr(m, "running_var", None), torch.Tensor)]
+        self._recs[key] = st
+        return st
+
+    def recorded_inputs(self, image, text_input, text_gt):
+        st = self._recs.get(self._rec_key(image, text_input, text_gt))
+        return None if st is None else (st["image"], st["length"], st["text_input"], st["text_gt"])
+
     def __call__(self, image, length, text_input, text_gt):
+        if not self._replay_ok(length):
+            return self._step(image, length, text_input, text_gt)
+        key = self._rec_key(image, text_input, text_gt)
+        st = self._recs.get(key)
+        if st is None:
+            n = self._seen[key] = self._seen.get(key, 0) + 1
+            if n <= self.REPLAY_WARMUP or len(self._recs) >= self.MAX_RECORDINGS:
+                return self._step(image, length, text_input, text_gt)
+            st = self._record(key, image, length, text_input, text_gt)
+            if st is None:
+                return self._step(image, length, text_input, text_gt)
+        self._fill(st, image, length, text_input, text_gt)
+        st["rec"].launch()
+        self.recorded = st["rec"]
+        K.bump_weight_epoch()
+        for i in st["rvars"]:
+            K._EVAL_INVSTD.pop(i, None)
+        return st["out"]
+
+    def _step(self, image, length, text_input, text_gt):
+        if self.state is not None:
+            self.state.bind()
+            self.state.advance()
+        try:
+            return self._step_body(image, length, text_input, text_gt)
+        finally:
+            if self.state is not None:
+                self.state.unbind()
+
+    def _step_body(self, image, length, text_input, text_gt):
         self.model.train()
         if not self.dropout:
             for m in self.model.modules():
@@ -94,6 +188,7 @@ class SLDTrainStep:
         self._works, self._sent_lo = [], self.flat.numel
         on_gpu = self.flat.flat_grad.is_cuda
         c = self.ctx
+        c.new_step()                                   # dropout sites count from 0 in every step (fixed per-site seeds)
         c.frags = self.frags if on_gpu else None
         if on_gpu:
             self.frags.refresh()

@@ -227,9 +227,12 @@ class Transformer(nn.Module):
         logits = self.generator_word(x)                                    # [B, L, 7]
         if test:
             return {"pred": logits, "map": attention_map, "conv": K.to_nchw(feat)}
-        lens = getattr(text_length, "_focr_host", None)
-        if lens is None:
-            lens = [int(v) for v in text_length.tolist()]
-        idx = torch.tensor([i * length + j for i, n in enumerate(lens) for j in range(n)], dtype=torch.long)
-        probs_res = ops.gather_rows(logits.view(b * length, -1), idx.to(logits.device, non_blocking=True))
+        idx = getattr(text_length, "_focr_idx", None)          # device-resident row index (sld/util.py converter)
+        if idx is None:
+            lens = getattr(text_length, "_focr_host", None)
+            if lens is None:
+                lens = [int(v) for v in text_length.tolist()]
+            idx = torch.tensor([i * length + j for i, n in enumerate(lens) for j in range(n)],
+                               dtype=torch.long).to(logits.device, non_blocking=True)
+        probs_res = ops.gather_rows(logits.view(b * length, -1), idx)
         return {"pred": probs_res, "map": attention_map, "conv": K.to_nchw(feat)}

@@ -42,6 +42,10 @@ def converter(mode, label, table=None, device="cuda", strokes=False):
     text_all = torch.tensor([alp2num_stroke[c] for s in seqs for c in s], dtype=torch.long)
     length = torch.tensor(lens, dtype=torch.long).to(device)
     length._focr_host = lens                   # host copy: the ragged gather needs no device -> host sync
+    # rows of the [B * Lmax, classes] logits that belong to real label positions (model/transformer.py forward): built here,
+    # with the rest of the encoding, so that the step itself contains no host -> device copy (engine replay)
+    length._focr_idx = torch.tensor([i * max_length + j for i, n in enumerate(lens) for j in range(n)],
+                                    dtype=torch.long).to(device)
     return length, text_input.to(device), text_all.to(device), character_level_label
 
 

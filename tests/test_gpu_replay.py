@@ -233,3 +233,43 @@ def test_mode3_trains_like_mode1():
     assert x["mean_displacement_cosine"] >= within_cos - 0.01 and x["mean_displacement_cosine"] >= 0.98, (x, w1, w3)
     assert x["worst_displacement_cosine"] >= min(w1["worst_displacement_cosine"], w3["worst_displacement_cosine"]) - 0.03
     assert x["psnr_diff_db_mean"] <= 2 * max(w1["psnr_diff_db_max"], w3["psnr_diff_db_max"]) + 0.02, (x, w1, w3)
+
+
+def test_sld_recorded_step_equals_eager():
+    """the stroke-level-decomposition recognizer's step (reference stroke-level-decomposition/train.py:63-77) recorded and
+    re-issued from the library against the same step launched from Python, from the same restored state, dropout on:
+    loss, predictions and the Adadelta update agree to the last-bit spread of two launches"""
+    from fudanocr_amd.sld import util as sld_util
+    from fudanocr_amd.sld.engine import SLDTrainStep
+    from fudanocr_amd.sld.model.transformer import Transformer
+    from fudanocr_amd.sld.synth import make_sld_batch
+    from fudanocr_amd.utils.weight_fill import fill_module_
+    dev = torch.device("cuda", 0)
+    net = fill_module_(Transformer("stroke")).to(dev)
+    step = SLDTrainStep(net, dropout=True, replay=True)
+    image, labels = make_sld_batch(4, 77)
+    image = image.to(dev)
+    length, text_input, text_gt, _ = sld_util.converter("stroke", labels, device=dev, strokes=True)
+    assert length._focr_idx.numel() == text_gt.numel()
+    for _ in range(2):
+        step(image, length, text_input, text_gt)
+    bufs = lambda: {k: v.clone() for k, v in net.state_dict().items() if "running_" in k or "num_batches" in k}  # noqa: E731
+    for s_ in range(3):
+        snap = (step.flat.flat_param.clone(), step.opt.sq.clone(), step.opt.acc.clone(), step.state.buf.clone(), bufs())
+        res = {}
+        for how in ("replay", "eager"):
+            step.flat.flat_param.copy_(snap[0]); step.opt.sq.copy_(snap[1]); step.opt.acc.copy_(snap[2])
+            step.state.buf.copy_(snap[3])
+            sd = net.state_dict()
+            for k, b in snap[4].items():
+                sd[k].copy_(b)
+            step.replay = how == "replay"
+            out = step(image, length, text_input, text_gt)
+            res[how] = (out["loss"].item(), out["pred"].clone(), step.flat.flat_param.clone())
+        step.replay = True
+        assert step.recorded is not None and step.recorded.info["kernels"] > 100
+        (l_r, p_r, w_r), (l_e, p_e, w_e) = res["replay"], res["eager"]
+        assert abs(l_r - l_e) <= 5e-6 * abs(l_e), (s_, l_r, l_e)
+        assert float((p_r - p_e).abs().max()) <= 1e-4 * float(p_e.abs().max()), s_
+        moved = (w_e - snap[0]).abs()
+        assert float((w_r - w_e).abs().mean()) <= 0.02 * float(moved.mean()), s_
