@@ -19,7 +19,8 @@ extern "C" int focr_get_precision(void);
 #define FOCR_TUNE_LSTM_PERSISTENT 2
 #define FOCR_TUNE_ATTN_BWD_DQ_VARIANT 3
 #define FOCR_TUNE_ATTN_FWD_MASK 4
-#define FOCR_TUNING_COUNT 5
+#define FOCR_TUNE_GRU_LOADER 5
+#define FOCR_TUNING_COUNT 6
 extern "C" int focr_get_tuning(int key);
 
 #define FOCR_CHECK_ARG(cond, msg)                          \

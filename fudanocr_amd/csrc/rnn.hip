@@ -16,6 +16,7 @@
 // Layouts: gx, dgx [rows][2][4H] with row(t,b) = t*st_t + b*st_b (so the CNN's [B,T,C] output is
 // consumed without a transpose); hseq, dhseq [T][B][2H]; gates [T][B][2][4H]; cseq [T][B][2][H].
 #include "focr_common.h"
+#include <type_traits>
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 // GRU scan: 48 transcendental gate evaluations per lane and time step sit on the critical path of a wave that owns
@@ -382,7 +383,11 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ 
         o_z[e] = dz * zz[e] * (1.f - zz[e]);
         dar[s] = o_r[e]; daz[s] = o_z[e]; dhn[s] = o_h[e];
       }
+#if defined(GRU_ABL) && (GRU_ABL & 1)
+      if (valid && step == T + 5) {
+#else
       if (valid) {
+#endif
         float* xo = dgx + (size_t)row * 192 + dir * 96;
         float* ho = dgh + (size_t)row * 192 + dir * 96;
         *reinterpret_cast<float4*>(xo + u) = make_float4(o_r[0], o_r[1], o_r[2], o_r[3]);
@@ -604,7 +609,320 @@ __global__ __launch_bounds__(64) void gru_bwd_bx3_kernel(const float* __restrict
         *reinterpret_cast<float4*>(hprev + ((size_t)row * 2 + dir) * 32 + u) = p4;
       }
     }
+#if defined(GRU_ABL) && (GRU_ABL & 2)
+    if (step + 1 < T && step < 1) request(step + 1);
+#else
     if (step + 1 < T) request(step + 1);
+#endif
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = dhp[r];
+#if defined(GRU_ABL) && (GRU_ABL & 4)
+    if (step == T + 5)
+#endif
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      gbf16x8 bh_, bl_;
+      g_split8(dar + 8 * m, bh_, bl_);
+      G_MFMA3(acc, wth[0][m], wtl[0][m], bh_, bl_);
+      g_split8(daz + 8 * m, bh_, bl_);
+      G_MFMA3(acc, wth[1][m], wtl[1][m], bh_, bl_);
+      g_split8(dhn + 8 * m, bh_, bl_);
+      G_MFMA3(acc, wth[2][m], wtl[2][m], bh_, bl_);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dh[r] = acc[r];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Loader / compute wave pairs (round 6; tuning key 5, default on).  The scans above are LATENCY-bound, not matrix-bound:
+// the backward's per-step operands (24 x 16 bytes per lane: dh, r, z, n, hn, h_prev) were requested one step ahead into
+// registers and still cost 1.8 of the 3.2 us per step standalone (tools/dev/gru_bench.py, -DGRU_ABL: 202 -> 87 us without
+// the loads, T = 64) -- and 2.6x that inside the training step, where the weight-gradient stream keeps the memory system
+// busy (525 us in the c1 trace).  A wave cannot keep more than 63 vector-memory operations in flight (vmcnt), and the
+// compute wave's own stores count against that.  So the block gets a SECOND wave that does nothing but DMA the operands of
+// steps t + 1 .. t + D - 1 straight into LDS (global_load_lds, 16 bytes per lane, no registers): its vmcnt holds only
+// those transfers, the compute wave's only its stores.  One raw s_barrier per step hands a landed stage over (and the
+// stage read in the previous step back).  LDS stage = [operand j][lane] x 16 bytes = the order the DMA writes and the
+// ds_read_b128 of the same lane reads: linear, conflict-free.  Arithmetic and its order are those of the kernels above:
+// results are bit-identical (tests/test_gpu_kernels.py::test_gru_loader_waves_equal_single_wave).
+// ---------------------------------------------------------------------------------------
+#define GL_BWD_OPS 24
+#define GL_FWD_OPS 12
+#define GL_LOADERS 2            // loader waves per block: each issues every second transfer of a stage, so each wave's vmcnt
+                                // (63 at most) covers D - 1 stages in flight: 5 x 12 (backward) / 5 x 6 (forward)
+#define GL_DMAX 6
+__device__ __forceinline__ void gl_dma16(const float* g, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+// Stage layout.  An operand row (32 floats of one sequence, one direction) is one 128-byte line in HBM; a transfer
+// instruction moves 8 such lines: lane l fetches 16-byte chunk (l & 7) ^ (l >> 3) of the line of sequence 8 i + (l >> 3)
+// (i = 0..3: four instructions per operand) and the DMA drops it at LDS offset 16 l of the instruction's 1 KB slot -- every
+// instruction reads 8 whole lines (the register version read 32-byte pieces of 32 lines).  The compute lane (li, lh) finds
+// chunk c = 2 q + lh of its sequence li at slot (li >> 3), row li & 7, position c ^ (li & 7): the XOR spreads the 8 lanes
+// of a row group over different banks (rows are 128 bytes apart: unswizzled, a ds_read_b128 would be 8-way conflicted).
+__device__ __forceinline__ float4 gl_lds16(const unsigned char* base, int w, int c, int li) {
+  return *reinterpret_cast<const float4*>(base + (w * 4 + (li >> 3)) * 1024 + (li & 7) * 128 + ((c ^ (li & 7)) * 16));
+}
+// wait until at most `younger` stages of PER transfers each are outstanding (vmcnt is in order; a loader wave issues
+// nothing else)
+template <int PER>
+__device__ __forceinline__ void gl_wait_stage(int younger) {
+  switch (younger) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PER) : "memory"); break;
+  }
+}
+
+__global__ __launch_bounds__(64 * (1 + GL_LOADERS)) void gru_fwd_ld_kernel(
+    const float* __restrict__ gx, const float* __restrict__ whh, const float* __restrict__ bhh, float* __restrict__ hseq,
+    float* __restrict__ gates, int nseq, int T, int IC, int OS, int IS, int TS, int D) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gl_ring[];      // D * GL_FWD_OPS * 1024 bytes
+  const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  const int role = threadIdx.x >> 6;                    // 0 = compute, 1 .. GL_LOADERS = loaders
+  const int wid = blockIdx.x;
+  const int dir = wid & 1, grp = wid >> 1;
+  if (grp * 32 >= nseq) return;
+  const int seq = grp * 32 + li;
+  const bool valid = seq < nseq;
+  const int sc = valid ? seq : nseq - 1;
+  const long base_row = (long)(sc / IC) * OS + (long)(sc % IC) * IS;
+
+  if (role >= 1) {
+    // this lane's four source sequences (one per transfer instruction of an operand) and its chunk of their lines
+    const int r8 = lane >> 3, chunk = (lane & 7) ^ r8;
+    long brow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int sq = grp * 32 + 8 * i + r8;
+      if (sq >= nseq) sq = nseq - 1;
+      brow[i] = (long)(sq / IC) * OS + (long)(sq % IC) * IS;
+    }
+    auto run = [&](auto mec) {
+      constexpr int me = decltype(mec)::value;           // (compile-time: every transfer's operand index is a constant)
+      auto issue = [&](int step) {
+        const int t = dir ? T - 1 - step : step;
+        unsigned char* st = gl_ring + (step % D) * (GL_FWD_OPS * 1024);
+#pragma unroll
+        for (int j = 0; j < GL_FWD_OPS / GL_LOADERS; ++j) {
+          const int o = j * GL_LOADERS + me, g = o >> 2, i = o & 3;
+          gl_dma16(gx + (size_t)(brow[i] + (long)t * TS) * 192 + dir * 96 + g * 32 + 4 * chunk, st + o * 1024);
+        }
+      };
+      for (int k = 0; k < D - 1; ++k)
+        if (k < T) issue(k);
+      for (int k = 0; k < T; ++k) {
+        gl_wait_stage<GL_FWD_OPS / GL_LOADERS>(min(D - 2, T - 1 - k));
+        __builtin_amdgcn_s_barrier();                   // hand-over k: stage k is in LDS; the compute wave is done with k - 1
+        if (k + D - 1 < T) issue(k + D - 1);
+      }
+    };
+    if (role == 1) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 1>{});
+    return;
+  }
+
+  gbf16x8 wah[3][2], wal[3][2];
+  float4 bh[3][4];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = whh[((size_t)dir * 96 + g * 32 + li) * GH + unit_of(8 * m + e, lh)];
+      g_split8(v, wah[g][m], wal[g][m]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      bh[g][q] = *reinterpret_cast<const float4*>(bhh + (size_t)dir * 96 + g * 32 + 8 * q + 4 * lh);
+  }
+  float h[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) h[r] = 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the weight loads: from here on this wave's vmcnt holds stores only
+
+  for (int step = 0; step < T; ++step) {
+    const int t = dir ? T - 1 - step : step;
+    const long row = base_row + (long)t * TS;
+    // the recurrent product needs no operand of this step: it runs in front of the hand-over
+    gbf16x8 hh[2], hl[2];
+    g_split8(h, hh[0], hl[0]);
+    g_split8(h + 8, hh[1], hl[1]);
+    f32x16 ar, az, an;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ar[r] = 0.f; az[r] = 0.f; an[r] = 0.f; }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      G_MFMA3(ar, wah[0][m], wal[0][m], hh[m], hl[m]);
+      G_MFMA3(az, wah[1][m], wal[1][m], hh[m], hl[m]);
+      G_MFMA3(an, wah[2][m], wal[2][m], hh[m], hl[m]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the previous step's LDS reads are long consumed)
+    __builtin_amdgcn_s_barrier();                       // hand-over `step`
+    asm volatile("" ::: "memory");
+    const unsigned char* st = gl_ring + (step % D) * (GL_FWD_OPS * 1024);
+    float4 xg[3][4];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xg[g][q] = gl_lds16(st, g, 2 * q + lh, li);
+    float* grow = gates + ((size_t)row * 2 + dir) * 128;
+    float* hrow = hseq + (size_t)row * 64 + dir * 32;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float xr[4] = {xg[0][q].x, xg[0][q].y, xg[0][q].z, xg[0][q].w};
+      const float xz[4] = {xg[1][q].x, xg[1][q].y, xg[1][q].z, xg[1][q].w};
+      const float xn[4] = {xg[2][q].x, xg[2][q].y, xg[2][q].z, xg[2][q].w};
+      const float br[4] = {bh[0][q].x, bh[0][q].y, bh[0][q].z, bh[0][q].w};
+      const float bz[4] = {bh[1][q].x, bh[1][q].y, bh[1][q].z, bh[1][q].w};
+      const float bn[4] = {bh[2][q].x, bh[2][q].y, bh[2][q].z, bh[2][q].w};
+      float rr[4], zz[4], nn[4], hn[4], hv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int s = 4 * q + e;
+        rr[e] = fast_sigmoid(xr[e] + ar[s] + br[e]);
+        zz[e] = fast_sigmoid(xz[e] + az[s] + bz[e]);
+        hn[e] = an[s] + bn[e];
+        nn[e] = fast_tanh(xn[e] + rr[e] * hn[e]);
+        hv[e] = (1.f - zz[e]) * nn[e] + zz[e] * h[s];
+        h[s] = hv[e];
+      }
+      if (valid) {
+        const int u = 8 * q + 4 * lh;
+        *reinterpret_cast<float4*>(grow + u) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+        *reinterpret_cast<float4*>(grow + 32 + u) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+        *reinterpret_cast<float4*>(grow + 64 + u) = make_float4(nn[0], nn[1], nn[2], nn[3]);
+        *reinterpret_cast<float4*>(grow + 96 + u) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+        *reinterpret_cast<float4*>(hrow + u) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(64 * (1 + GL_LOADERS)) void gru_bwd_ld_kernel(
+    const float* __restrict__ dhseq, const float* __restrict__ whh, const float* __restrict__ gates,
+    const float* __restrict__ hseq, float* __restrict__ dgx, float* __restrict__ dgh, float* __restrict__ hprev, int nseq,
+    int T, int IC, int OS, int IS, int TS, int D) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gl_ring[];      // D * GL_BWD_OPS * 1024 bytes
+  const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  const int role = threadIdx.x >> 6;
+  const int wid = blockIdx.x;
+  const int dir = wid & 1, grp = wid >> 1;
+  if (grp * 32 >= nseq) return;
+  const int seq = grp * 32 + li;
+  const bool valid = seq < nseq;
+  const int sc = valid ? seq : nseq - 1;
+  const long base_row = (long)(sc / IC) * OS + (long)(sc % IC) * IS;
+
+  if (role >= 1) {
+    const int r8 = lane >> 3, chunk = (lane & 7) ^ r8;
+    long brow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int sq = grp * 32 + 8 * i + r8;
+      if (sq >= nseq) sq = nseq - 1;
+      brow[i] = (long)(sq / IC) * OS + (long)(sq % IC) * IS;
+    }
+    auto run = [&](auto mec) {
+      constexpr int me = decltype(mec)::value;
+      auto issue = [&](int step) {
+        const int t = dir ? step : T - 1 - step;
+        const bool has_prev = dir ? (t < T - 1) : (t > 0);
+        // (no previous step: the transfer still happens, from the step's own row, so that every stage is 24 transfers; the
+        // compute wave substitutes zeros)
+        const long dprev = has_prev ? (long)(dir ? 1 : -1) * TS : 0;
+        unsigned char* st = gl_ring + (step % D) * (GL_BWD_OPS * 1024);
+#pragma unroll
+        for (int j = 0; j < GL_BWD_OPS / GL_LOADERS; ++j) {
+          const int o = j * GL_LOADERS + me, w = o >> 2, i = o & 3;      // operand w: dh, r, z, n, hn, h_prev
+          const long row = brow[i] + (long)t * TS;
+          const float* src = w == 0 ? dhseq + (size_t)row * 64 + dir * 32
+                             : w == 5 ? hseq + (size_t)(row + dprev) * 64 + dir * 32
+                                      : gates + ((size_t)row * 2 + dir) * 128 + (w - 1) * 32;
+          gl_dma16(src + 4 * chunk, st + o * 1024);
+        }
+      };
+      for (int k = 0; k < D - 1; ++k)
+        if (k < T) issue(k);
+      for (int k = 0; k < T; ++k) {
+        gl_wait_stage<GL_BWD_OPS / GL_LOADERS>(min(D - 2, T - 1 - k));
+        __builtin_amdgcn_s_barrier();
+        if (k + D - 1 < T) issue(k + D - 1);
+      }
+    };
+    if (role == 1) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 1>{});
+    return;
+  }
+
+  gbf16x8 wth[3][2], wtl[3][2];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = whh[((size_t)dir * 96 + g * 32 + unit_of(8 * m + e, lh)) * GH + li];
+      g_split8(v, wth[g][m], wtl[g][m]);
+    }
+  float dh[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dh[r] = 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  for (int step = 0; step < T; ++step) {
+    const int t = dir ? step : T - 1 - step;
+    const bool has_prev = dir ? (t < T - 1) : (t > 0);
+    const long row = base_row + (long)t * TS;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // hand-over `step`
+    asm volatile("" ::: "memory");
+    const unsigned char* st = gl_ring + (step % D) * (GL_BWD_OPS * 1024);
+    float dar[16], daz[16], dhn[16], dhp[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int u = 8 * q + 4 * lh;
+      const int c = 2 * q + lh;
+      const float4 g4 = gl_lds16(st, 0, c, li), r4 = gl_lds16(st, 1, c, li), z4 = gl_lds16(st, 2, c, li);
+      const float4 n4 = gl_lds16(st, 3, c, li), h4 = gl_lds16(st, 4, c, li);
+      float4 p4 = gl_lds16(st, 5, c, li);
+      if (!has_prev) p4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
+      const float zz[4] = {z4.x, z4.y, z4.z, z4.w}, nn[4] = {n4.x, n4.y, n4.z, n4.w};
+      const float hn[4] = {h4.x, h4.y, h4.z, h4.w}, hp[4] = {p4.x, p4.y, p4.z, p4.w};
+      float o_r[4], o_z[4], o_n[4], o_h[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int s = 4 * q + e;
+        const float dht = gg[e] + dh[s];
+        const float dn = dht * (1.f - zz[e]);
+        const float dz = dht * (hp[e] - nn[e]);
+        dhp[s] = dht * zz[e];
+        const float dan = dn * (1.f - nn[e] * nn[e]);
+        o_n[e] = dan;
+        o_r[e] = dan * hn[e] * rr[e] * (1.f - rr[e]);
+        o_h[e] = dan * rr[e];
+        o_z[e] = dz * zz[e] * (1.f - zz[e]);
+        dar[s] = o_r[e]; daz[s] = o_z[e]; dhn[s] = o_h[e];
+      }
+      if (valid) {
+        float* xo = dgx + (size_t)row * 192 + dir * 96;
+        float* ho = dgh + (size_t)row * 192 + dir * 96;
+        *reinterpret_cast<float4*>(xo + u) = make_float4(o_r[0], o_r[1], o_r[2], o_r[3]);
+        *reinterpret_cast<float4*>(xo + 32 + u) = make_float4(o_z[0], o_z[1], o_z[2], o_z[3]);
+        *reinterpret_cast<float4*>(xo + 64 + u) = make_float4(o_n[0], o_n[1], o_n[2], o_n[3]);
+        *reinterpret_cast<float4*>(ho + u) = make_float4(o_r[0], o_r[1], o_r[2], o_r[3]);
+        *reinterpret_cast<float4*>(ho + 32 + u) = make_float4(o_z[0], o_z[1], o_z[2], o_z[3]);
+        *reinterpret_cast<float4*>(ho + 64 + u) = make_float4(o_h[0], o_h[1], o_h[2], o_h[3]);
+        *reinterpret_cast<float4*>(hprev + ((size_t)row * 2 + dir) * 32 + u) = p4;
+      }
+    }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = dhp[r];
@@ -623,13 +941,44 @@ __global__ __launch_bounds__(64) void gru_bwd_bx3_kernel(const float* __restrict
   }
 }
 
+// ring depth for a scan of T steps over `blocks` blocks: deep rings (fewer resident blocks per CU) where the launch does
+// not fill the chip anyway or the scan is long; the smallest ring that still keeps two stages in flight for short scans
+static int gl_ring_depth(int T, int blocks, int ops) {
+  int d = (T >= 32 || blocks <= 256) ? GL_DMAX : 3;
+  if (d > T + 1) d = T + 1 < 2 ? 2 : T + 1;
+  while (d > 2 && (size_t)d * ops * 1024 > 150 * 1024) --d;
+  return d;
+}
+template <typename KernT>
+static bool gl_set_lds(KernT kern, size_t lds, focr_dev_flags& attr) {
+  if (focr_dev_first(attr)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            GL_DMAX * GL_BWD_OPS * 1024) != hipSuccess)
+      return false;
+    focr_dev_mark(attr);
+  }
+  (void)lds;
+  return true;
+}
+
 extern "C" int focr_gru_bidir_fwd(const float* gx, const float* whh, const float* bhh, float* hseq,
                                   float* gates, int nseq, int T, int IC, int OS, int IS, int TS,
                                   hipStream_t stream) {
   FOCR_CHECK_ARG(gx && whh && bhh && hseq && gates, "null pointer");
   FOCR_CHECK_ARG(nseq > 0 && T > 0 && IC > 0, "bad argument");
   int waves = cdiv(nseq, 32) * 2;
-  if (focr_get_precision() != 0)
+  if (focr_get_precision() != 0 && focr_get_tuning(FOCR_TUNE_GRU_LOADER) != 0) {
+    const int D = gl_ring_depth(T, waves, GL_FWD_OPS);
+    const size_t lds = (size_t)D * GL_FWD_OPS * 1024;
+    static focr_dev_flags attr;
+    if (!gl_set_lds(gru_fwd_ld_kernel, lds, attr)) {
+      focr_set_error("focr_gru_bidir_fwd: cannot reserve %zu bytes of LDS", lds);
+      return FOCR_EHIP;
+    }
+    hipLaunchKernelGGL(gru_fwd_ld_kernel, dim3(waves), 64 * (1 + GL_LOADERS), lds, stream, gx, whh, bhh, hseq, gates, nseq, T,
+                       IC, OS, IS, TS, D);
+  }
+  else if (focr_get_precision() != 0)
     hipLaunchKernelGGL(gru_fwd_bx3_kernel, dim3(waves), 64, 0, stream, gx, whh, bhh, hseq, gates, nseq, T, IC, OS, IS, TS);
   else
     hipLaunchKernelGGL(gru_fwd_kernel, dim3(cdiv(waves, 4)), 256, 0, stream, gx, whh, bhh, hseq, gates, nseq, T, IC,
@@ -643,7 +992,17 @@ extern "C" int focr_gru_bidir_bwd(const float* dhseq, const float* whh, const fl
   FOCR_CHECK_ARG(dhseq && whh && gates && hseq && dgx && dgh && hprev, "null pointer");
   FOCR_CHECK_ARG(nseq > 0 && T > 0 && IC > 0, "bad argument");
   int waves = cdiv(nseq, 32) * 2;
-  if (focr_get_precision() != 0)
+  if (focr_get_precision() != 0 && focr_get_tuning(FOCR_TUNE_GRU_LOADER) != 0) {
+    const int D = gl_ring_depth(T, waves, GL_BWD_OPS);
+    const size_t lds = (size_t)D * GL_BWD_OPS * 1024;
+    static focr_dev_flags attr;
+    if (!gl_set_lds(gru_bwd_ld_kernel, lds, attr)) {
+      focr_set_error("focr_gru_bidir_bwd: cannot reserve %zu bytes of LDS", lds);
+      return FOCR_EHIP;
+    }
+    hipLaunchKernelGGL(gru_bwd_ld_kernel, dim3(waves), 64 * (1 + GL_LOADERS), lds, stream, dhseq, whh, gates, hseq, dgx, dgh,
+                       hprev, nseq, T, IC, OS, IS, TS, D);
+  } else if (focr_get_precision() != 0)
     hipLaunchKernelGGL(gru_bwd_bx3_kernel, dim3(waves), 64, 0, stream, dhseq, whh, gates, hseq, dgx, dgh, hprev, nseq, T,
                        IC, OS, IS, TS);
   else

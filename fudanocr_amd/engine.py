@@ -406,7 +406,7 @@ class TrainStep:
         from . import _lib
         lib = _lib.load()
         return (tuple(lr.shape), tuple(hr.shape), encoded is not None, lib.focr_get_precision(),
-                tuple(lib.focr_get_tuning(k) for k in range(5)), bool(self.dropout), bool(self.wgrad_side_stream))
+                tuple(lib.focr_get_tuning(k) for k in range(6)), bool(self.dropout), bool(self.wgrad_side_stream))
 
     @staticmethod
     def _fill(st, lr, hr, encoded):

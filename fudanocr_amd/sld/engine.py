@@ -107,7 +107,7 @@ class SLDTrainStep:
         from .. import _lib
         lib = _lib.load()
         return (tuple(image.shape), tuple(text_input.shape), int(text_gt.numel()), lib.focr_get_precision(),
-                tuple(lib.focr_get_tuning(k) for k in range(5)), bool(self.dropout), bool(self.wgrad_side_stream))
+                tuple(lib.focr_get_tuning(k) for k in range(6)), bool(self.dropout), bool(self.wgrad_side_stream))
 
     @staticmethod
     def _fill(st, image, length, text_input, text_gt):

@@ -53,7 +53,9 @@ int focr_set_precision(int mode);
  * 128-query dQ blocks; key 4: the 256-query attention forward: 2 (default) = keep-word scalar requests behind the K-fragment
  * reads (travelling under the score MFMAs) + softmax on scores relative to the running reference (cross-half max exchange
  * only in the rescale branch); 1 = the keep-word schedule alone; 0 = requests in front of the fragment reads (round 1-4).
- * Values 0 and 1 are bit-identical; 2 agrees with them to rounding whenever a rescale happens. */
+ * Values 0 and 1 are bit-identical; 2 agrees with them to rounding whenever a rescale happens.
+ * key 5: TSRN GRU scans (focr_gru_bidir_*): 1 (default) = loader / compute wave pairs, the next steps' operands DMA'd into
+ * an LDS ring by a second wave; 0 = single-wave scans with register prefetch.  Bit-identical results. */
 int focr_set_tuning(int key, int value);
 int focr_get_tuning(int key);
 int focr_get_precision(void);

@@ -944,6 +944,47 @@ def test_gru(vertical):
     close(wih.grad, torch.cat([P["weight_ih_l0"].grad, P["weight_ih_l0_reverse"].grad]), 1e-4, what="gru dWih")
 
 
+@pytest.mark.parametrize("vertical", [True, False], ids=["vertical", "horizontal"])
+def test_gru_loader_waves_equal_single_wave(vertical):
+    """tuning key 5: the GRU scans as loader / compute wave pairs (operands DMA'd into an LDS ring by a second wave,
+    csrc/rnn.hip gru_*_ld_kernel) against the single-wave scans with register prefetch: same arithmetic in the same order
+    -> bit-identical h, gate saves, gate gradients and h_prev; ragged sequence counts (a partially filled wave) and a scan
+    of ONE step included"""
+    from fudanocr_amd import _lib
+    k = K()
+    lib = _lib.load()
+    old_t, old_p = lib.focr_get_tuning(5), _lib.get_precision()
+    _lib.set_precision(2)
+    try:
+        for (b, h, w) in ((3, 16, 24), (5, 16, 64), (1, 1, 40), (2, 7, 1)):
+            rows = b * h * w
+            gx = dev(rnd(rows, 192, seed=1))
+            whh = dev(rnd(2, 96, 32, seed=2, scale=1 / 5))
+            bhh = dev(rnd(2, 96, seed=3, scale=0.1))
+            dh = dev(rnd(rows, 64, seed=4))
+            cfg = (b * w, h, w, h * w, 1, w) if vertical else (b * h, w, 1, w, 0, 1)
+            res = {}
+            for mode in (0, 1):
+                _lib.call("focr_set_tuning", 5, mode)
+                hseq = torch.full((rows, 64), float("nan"), device="cuda")
+                gates = torch.full((rows, 2, 128), float("nan"), device="cuda")
+                dgx = torch.full((rows, 192), float("nan"), device="cuda")
+                dgh = torch.full((rows, 192), float("nan"), device="cuda")
+                hprev = torch.full((rows, 2, 32), float("nan"), device="cuda")
+                _lib.call("focr_gru_bidir_fwd", gx.data_ptr(), whh.data_ptr(), bhh.data_ptr(), hseq.data_ptr(),
+                          gates.data_ptr(), *cfg, torch.cuda.current_stream().cuda_stream)
+                _lib.call("focr_gru_bidir_bwd", dh.data_ptr(), whh.data_ptr(), gates.data_ptr(), hseq.data_ptr(),
+                          dgx.data_ptr(), dgh.data_ptr(), hprev.data_ptr(), *cfg, torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                res[mode] = (hseq, gates, dgx, dgh, hprev)
+            for a_, b_, what in zip(res[0], res[1], ("h", "gates", "dgx", "dgh", "hprev")):
+                assert not torch.isnan(b_).any(), (what, (b, h, w))
+                assert torch.equal(a_, b_), (what, (b, h, w), (a_ - b_).abs().max().item())
+    finally:
+        _lib.call("focr_set_tuning", 5, old_t)
+        _lib.set_precision(old_p)
+
+
 @pytest.mark.parametrize("shape", [(3, 5, 128, 3), (2, 32, 64, 3), (1, 4, 32, 2), (70, 16, 64, 3), (2, 1, 32, 1),
                                    (5, 33, 96, 3)])
 def test_conv9x9_output_layer(shape, precision):
