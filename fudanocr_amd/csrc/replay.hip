@@ -14,6 +14,7 @@
 // Ownership (include/focr.h conventions): no device memory is allocated; the graph stays the caller's (it owns the kernel
 // argument storage the node getters point into and must outlive the handle); the handle owns only HIP events.
 #include "focr_common.h"
+#include "replay_plan.h"
 #include <vector>
 #include <algorithm>
 #include <cstring>
@@ -45,14 +46,6 @@ struct Replay {
   std::vector<Probe> probes;
   int counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long launches = 0;
-};
-
-struct Bits {
-  std::vector<uint64_t> w;
-  explicit Bits(size_t n = 0) : w((n + 63) / 64, 0) {}
-  void set(int i) { w[i >> 6] |= 1ull << (i & 63); }
-  bool get(int i) const { return (w[i >> 6] >> (i & 63)) & 1; }
-  void orin(const Bits& o) { for (size_t i = 0; i < w.size(); ++i) w[i] |= o.w[i]; }
 };
 
 #define RP_HIP(call)                                                                      \
@@ -198,64 +191,21 @@ extern "C" int focr_replay_build(void* graph_, void* const* lanes, int n_lanes, 
       return FOCR_EHIP;
     }
   }
-  // ---- lanes.  A node goes (1) behind a direct dependency that is still the last node of its lane (lowest lane first, so
-  // the main chain stays on lane 0), else (2) behind the last node of any lane that is an ANCESTOR of it (stream order then
-  // adds no ordering the graph did not have), else (3) on an unused lane, else (4) behind its latest dependency's lane.
-  std::vector<Bits> anc(n, Bits(n)), lane_anc(n_lanes, Bits(n));
-  std::vector<int> tail(n_lanes, -1);
-  for (size_t i = 0; i < n; ++i) {
-    for (int d : deps[i]) { anc[i].orin(anc[d]); anc[i].set(d); }
-    int lane = -1;
-    for (int L = 0; L < n_lanes && lane < 0; ++L)
-      if (tail[L] >= 0 && std::find(deps[i].begin(), deps[i].end(), tail[L]) != deps[i].end()) lane = L;
-    for (int L = 0; L < n_lanes && lane < 0; ++L)
-      if (tail[L] >= 0 && anc[i].get(tail[L])) lane = L;
-    for (int L = 0; L < n_lanes && lane < 0; ++L)
-      if (tail[L] < 0) lane = L;
-    if (lane < 0) lane = deps[i].empty() ? 0 : r->nodes[*std::max_element(deps[i].begin(), deps[i].end())].lane;
-    RNode& nd = r->nodes[i];
-    nd.lane = lane;
-    r->lane_used[lane] = 1;
-    // waits: dependencies on other lanes not yet ordered before this lane's tail; per foreign lane only the latest one
-    std::vector<int> need(n_lanes, -1);
-    for (int d : deps[i]) {
-      int dl = r->nodes[d].lane;
-      if (dl == lane || lane_anc[lane].get(d)) continue;
-      need[dl] = std::max(need[dl], d);
-    }
-    for (int L = 0; L < n_lanes; ++L) {
-      // (a later node of lane L than need[L] that is already ordered before us makes the wait redundant)
-      if (need[L] < 0) continue;
-      bool covered = false;
-      for (int t = tail[L]; t > need[L] && !covered; --t)
-        if (r->nodes[t].lane == L && lane_anc[lane].get(t)) covered = true;
-      if (!covered) nd.waits.push_back(need[L]);
-    }
-    for (int w : nd.waits) {
-      if (r->nodes[w].event < 0) {
-        r->nodes[w].event = (int)r->events.size();
+  // ---- lanes and cross-lane waits: replay_plan.h (pure C++, also compiled and checked on the CPU under ASan / UBSan by
+  // tests/test_host_logic.py::test_replay_plan_orders_every_dependency)
+  {
+    const focr_replay::Plan plan = focr_replay::plan_lanes(deps, n_lanes);
+    for (size_t i = 0; i < n; ++i) {
+      RNode& nd = r->nodes[i];
+      nd.lane = plan.nodes[i].lane;
+      nd.waits = plan.nodes[i].waits;
+      if (plan.nodes[i].record) {
+        nd.event = (int)r->events.size();
         r->events.push_back(nullptr);
       }
-      lane_anc[lane].orin(anc[w]);
-      lane_anc[lane].set(w);
-      r->counts[6]++;
     }
-    lane_anc[lane].orin(anc[i]);
-    lane_anc[lane].set((int)i);
-    tail[lane] = (int)i;
-  }
-  // the longest chain becomes lane 0 (the caller's stream), the next one lane 1, ...: which captured stream a chain came
-  // from is not visible in a graph, its length is -- the step's main chain is the long one
-  {
-    std::vector<int> cnt(n_lanes, 0), order(n_lanes), to(n_lanes);
-    for (const RNode& nd : r->nodes) cnt[nd.lane]++;
-    for (int L = 0; L < n_lanes; ++L) order[L] = L;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cnt[a] > cnt[b]; });
-    for (int L = 0; L < n_lanes; ++L) to[order[L]] = L;
-    for (RNode& nd : r->nodes) nd.lane = to[nd.lane];
-    std::vector<int> used(n_lanes, 0);
-    for (int L = 0; L < n_lanes; ++L) used[to[L]] = r->lane_used[L];
-    r->lane_used.swap(used);
+    r->lane_used = plan.lane_used;
+    r->counts[6] = plan.n_waits;
   }
   for (hipEvent_t& e : r->events) {
     hipError_t err = hipEventCreateWithFlags(&e, hipEventDisableTiming);

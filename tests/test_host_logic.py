@@ -400,3 +400,17 @@ def test_bench_cpu_baseline_legs_are_guarded_and_merged(monkeypatch):
     monkeypatch.setattr(os, "cpu_count", lambda: 8)
     r = bench.cpu_baseline_guarded("c3")
     assert [c[0] for c in calls] == [8] and r["cores"] == 8 and list(r["by_threads"]) == ["8"]
+
+
+def test_replay_plan_orders_every_dependency(tmp_path):
+    """csrc/replay_plan.h -- the lane / cross-lane-wait plan of a recorded step (csrc/replay.hip) -- compiled on the CPU with
+    AddressSanitizer + UBSan and checked on 600 random DAGs (tests/cpp/replay_plan_check.cpp): every dependency of every
+    node is ordered before it by lane order or by the waits the plan kept; a wait that was dropped as redundant really is."""
+    exe = str(tmp_path / "replay_plan_check")
+    src = os.path.join(ROOT, "tests", "cpp", "replay_plan_check.cpp")
+    inc = os.path.join(ROOT, "fudanocr_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-I", inc, src, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.strip().startswith("ok 602 graphs"), out.stdout
