@@ -52,9 +52,10 @@ extern "C" int focr_get_precision(void) { return g_precision.load(std::memory_or
 //                            2: single-pass backward (dQ, dK, dV from one S / dP evaluation, attention_bwd1_bx3.h; precision
 //                            modes 2 / 3, Ntok % 256 == 0, else as 1)   1: two passes, dQ pass with 256-query blocks (two
 //                            tiles per wave)   0: two passes, 128-query blocks
-//   5 "gru_loader"          1: TSRN GRU scans as loader / compute wave pairs (operands of the next steps DMA'd into an LDS
+//   5 "gru_loader"          2: 16-sequence compute waves on the 16x16x32 MFMA + one loader wave (default)
+//                            1: TSRN GRU scans as loader / compute wave pairs (operands of the next steps DMA'd into an LDS
 //                            ring by a second wave, rnn.hip)   0: single-wave scans with register prefetch (rounds 1-5)
-static std::atomic<int> g_tuning[FOCR_TUNING_COUNT] = {{1}, {1}, {1}, {2}, {2}, {1}};
+static std::atomic<int> g_tuning[FOCR_TUNING_COUNT] = {{1}, {1}, {1}, {2}, {2}, {2}};
 extern "C" int focr_set_tuning(int key, int value) {
   if (key < 0 || key >= FOCR_TUNING_COUNT) {
     focr_set_error("focr_set_tuning: unknown key %d", key);

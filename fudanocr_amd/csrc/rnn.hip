@@ -941,6 +941,275 @@ __global__ __launch_bounds__(64 * (1 + GL_LOADERS)) void gru_bwd_ld_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// 16-sequence waves (round 6, tuning key 5 = 2, the default).  With the loads out of the way the 32-sequence compute wave is
+// ISSUE-bound: ~600 instructions per step for its 16 hidden units per lane, and the T = 64 scans of the TSRN blocks are only
+// 128 such waves on a 256-CU chip.  On v_mfma_f32_16x16x32_bf16 a wave owns 16 sequences and a lane 8 hidden units -- the
+// same "the accumulators ARE the next step's B fragment" identity holds: C/D lane (col = seq = l & 15, rows 4 g4 + j,
+// g4 = l >> 4) of M-tile m is unit 16 m + 4 g4 + j, so k-slot (k-group g4, element e) of the 32-deep contraction is DEFINED
+// as unit(g4, e) = e < 4 ? 4 g4 + e : 16 + 4 g4 + (e - 4) and the lane's own eight values are its B fragment; W_hh is
+// gathered once per wave in that k order.  Twice the blocks, half the per-wave work, 18 quarter-size MFMAs per step; one
+// loader wave suffices (12 / 6 whole-line transfers per stage: 5 stages in flight within vmcnt).  Same memory layouts as
+// every other GRU kernel here; the contraction order inside an MFMA differs, so results agree with them to rounding, not
+// bit for bit.
+// ---------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) float gf32x4;
+#define G16_MFMA3(acc, ah, al, bh, bl)                                      \
+  do {                                                                      \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);    \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);    \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);    \
+  } while (0)
+__device__ __forceinline__ int unit16(int kg, int e) { return e < 4 ? 4 * kg + e : 16 + 4 * kg + (e - 4); }
+// chunk c (16 bytes) of operand w of sequence s (0..15) inside a stage: two 1 KB transfer slots per operand (8 sequences
+// each), rows at 128-byte pitch, chunk position XORed with the row (see gl_lds16)
+__device__ __forceinline__ float4 g16_lds(const unsigned char* base, int w, int c, int s) {
+  return *reinterpret_cast<const float4*>(base + (w * 2 + (s >> 3)) * 1024 + (s & 7) * 128 + ((c ^ (s & 7)) * 16));
+}
+#define G16_FWD_OPS 6
+#define G16_BWD_OPS 12
+
+__global__ __launch_bounds__(128) void gru_fwd_l16_kernel(const float* __restrict__ gx, const float* __restrict__ whh,
+                                                          const float* __restrict__ bhh, float* __restrict__ hseq,
+                                                          float* __restrict__ gates, int nseq, int T, int IC, int OS,
+                                                          int IS, int TS, int D) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gl_ring[];      // D * G16_FWD_OPS * 1024 bytes
+  const int lane = threadIdx.x & 63, sq = lane & 15, g4 = lane >> 4;
+  const int role = threadIdx.x >> 6;
+  const int wid = blockIdx.x;
+  const int dir = wid & 1, grp = wid >> 1;
+  if (grp * 16 >= nseq) return;
+
+  if (role == 1) {
+    const int r8 = lane >> 3, chunk = (lane & 7) ^ r8;
+    long brow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int q = grp * 16 + 8 * i + r8;
+      if (q >= nseq) q = nseq - 1;
+      brow[i] = (long)(q / IC) * OS + (long)(q % IC) * IS;
+    }
+    auto issue = [&](int step) {
+      const int t = dir ? T - 1 - step : step;
+      unsigned char* st = gl_ring + (step % D) * (G16_FWD_OPS * 1024);
+#pragma unroll
+      for (int o = 0; o < G16_FWD_OPS; ++o) {
+        const int g = o >> 1, i = o & 1;
+        gl_dma16(gx + (size_t)(brow[i] + (long)t * TS) * 192 + dir * 96 + g * 32 + 4 * chunk, st + o * 1024);
+      }
+    };
+    for (int k = 0; k < D - 1; ++k)
+      if (k < T) issue(k);
+    for (int k = 0; k < T; ++k) {
+      gl_wait_stage<G16_FWD_OPS>(min(D - 2, T - 1 - k));
+      __builtin_amdgcn_s_barrier();
+      if (k + D - 1 < T) issue(k + D - 1);
+    }
+    return;
+  }
+
+  const int seq = grp * 16 + sq;
+  const bool valid = seq < nseq;
+  const int sc = valid ? seq : nseq - 1;
+  const long base_row = (long)(sc / IC) * OS + (long)(sc % IC) * IS;
+  gbf16x8 wah[3][2], wal[3][2];            // A[gate unit 16 m + (l & 15)][k-slot (g4, e)] = W_hh[g*32 + 16 m + r][unit16(g4, e)]
+  float4 bh[3][2];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = whh[((size_t)dir * 96 + g * 32 + 16 * m + sq) * GH + unit16(g4, e)];
+      g_split8(v, wah[g][m], wal[g][m]);
+      bh[g][m] = *reinterpret_cast<const float4*>(bhh + (size_t)dir * 96 + g * 32 + 16 * m + 4 * g4);
+    }
+  float h[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) h[r] = 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  for (int step = 0; step < T; ++step) {
+    const int t = dir ? T - 1 - step : step;
+    const long row = base_row + (long)t * TS;
+    gbf16x8 hh, hl;
+    g_split8(h, hh, hl);
+    gf32x4 acc[3][2];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        acc[g][m] = gf32x4{0.f, 0.f, 0.f, 0.f};
+        G16_MFMA3(acc[g][m], wah[g][m], wal[g][m], hh, hl);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // hand-over `step`
+    asm volatile("" ::: "memory");
+    const unsigned char* st = gl_ring + (step % D) * (G16_FWD_OPS * 1024);
+    float* grow = gates + ((size_t)row * 2 + dir) * 128;
+    float* hrow = hseq + (size_t)row * 64 + dir * 32;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int c = 4 * m + g4, u = 16 * m + 4 * g4;
+      const float4 x0 = g16_lds(st, 0, c, sq), x1 = g16_lds(st, 1, c, sq), x2 = g16_lds(st, 2, c, sq);
+      const float xr[4] = {x0.x, x0.y, x0.z, x0.w}, xz[4] = {x1.x, x1.y, x1.z, x1.w}, xn[4] = {x2.x, x2.y, x2.z, x2.w};
+      const float br[4] = {bh[0][m].x, bh[0][m].y, bh[0][m].z, bh[0][m].w};
+      const float bz[4] = {bh[1][m].x, bh[1][m].y, bh[1][m].z, bh[1][m].w};
+      const float bn[4] = {bh[2][m].x, bh[2][m].y, bh[2][m].z, bh[2][m].w};
+      float rr[4], zz[4], nn[4], hn[4], hv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * m + e;
+        rr[e] = fast_sigmoid(xr[e] + acc[0][m][e] + br[e]);
+        zz[e] = fast_sigmoid(xz[e] + acc[1][m][e] + bz[e]);
+        hn[e] = acc[2][m][e] + bn[e];
+        nn[e] = fast_tanh(xn[e] + rr[e] * hn[e]);
+        hv[e] = (1.f - zz[e]) * nn[e] + zz[e] * h[i];
+        h[i] = hv[e];
+      }
+      if (valid) {
+        *reinterpret_cast<float4*>(grow + u) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+        *reinterpret_cast<float4*>(grow + 32 + u) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+        *reinterpret_cast<float4*>(grow + 64 + u) = make_float4(nn[0], nn[1], nn[2], nn[3]);
+        *reinterpret_cast<float4*>(grow + 96 + u) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+        *reinterpret_cast<float4*>(hrow + u) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(128) void gru_bwd_l16_kernel(const float* __restrict__ dhseq, const float* __restrict__ whh,
+                                                          const float* __restrict__ gates, const float* __restrict__ hseq,
+                                                          float* __restrict__ dgx, float* __restrict__ dgh,
+                                                          float* __restrict__ hprev, int nseq, int T, int IC, int OS,
+                                                          int IS, int TS, int D) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gl_ring[];      // D * G16_BWD_OPS * 1024 bytes
+  const int lane = threadIdx.x & 63, sq = lane & 15, g4 = lane >> 4;
+  const int role = threadIdx.x >> 6;
+  const int wid = blockIdx.x;
+  const int dir = wid & 1, grp = wid >> 1;
+  if (grp * 16 >= nseq) return;
+
+  if (role == 1) {
+    const int r8 = lane >> 3, chunk = (lane & 7) ^ r8;
+    long brow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int q = grp * 16 + 8 * i + r8;
+      if (q >= nseq) q = nseq - 1;
+      brow[i] = (long)(q / IC) * OS + (long)(q % IC) * IS;
+    }
+    auto issue = [&](int step) {
+      const int t = dir ? step : T - 1 - step;
+      const bool has_prev = dir ? (t < T - 1) : (t > 0);
+      const long dprev = has_prev ? (long)(dir ? 1 : -1) * TS : 0;      // (no previous step: own row, the compute wave zeroes it)
+      unsigned char* st = gl_ring + (step % D) * (G16_BWD_OPS * 1024);
+#pragma unroll
+      for (int o = 0; o < G16_BWD_OPS; ++o) {
+        const int w = o >> 1, i = o & 1;                                   // operand w: dh, r, z, n, hn, h_prev
+        const long row = brow[i] + (long)t * TS;
+        const float* src = w == 0 ? dhseq + (size_t)row * 64 + dir * 32
+                           : w == 5 ? hseq + (size_t)(row + dprev) * 64 + dir * 32
+                                    : gates + ((size_t)row * 2 + dir) * 128 + (w - 1) * 32;
+        gl_dma16(src + 4 * chunk, st + o * 1024);
+      }
+    };
+    for (int k = 0; k < D - 1; ++k)
+      if (k < T) issue(k);
+    for (int k = 0; k < T; ++k) {
+      gl_wait_stage<G16_BWD_OPS>(min(D - 2, T - 1 - k));
+      __builtin_amdgcn_s_barrier();
+      if (k + D - 1 < T) issue(k + D - 1);
+    }
+    return;
+  }
+
+  const int seq = grp * 16 + sq;
+  const bool valid = seq < nseq;
+  const int sc = valid ? seq : nseq - 1;
+  const long base_row = (long)(sc / IC) * OS + (long)(sc % IC) * IS;
+  // dh_prev^T[k][seq] = sum_j W_hh[j][k] dg[seq][j]: A[k = 16 m + (l & 15)][k-slot (g4, e) of gate g] = W_hh[g*32 + unit16(g4, e)][k]
+  gbf16x8 wth[3][2], wtl[3][2];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = whh[((size_t)dir * 96 + g * 32 + unit16(g4, e)) * GH + 16 * m + sq];
+      g_split8(v, wth[g][m], wtl[g][m]);
+    }
+  float dh[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) dh[r] = 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  for (int step = 0; step < T; ++step) {
+    const int t = dir ? step : T - 1 - step;
+    const bool has_prev = dir ? (t < T - 1) : (t > 0);
+    const long row = base_row + (long)t * TS;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // hand-over `step`
+    asm volatile("" ::: "memory");
+    const unsigned char* st = gl_ring + (step % D) * (G16_BWD_OPS * 1024);
+    float dar[8], daz[8], dhn[8], dhp[8];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int c = 4 * m + g4, u = 16 * m + 4 * g4;
+      const float4 g4v = g16_lds(st, 0, c, sq), r4 = g16_lds(st, 1, c, sq), z4 = g16_lds(st, 2, c, sq);
+      const float4 n4 = g16_lds(st, 3, c, sq), h4 = g16_lds(st, 4, c, sq);
+      float4 p4 = g16_lds(st, 5, c, sq);
+      if (!has_prev) p4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float gg[4] = {g4v.x, g4v.y, g4v.z, g4v.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
+      const float zz[4] = {z4.x, z4.y, z4.z, z4.w}, nn[4] = {n4.x, n4.y, n4.z, n4.w};
+      const float hn[4] = {h4.x, h4.y, h4.z, h4.w}, hp[4] = {p4.x, p4.y, p4.z, p4.w};
+      float o_r[4], o_z[4], o_n[4], o_h[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * m + e;
+        const float dht = gg[e] + dh[i];
+        const float dn = dht * (1.f - zz[e]);
+        const float dz = dht * (hp[e] - nn[e]);
+        dhp[i] = dht * zz[e];
+        const float dan = dn * (1.f - nn[e] * nn[e]);
+        o_n[e] = dan;
+        o_r[e] = dan * hn[e] * rr[e] * (1.f - rr[e]);
+        o_h[e] = dan * rr[e];
+        o_z[e] = dz * zz[e] * (1.f - zz[e]);
+        dar[i] = o_r[e]; daz[i] = o_z[e]; dhn[i] = o_h[e];
+      }
+      if (valid) {
+        float* xo = dgx + (size_t)row * 192 + dir * 96;
+        float* ho = dgh + (size_t)row * 192 + dir * 96;
+        *reinterpret_cast<float4*>(xo + u) = make_float4(o_r[0], o_r[1], o_r[2], o_r[3]);
+        *reinterpret_cast<float4*>(xo + 32 + u) = make_float4(o_z[0], o_z[1], o_z[2], o_z[3]);
+        *reinterpret_cast<float4*>(xo + 64 + u) = make_float4(o_n[0], o_n[1], o_n[2], o_n[3]);
+        *reinterpret_cast<float4*>(ho + u) = make_float4(o_r[0], o_r[1], o_r[2], o_r[3]);
+        *reinterpret_cast<float4*>(ho + 32 + u) = make_float4(o_z[0], o_z[1], o_z[2], o_z[3]);
+        *reinterpret_cast<float4*>(ho + 64 + u) = make_float4(o_h[0], o_h[1], o_h[2], o_h[3]);
+        *reinterpret_cast<float4*>(hprev + ((size_t)row * 2 + dir) * 32 + u) = p4;
+      }
+    }
+    gf32x4 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[m] = gf32x4{dhp[4 * m], dhp[4 * m + 1], dhp[4 * m + 2], dhp[4 * m + 3]};
+    gbf16x8 bh_, bl_;
+    g_split8(dar, bh_, bl_);
+    G16_MFMA3(acc[0], wth[0][0], wtl[0][0], bh_, bl_);
+    G16_MFMA3(acc[1], wth[0][1], wtl[0][1], bh_, bl_);
+    g_split8(daz, bh_, bl_);
+    G16_MFMA3(acc[0], wth[1][0], wtl[1][0], bh_, bl_);
+    G16_MFMA3(acc[1], wth[1][1], wtl[1][1], bh_, bl_);
+    g_split8(dhn, bh_, bl_);
+    G16_MFMA3(acc[0], wth[2][0], wtl[2][0], bh_, bl_);
+    G16_MFMA3(acc[1], wth[2][1], wtl[2][1], bh_, bl_);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dh[4 * m + e] = acc[m][e];
+  }
+}
+
 // ring depth for a scan of T steps over `blocks` blocks: deep rings (fewer resident blocks per CU) where the launch does
 // not fill the chip anyway or the scan is long; the smallest ring that still keeps two stages in flight for short scans
 static int gl_ring_depth(int T, int blocks, int ops) {
@@ -967,7 +1236,18 @@ extern "C" int focr_gru_bidir_fwd(const float* gx, const float* whh, const float
   FOCR_CHECK_ARG(gx && whh && bhh && hseq && gates, "null pointer");
   FOCR_CHECK_ARG(nseq > 0 && T > 0 && IC > 0, "bad argument");
   int waves = cdiv(nseq, 32) * 2;
-  if (focr_get_precision() != 0 && focr_get_tuning(FOCR_TUNE_GRU_LOADER) != 0) {
+  if (focr_get_precision() != 0 && focr_get_tuning(FOCR_TUNE_GRU_LOADER) >= 2) {
+    const int blocks = cdiv(nseq, 16) * 2;
+    int D = blocks > 512 ? 3 : GL_DMAX;
+    if (D > T + 1) D = T + 1;
+    const size_t lds = (size_t)D * G16_FWD_OPS * 1024;
+    static focr_dev_flags attr;
+    if (!gl_set_lds(gru_fwd_l16_kernel, lds, attr)) {
+      focr_set_error("focr_gru_bidir_fwd: cannot reserve %zu bytes of LDS", lds);
+      return FOCR_EHIP;
+    }
+    hipLaunchKernelGGL(gru_fwd_l16_kernel, dim3(blocks), 128, lds, stream, gx, whh, bhh, hseq, gates, nseq, T, IC, OS, IS, TS, D);
+  } else if (focr_get_precision() != 0 && focr_get_tuning(FOCR_TUNE_GRU_LOADER) != 0) {
     const int D = gl_ring_depth(T, waves, GL_FWD_OPS);
     const size_t lds = (size_t)D * GL_FWD_OPS * 1024;
     static focr_dev_flags attr;
@@ -992,7 +1272,19 @@ extern "C" int focr_gru_bidir_bwd(const float* dhseq, const float* whh, const fl
   FOCR_CHECK_ARG(dhseq && whh && gates && hseq && dgx && dgh && hprev, "null pointer");
   FOCR_CHECK_ARG(nseq > 0 && T > 0 && IC > 0, "bad argument");
   int waves = cdiv(nseq, 32) * 2;
-  if (focr_get_precision() != 0 && focr_get_tuning(FOCR_TUNE_GRU_LOADER) != 0) {
+  if (focr_get_precision() != 0 && focr_get_tuning(FOCR_TUNE_GRU_LOADER) >= 2) {
+    const int blocks = cdiv(nseq, 16) * 2;
+    int D = blocks > 512 ? 3 : GL_DMAX;
+    if (D > T + 1) D = T + 1;
+    const size_t lds = (size_t)D * G16_BWD_OPS * 1024;
+    static focr_dev_flags attr;
+    if (!gl_set_lds(gru_bwd_l16_kernel, lds, attr)) {
+      focr_set_error("focr_gru_bidir_bwd: cannot reserve %zu bytes of LDS", lds);
+      return FOCR_EHIP;
+    }
+    hipLaunchKernelGGL(gru_bwd_l16_kernel, dim3(blocks), 128, lds, stream, dhseq, whh, gates, hseq, dgx, dgh, hprev, nseq, T,
+                       IC, OS, IS, TS, D);
+  } else if (focr_get_precision() != 0 && focr_get_tuning(FOCR_TUNE_GRU_LOADER) != 0) {
     const int D = gl_ring_depth(T, waves, GL_BWD_OPS);
     const size_t lds = (size_t)D * GL_BWD_OPS * 1024;
     static focr_dev_flags attr;

@@ -54,8 +54,9 @@ int focr_set_precision(int mode);
  * reads (travelling under the score MFMAs) + softmax on scores relative to the running reference (cross-half max exchange
  * only in the rescale branch); 1 = the keep-word schedule alone; 0 = requests in front of the fragment reads (round 1-4).
  * Values 0 and 1 are bit-identical; 2 agrees with them to rounding whenever a rescale happens.
- * key 5: TSRN GRU scans (focr_gru_bidir_*): 1 (default) = loader / compute wave pairs, the next steps' operands DMA'd into
- * an LDS ring by a second wave; 0 = single-wave scans with register prefetch.  Bit-identical results. */
+ * key 5: TSRN GRU scans (focr_gru_bidir_*): 2 (default) = 16-sequence compute waves on the 16x16x32 MFMA + one loader wave
+ * that DMAs the next steps' operands into an LDS ring; 1 = 32-sequence compute wave + two loader waves; 0 = single-wave scans
+ * with register prefetch.  0 and 1 are bit-identical, 2 agrees with them to rounding. */
 int focr_set_tuning(int key, int value);
 int focr_get_tuning(int key);
 int focr_get_precision(void);

@@ -946,10 +946,11 @@ def test_gru(vertical):
 
 @pytest.mark.parametrize("vertical", [True, False], ids=["vertical", "horizontal"])
 def test_gru_loader_waves_equal_single_wave(vertical):
-    """tuning key 5: the GRU scans as loader / compute wave pairs (operands DMA'd into an LDS ring by a second wave,
-    csrc/rnn.hip gru_*_ld_kernel) against the single-wave scans with register prefetch: same arithmetic in the same order
-    -> bit-identical h, gate saves, gate gradients and h_prev; ragged sequence counts (a partially filled wave) and a scan
-    of ONE step included"""
+    """tuning key 5: the GRU scans as loader / compute wave groups (operands DMA'd into an LDS ring by loader waves,
+    csrc/rnn.hip gru_*_ld_kernel = 1, 16-sequence waves gru_*_l16_kernel = 2, the default) against the single-wave scans
+    with register prefetch (0): key 1 is the same arithmetic in the same order -> bit-identical h, gate saves, gate
+    gradients and h_prev; key 2 agrees to rounding; ragged sequence counts (a partially filled wave) and a scan of ONE step
+    included"""
     from fudanocr_amd import _lib
     k = K()
     lib = _lib.load()
@@ -964,7 +965,7 @@ def test_gru_loader_waves_equal_single_wave(vertical):
             dh = dev(rnd(rows, 64, seed=4))
             cfg = (b * w, h, w, h * w, 1, w) if vertical else (b * h, w, 1, w, 0, 1)
             res = {}
-            for mode in (0, 1):
+            for mode in (0, 1, 2):
                 _lib.call("focr_set_tuning", 5, mode)
                 hseq = torch.full((rows, 64), float("nan"), device="cuda")
                 gates = torch.full((rows, 2, 128), float("nan"), device="cuda")
@@ -977,9 +978,12 @@ def test_gru_loader_waves_equal_single_wave(vertical):
                           dgx.data_ptr(), dgh.data_ptr(), hprev.data_ptr(), *cfg, torch.cuda.current_stream().cuda_stream)
                 torch.cuda.synchronize()
                 res[mode] = (hseq, gates, dgx, dgh, hprev)
-            for a_, b_, what in zip(res[0], res[1], ("h", "gates", "dgx", "dgh", "hprev")):
-                assert not torch.isnan(b_).any(), (what, (b, h, w))
+            for a_, b_, c_, what in zip(res[0], res[1], res[2], ("h", "gates", "dgx", "dgh", "hprev")):
+                assert not torch.isnan(b_).any() and not torch.isnan(c_).any(), (what, (b, h, w))
                 assert torch.equal(a_, b_), (what, (b, h, w), (a_ - b_).abs().max().item())
+                # key 5 = 2 (16-sequence waves on the 16x16x32 MFMA): another contraction order inside the MFMA -> rounding
+                assert float((a_ - c_).abs().max()) <= 2e-5 * float(a_.abs().max()) + 1e-7, \
+                    (what, (b, h, w), (a_ - c_).abs().max().item())
     finally:
         _lib.call("focr_set_tuning", 5, old_t)
         _lib.set_precision(old_p)

@@ -28,10 +28,13 @@ def timeit(fn, iters=10, warm=3):
 
 
 h, w = 16, 64
-for name, cfg in (("vertical   (8192 x 16)", (B * w, h, w, h * w, 1, w)), ("horizontal (2048 x 64)", (B * h, w, 1, w, 0, 1))):
-    nseq, T, ic, os_, is_, ts = cfg
-    f = lambda: _lib.call("focr_gru_bidir_fwd", K._p(gx), K._p(whh), K._p(bhh), K._p(hseq), K._p(gates), nseq, T, ic, os_, is_, ts, K._stream())
-    b = lambda: _lib.call("focr_gru_bidir_bwd", K._p(dh), K._p(whh), K._p(gates), K._p(hseq), K._p(dgx), K._p(dgh), K._p(hprev), nseq, T, ic, os_, is_, ts, K._stream())
-    mf, nf = timeit(f); mb, nb = timeit(b)
-    print("%s  fwd median %7.1f min %7.1f us (%.2f us/step)   bwd median %7.1f min %7.1f us (%.2f us/step)" % (name, mf, nf, nf / T, mb, nb, nb / T))
+for tune in ([int(x) for x in os.environ["GRU_TUNE"].split(",")] if os.environ.get("GRU_TUNE") else [_lib.load().focr_get_tuning(5)]):
+  _lib.call("focr_set_tuning", 5, tune)
+  print("tuning key 5 =", tune)
+  for name, cfg in (("vertical   (8192 x 16)", (B * w, h, w, h * w, 1, w)), ("horizontal (2048 x 64)", (B * h, w, 1, w, 0, 1))):
+      nseq, T, ic, os_, is_, ts = cfg
+      f = lambda: _lib.call("focr_gru_bidir_fwd", K._p(gx), K._p(whh), K._p(bhh), K._p(hseq), K._p(gates), nseq, T, ic, os_, is_, ts, K._stream())
+      b = lambda: _lib.call("focr_gru_bidir_bwd", K._p(dh), K._p(whh), K._p(gates), K._p(hseq), K._p(dgx), K._p(dgh), K._p(hprev), nseq, T, ic, os_, is_, ts, K._stream())
+      mf, nf = timeit(f); mb, nb = timeit(b)
+      print("%s  fwd median %7.1f min %7.1f us (%.2f us/step)   bwd median %7.1f min %7.1f us (%.2f us/step)" % (name, mf, nf, nf / T, mb, nb, nb / T))
 print("checksum", float(hseq.double().sum()), float(dgx.double().sum()))
