@@ -27,11 +27,18 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 hbf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 hbf16x4;
 
-#define H3_TR 4                                    // output rows per block
-#define H3_TP 32                                   // output pixels per row and block
+#define H3_TR 4                                    // output rows per block (default shape)
+#define H3_TP 32                                   // output pixels per row and block (default shape)
 #define H3_HR (H3_TR + 2)
 #define H3_HP (H3_TP + 2)
-#define H3_PLANE_BYTES (H3_HR * H3_HP * 128)       // one bf16 plane of the halo: 26112 B
+#define H3_PLANE_BYTES (H3_HR * H3_HP * 128)       // one bf16 plane of the halo: 26112 B (the largest of the shapes below)
+// Tile shapes (round 6).  A block always owns 128 output pixels = 4 waves x one 32-pixel MFMA M tile, but maps narrower
+// than 32 pixels wasted the rest of a 4 x 32 tile on padding -- half of it at W = 16, three quarters at W = 8, which is
+// where the >= 256-channel layers of the SLD and text-focus ResNets live (16 x 16 and 8 x 8 maps).  TP = pixels per tile
+// row: 32 (4 rows), 16 (8 rows: a wave's M tile = 2 rows x 16 px) or 8 (16 rows: 4 rows x 8 px); the halo is
+// (128 / TP + 2) x (TP + 2) pixels = 204 / 180 / 180, i.e. never larger than the default's, so the LDS layout (plane
+// offsets, weight buffers behind the halo) does not depend on the shape.
+__host__ __device__ constexpr int h3_tp_for(int W) { return W <= 8 ? 8 : (W <= 16 ? 16 : 32); }
 #define H3_KSC 2                                   // MFMA k-steps (16 channels) per weight chunk
 #define H3_NCHUNK 18                               // 9 taps x 4 k-steps / 2
 #ifndef H3_DIST
@@ -42,7 +49,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 hbf16x4;
 // byte offset (inside one halo plane) of the 16-byte chunk c (channels 8c..8c+7) of halo pixel (r, p):
 // a pixel is 128 B; the chunk index is XORed with bits 1..3 of p so that the 16 lanes of a ds_read_b128 group
 // (16 different pixels, same logical chunk) land on 16 different 16-byte slots of the 256-byte bank row
-__host__ __device__ inline int h3_off(int r, int p, int c) { return ((r * H3_HP + p) * 8 + (c ^ ((p >> 1) & 7))) * 16; }
+__host__ __device__ inline int h3_off(int r, int p, int c, int hp = H3_HP) { return ((r * hp + p) * 8 + (c ^ ((p >> 1) & 7))) * 16; }
 
 // Fragment-ordered split weights: element (row n, contraction index k) of an [Nrows][K] matrix, plane 0 = hi, 1 = lo.
 // Piece (n / 32, k / 16, plane) is 1 KB: lane l = 32 * ((k >> 3) & 1) + (n & 31) holds k & 7 -- exactly the
@@ -126,10 +133,10 @@ __device__ __forceinline__ void h3_ldsr(h3_i32x4& d, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF) : "memory");
 }
 // reads of local k-step J of chunk C (tap = (3C + J) >> 2): A from the halo, B from chunk buffer C & 1
-template <int PLANES, int C, int J>
+template <int PLANES, int C, int J, int HP = H3_HP>
 __device__ __forceinline__ void h3_read_step(H3Frags<PLANES>& f, const unsigned (&aoff)[3][4], unsigned boff) {
   constexpr int l = H3_KSC * C + J, tap = l >> 2, kk = l & 3, kh = tap / 3, kw = tap - 3 * kh;
-  constexpr int ao = kh * (H3_HP * 128);
+  constexpr int ao = kh * (HP * 128);
   constexpr int bo = (C % H3_NBUF) * (2 * H3_KSC * PLANES * 1024);
   h3_ldsr<ao>(f.a[0], aoff[kw][kk]);
   if (PLANES == 2) h3_ldsr<ao + H3_PLANE_BYTES>(f.a[1], aoff[kw][kk]);
@@ -189,12 +196,14 @@ __device__ unsigned long long* h3_trace_buf;
 #define H3_STAMP(k)
 #endif
 
-template <int PLANES>
+template <int PLANES, int TP = H3_TP>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_kernel(const float* __restrict__ X, const __bf16* __restrict__ Wf,
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ R, float* __restrict__ Y,
                                                               float* __restrict__ stats, H3Geom g, float alpha,
                                                               int relu) {
+  constexpr int TR = 128 / TP, HR = TR + 2, HP = TP + 2;      // tile rows, halo rows / pixels per halo row
+  constexpr int RPW = 32 / TP;                     // image rows of a wave's 32-pixel M tile
   constexpr int NP = 2 * H3_KSC * PLANES;          // 1 KB weight pieces per chunk (2 column tiles x 3 k-steps x planes)
   constexpr int BBUF = NP * 1024;
   constexpr int HALO = PLANES * H3_PLANE_BYTES;
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       tile = id - img * tpi;
     }
   }
-  const int y0 = (tile / g.tiles_x) * H3_TR, x0 = (tile % g.tiles_x) * H3_TP;
+  const int y0 = (tile / g.tiles_x) * TR, x0 = (tile % g.tiles_x) * TP;
   const int nslices = g.Cin >> 6;
   const int ks_per_tap = g.Cin >> 4;
 
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
     for (int i = I0; i < I1; ++i) {
       const int idx = i * 256 + tid, pxl = idx >> 4, c4 = idx & 15;
-      const int r = pxl / H3_HP, p = pxl - r * H3_HP;
+      const int r = pxl / HP, p = pxl - r * HP;
       const int iy = y0 + r - 1, ix = x0 + p - 1;
       const bool ok = (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
       const int pix = ok ? iy * g.W + ix : 0;
@@ -274,12 +283,12 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
     for (int i = I0; i < I1; ++i) {
       const int idx = i * 256 + tid, pxl = idx >> 4, c4 = idx & 15;
-      const int r = pxl / H3_HP, p = pxl - r * H3_HP;
+      const int r = pxl / HP, p = pxl - r * HP;
       const int iy = y0 + r - 1, ix = x0 + p - 1;
       float4 x = v[i - I0];
       if (!((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)) x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pxl < H3_HR * H3_HP) {
-        const int o = h3_off(r, p, c4 >> 1) + (c4 & 1) * 8;
+      if (pxl < HR * HP) {
+        const int o = h3_off(r, p, c4 >> 1, HP) + (c4 & 1) * 8;
         if (PLANES == 2) {
           hbf16x4 h, l;
           h3_split4(x, h, l);
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
   };
   auto stage_halo = [&](int s) {
-    constexpr int NPASS = (H3_HR * H3_HP * 16 + 255) / 256;     // 13
+    constexpr int NPASS = (HR * HP * 16 + 255) / 256;           // 13 (12 for the narrow shapes)
     // two batches (7 + 6 loads per thread): one batch of 13 is SLOWER (staging phase 6.8 -> 7.4 us in the block trace,
     // launch 40.8 -> 42.0 us, 31 spilled VGPRs in the split-product variant) -- the phase is bandwidth-, not
     // round-trip-bound
@@ -310,7 +319,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
-      aoff[kw][kk] = lds0 + (wave * H3_HP + li + kw) * 128 + (((2 * kk + lh) ^ (((li + kw) >> 1) & 7)) << 4);
+      aoff[kw][kk] = lds0 + ((wave * RPW + li / TP) * HP + (li % TP) + kw) * 128 +
+                     (((2 * kk + lh) ^ ((((li % TP) + kw) >> 1) & 7)) << 4);
   const unsigned boff = lds0 + HALO + lane * 16;
   const int cg0 = blockIdx.y * g.cg_loop;
   constexpr int RS = 3 * PLANES;                    // LDS reads per k-step
@@ -327,7 +337,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     // residual values of the transposed epilogue (lane = 4 channels of pixel 4 i + lane / 16): requested before the
     // last slice's contraction, consumed after it
-    const int ec4 = lane & 15, epq = lane >> 4, eco = cg * 64 + ec4 * 4, oy = y0 + wave;
+    // (default shape: a wave's pixel m = 0..31 is (row y0 + wave, column x0 + m); narrow shapes: RPW rows of TP pixels)
+    const int ec4 = lane & 15, epq = lane >> 4, eco = cg * 64 + ec4 * 4, oy = y0 + wave * RPW;
     float4 rv[8];
     for (int s = 0; s < nslices; ++s) {
 #ifndef H3_ABL_STAGE
@@ -339,30 +350,30 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       if (s == nslices - 1 && g.cg_loop == 1) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const int ox = x0 + 4 * i + epq;
-          const bool ok = oy < g.H && ox < g.W;
-          const size_t pix = (size_t)(img * g.H + (ok ? oy : 0)) * g.W + (ok ? ox : 0);
+          const int m = 4 * i + epq, ox = x0 + m % TP, oyy = oy + m / TP;
+          const bool ok = oyy < g.H && ox < g.W;
+          const size_t pix = (size_t)(img * g.H + (ok ? oyy : 0)) * g.W + (ok ? ox : 0);
           rv[i] = R ? *reinterpret_cast<const float4*>(R + pix * g.ldr + eco) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
       const bool more = (s + 1 < nslices) || (gi + 1 < g.cg_loop);
       const int ncg = s + 1 < nslices ? cg : cg + 1, nsl = s + 1 < nslices ? s + 1 : 0;
       H3Frags<PLANES> fa, fb;                       // fa: step 0 of a chunk, fb: step 1
-      h3_read_step<PLANES, 0, 0>(fa, aoff, boff);
+      h3_read_step<PLANES, 0, 0, HP>(fa, aoff, boff);
       // chunk C (buffer C % 3): [DMA chunk C+2] read fb<-step1 | wait fa, MFMA fa | wait fb | chunk C+1 landed (counted
       // vmcnt: the pieces of C+2 stay in flight), barrier | read fa<-step0 of chunk C+1 | MFMA fb
 #define H3_CHUNK(C)                                                                              \
   {                                                                                              \
     if ((C) + H3_DIST < H3_NCHUNK) issue_chunk(cg, s, (C) + H3_DIST, ((C) + H3_DIST) % H3_NBUF); \
     else if (more) issue_chunk(ncg, nsl, (C) + H3_DIST - H3_NCHUNK, ((C) + H3_DIST) % H3_NBUF);  \
-    h3_read_step<PLANES, (C), 1>(fb, aoff, boff);                                                \
+    h3_read_step<PLANES, (C), 1, HP>(fb, aoff, boff);                                               \
     h3_wait<PLANES, RS>(fa);                                                                     \
     h3_mfma_step<PLANES>(acc, fa);                                                               \
     h3_wait<PLANES, 0>(fb);                                                                      \
     if ((C) + H3_DIST < H3_NCHUNK || more) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((H3_DIST - 1) * NW) : "memory"); \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
     __builtin_amdgcn_s_barrier();                                                                \
-    if ((C) + 1 < H3_NCHUNK) h3_read_step<PLANES, ((C) + 1) % H3_NCHUNK, 0>(fa, aoff, boff);     \
+    if ((C) + 1 < H3_NCHUNK) h3_read_step<PLANES, ((C) + 1) % H3_NCHUNK, 0, HP>(fa, aoff, boff);     \
     __builtin_amdgcn_sched_barrier(0);                                                           \
     h3_mfma_step<PLANES>(acc, fb);                                                               \
   }
@@ -398,8 +409,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         float4 v = make_float4(alpha * a.x + bv.x + rv[i].x, alpha * a.y + bv.y + rv[i].y, alpha * a.z + bv.z + rv[i].z,
                                alpha * a.w + bv.w + rv[i].w);
         if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-        if (oy < g.H && x0 + 4 * i + pq < g.W) {
-          const size_t pix = (size_t)(img * g.H + oy) * g.W + x0e + 4 * i + pq;
+        const int m = 4 * i + pq, oyy = oy + m / TP;
+        if (oyy < g.H && x0 + m % TP < g.W) {
+          const size_t pix = (size_t)(img * g.H + oyy) * g.W + x0e + m % TP;
           *reinterpret_cast<float4*>(Y + pix * g.ldy + co) = v;
           s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
           s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
@@ -431,7 +443,6 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     } else {
       // several output groups per block (Cin == 64, the halo must stay): direct stores; the residual values are
       // loaded as one batch from clamped addresses (never under a per-element branch)
-      const bool rowok = oy < g.H;
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         const int co = cg * 64 + nt * 32 + li;
@@ -439,17 +450,17 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         float rv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const bool ok = rowok && ox < g.W;
-          const size_t pix = (size_t)(img * g.H + (ok ? oy : 0)) * g.W + (ok ? ox : 0);
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * lh, ox = x0 + m % TP, oyy = oy + m / TP;
+          const bool ok = oyy < g.H && ox < g.W;
+          const size_t pix = (size_t)(img * g.H + (ok ? oyy : 0)) * g.W + (ok ? ox : 0);
           rv[r] = R ? R[pix * g.ldr + co] : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * lh, ox = x0 + m % TP, oyy = oy + m / TP;
           float v = alpha * acc[nt][r] + b + rv[r];
           if (relu) v = fmaxf(v, 0.f);
-          if (rowok && ox < g.W) Y[((size_t)(img * g.H + oy) * g.W + ox) * g.ldy + co] = v;
+          if (oyy < g.H && ox < g.W) Y[((size_t)(img * g.H + oyy) * g.W + ox) * g.ldy + co] = v;
         }
       }
     }
@@ -465,22 +476,23 @@ int focr_conv3x3_halo_eligible(int H, int W, int Cin, int Cout, int KH, int KW, 
          W >= 1;
 }
 
-template <int PLANES>
+template <int PLANES, int TP>
 static int launch_h3(const float* x, const __bf16* wf, const float* bias, const float* residual, float* y, float* stats,
                      int N, int H, int W, int Cin, int Cout, int ldx, int ldy, int ldr, float alpha, int relu,
                      hipStream_t stream) {
   constexpr int LDS = PLANES * H3_PLANE_BYTES + H3_NBUF * (2 * H3_KSC * PLANES) * 1024;
+  constexpr int TR = 128 / TP;
   static focr_dev_flags attr_set;
   if (focr_dev_first(attr_set)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<PLANES>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<PLANES, TP>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return 0;
     focr_dev_mark(attr_set);
   }
   H3Geom g;
   g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ldx = ldx; g.ldy = ldy; g.ldr = ldr;
-  g.tiles_x = (W + H3_TP - 1) / H3_TP;
-  g.tiles_y = (H + H3_TR - 1) / H3_TR;
+  g.tiles_x = (W + TP - 1) / TP;
+  g.tiles_y = (H + TR - 1) / TR;
   g.ksteps_total = 9 * Cin / 16;
   const int groups = Cout / 64;
   // Cin == 64: the halo is staged once and every output group is contracted from it inside the block -- unless that
@@ -488,9 +500,19 @@ static int launch_h3(const float* x, const __bf16* wf, const float* bias, const 
   const int tiles = N * g.tiles_x * g.tiles_y;
   g.cg_loop = (Cin == 64 && tiles >= 512 && !stats) ? groups : 1;   // the statistics epilogue reuses the halo's LDS
   dim3 grid(tiles, groups / g.cg_loop);
-  hipLaunchKernelGGL((conv3x3_halo_kernel<PLANES>), grid, 256, LDS, stream, x, wf, bias, residual, y, stats, g, alpha,
+  hipLaunchKernelGGL((conv3x3_halo_kernel<PLANES, TP>), grid, 256, LDS, stream, x, wf, bias, residual, y, stats, g, alpha,
                      relu);
   return 1;
+}
+template <int PLANES>
+static int launch_h3_shape(const float* x, const __bf16* wf, const float* bias, const float* residual, float* y, float* stats,
+                           int N, int H, int W, int Cin, int Cout, int ldx, int ldy, int ldr, float alpha, int relu,
+                           hipStream_t stream) {
+  switch (h3_tp_for(W)) {
+    case 8: return launch_h3<PLANES, 8>(x, wf, bias, residual, y, stats, N, H, W, Cin, Cout, ldx, ldy, ldr, alpha, relu, stream);
+    case 16: return launch_h3<PLANES, 16>(x, wf, bias, residual, y, stats, N, H, W, Cin, Cout, ldx, ldy, ldr, alpha, relu, stream);
+    default: return launch_h3<PLANES, 32>(x, wf, bias, residual, y, stats, N, H, W, Cin, Cout, ldx, ldy, ldr, alpha, relu, stream);
+  }
 }
 
 // stats != nullptr: float [tiles][Cout][2] per-block (sum, sum of squares) of the stored outputs; returns the number
@@ -500,11 +522,12 @@ int focr_conv3x3_halo(const float* x, const void* wfrag, const float* bias, cons
                       int relu, int planes, hipStream_t stream) {
   const __bf16* wf = reinterpret_cast<const __bf16*>(wfrag);
   if (planes == 1)
-    return launch_h3<1>(x, wf, bias, residual, y, stats, N, H, W, Cin, Cout, ldx, ldy, ldr, alpha, relu, stream);
-  return launch_h3<2>(x, wf, bias, residual, y, stats, N, H, W, Cin, Cout, ldx, ldy, ldr, alpha, relu, stream);
+    return launch_h3_shape<1>(x, wf, bias, residual, y, stats, N, H, W, Cin, Cout, ldx, ldy, ldr, alpha, relu, stream);
+  return launch_h3_shape<2>(x, wf, bias, residual, y, stats, N, H, W, Cin, Cout, ldx, ldy, ldr, alpha, relu, stream);
 }
 int focr_conv3x3_halo_tiles(int N, int H, int W) {
-  return N * ((W + H3_TP - 1) / H3_TP) * ((H + H3_TR - 1) / H3_TR);
+  const int tp = h3_tp_for(W), tr = 128 / tp;
+  return N * ((W + tp - 1) / tp) * ((H + tr - 1) / tr);
 }
 
 int focr_weight_prep_frag_launch(const void* descs_dev, int n, long max_threads, hipStream_t stream) {
