@@ -940,6 +940,13 @@ static inline int bwd_slabs(long rows) {
 #ifndef BN_BWD_MAXSLABS
 #define BN_BWD_MAXSLABS 2048
 #endif
+  // wide, short tensors (the SLD / text-focus ResNets: 8192 rows x 512 channels): 64-row slabs are 128 blocks, half the
+  // chip and a 26 us launch for 33 MB (profiles/r06b_c5_bygrid.txt); 16-row slabs until there are 512 blocks
+  if (s < 512) {
+    long t = (rows + 15) / 16;
+    if (t > 512) t = 512;
+    if (t > s) s = t;
+  }
   if (s > BN_BWD_MAXSLABS) s = BN_BWD_MAXSLABS;
   if (s < 1) s = 1;
   return (int)s;
