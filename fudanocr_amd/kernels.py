@@ -838,10 +838,49 @@ def batchnorm_act(x, gamma, beta, rmean, rvar, nbt, training, act=ACT_NONE, resi
     return _BatchNormAct.apply(x, gamma, beta, rmean, rvar, nbt, residual, training, act, momentum, eps, stats)
 
 
-def conv_bn(x, conv, bn, act=ACT_NONE, residual=None, take_deferred=False):
+_FOLD_BN = os.environ.get("FOCR_FOLD_BN", "1") != "0"
+
+
+def conv_bn_foldable(conv, bn, x):
+    """conv -> eval-mode BatchNorm with nothing to train (the frozen recognizers of the text- / stroke-focus losses,
+    loss/text_focus_loss.py:54-60): the normalisation is a per-channel affine map of the convolution's output and can be
+    folded into its weights and bias (as model/crnn/crnn.py does for the frozen CRNN)"""
+    if not _FOLD_BN or bn.training or not bn.track_running_stats or not x.is_cuda or conv.weight.dim() != 4:
+        return False
+    return not any(p is not None and p.requires_grad for p in (conv.weight, conv.bias, bn.weight, bn.bias))
+
+
+def _conv_bn_folded(conv, bn):
+    """(weight * a[co], (bias - mean) * a + beta), a = gamma / sqrt(running_var + eps); cached on the BatchNorm module until
+    one of the six tensors changes (address + version counter).  Replaced folds are kept alive: their addresses key the
+    frozen entries of FlipTable / FragTable and must never be reused by a newer fold."""
+    ts = (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    key = tuple((t.data_ptr(), t._version) if t is not None else None for t in ts) + (bn.eps,)
+    hit = bn.__dict__.get("_focr_fold")
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            a = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            wf = (conv.weight * a.view(-1, 1, 1, 1)).contiguous(memory_format=torch.channels_last)
+            b0 = conv.bias if conv.bias is not None else torch.zeros_like(bn.running_mean)
+            bf = ((b0 - bn.running_mean) * a + bn.bias).contiguous()
+        if hit is not None:
+            bn.__dict__.setdefault("_focr_fold_retired", []).append(hit[1:])
+        bn.__dict__["_focr_fold"] = hit = (key, wf, bf)
+    return hit[1], hit[2]
+
+
+def conv_bn(x, conv, bn, act=ACT_NONE, residual=None, take_deferred=False, relu_out=False):
     """act(bn(conv(x))) [+ residual] for a Conv2d / BatchNorm2d module pair (tbsrn.py:246-249, tsrn.py:89-93).  In
     training mode on a halo-kernel layer the convolution's epilogue emits the per-tile sums the BatchNorm needs, so
-    the two statistics passes over the conv output disappear."""
+    the two statistics passes over the conv output disappear.
+    relu_out (foldable layers only, see conv_bn_foldable): relu(bn(conv(x)) + residual) -- the tail of a ResNet basic
+    block -- as ONE convolution launch with folded weights, residual and relu in its epilogue."""
+    if conv_bn_foldable(conv, bn, x) and (relu_out or residual is None) and act in (ACT_NONE, ACT_RELU):
+        wf, bf = _conv_bn_folded(conv, bn)
+        return conv2d(x, wf, bf, pad=conv.padding, residual=residual, relu=bool(relu_out) or act == ACT_RELU,
+                      take_deferred=take_deferred)
+    if relu_out:
+        raise RuntimeError("conv_bn(relu_out=True) needs a foldable layer (check conv_bn_foldable first)")
     training = bn.training or not bn.track_running_stats
     w = conv.weight
     kh, kw = w.shape[2], w.shape[3]

@@ -29,8 +29,12 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         out = K.conv_bn(x, self.conv1, self.bn1, act=K.ACT_RELU)
-        out = K.conv_bn(out, self.conv2, self.bn2)
         residual = x if self.downsample is None else K.conv_bn(x, self.downsample[0], self.downsample[1])
+        if K.conv_bn_foldable(self.conv2, self.bn2, out):
+            # frozen, eval-mode block (the recognizers inside the text- / stroke-focus losses): relu(bn2(conv2) + residual)
+            # is one convolution launch on folded weights
+            return K.conv_bn(out, self.conv2, self.bn2, residual=residual, relu_out=True)
+        out = K.conv_bn(out, self.conv2, self.bn2)
         return ops.add_relu(out, residual)
 
 
