@@ -431,7 +431,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_bx3_wide_kernel(const float* _
       }
     }
     __syncthreads();
+#if defined(WGW_ABL) && (WGW_ABL & 1)
+    if (pc + 64 < pend && pc < pbeg + 64) load_chunk(pc + 64);
+#else
     if (pc + 64 < pend) load_chunk(pc + 64);
+#endif
+#if defined(WGW_ABL) && (WGW_ABL & 2)
+    if (pc == pend + 12345)
+#endif
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       bf16x8 ah[2], al[2], bh[2], bl[2];
