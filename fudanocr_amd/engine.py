@@ -152,6 +152,8 @@ class TrainStep:
     stream, so these collectives overlap the remaining backward kernels."""
 
     REPLAY_WARMUP = 2      # eager steps per input signature before the step is recorded (lazy tables, workspaces)
+    MAX_RECORDINGS = 3     # signatures kept (each recording owns a private memory pool of the step's temporaries): e.g. the
+    #                        full batch, an epoch's short last batch, a second precision mode; further signatures step eagerly
 
     def __init__(self, model, crit, lr=1e-4, betas=(0.5, 0.999), max_norm=0.25, process_group=None,
                  wgrad_side_stream=True, n_buckets=4, dropout=True, boundaries=("block3", "block6"),
@@ -466,7 +468,7 @@ class TrainStep:
         st = self._recs.get(key)
         if st is None:
             n = self._seen[key] = self._seen.get(key, 0) + 1
-            if n <= self.REPLAY_WARMUP:
+            if n <= self.REPLAY_WARMUP or len(self._recs) >= self.MAX_RECORDINGS:
                 return self._step(images_lr, images_hr, label_strs, encoded)
             st = self._record(key, images_lr, images_hr, encoded)
             if st is None:
