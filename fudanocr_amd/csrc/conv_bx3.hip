@@ -5,6 +5,7 @@
 // End-to-end error equals plain fp32's (tools/exp_split_precision.py); MFMA time is 3/16 of the
 // f32-MFMA kernel's, so these layers become L2/HBM-traffic bound instead.
 #include "focr_common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -15,6 +16,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
 struct ConvGeomX {
   int N, H, W, Cin, OH, OW, Cout, KH, KW, padH, padW, Ktot, M, ldy, ldr, ldx;
+  int xcd_nk = 0, xcd_sp = 0;      // conv_wgrad_bx3_wide_kernel, XCD-aware 1-D grid: k tiles, pixel splits (multiple of 8); 0 = 3-D grid
 };
 
 __device__ __forceinline__ void split4(float4 v, bf16x4& hi, bf16x4& lo) { focr_split4(v, hi, lo); }
@@ -365,14 +367,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_bx3_wide_kernel(const float* _
                                                                   ConvGeomX g, int ldd, int pix_per_split) {
   __shared__ __attribute__((aligned(16))) __bf16 Dth[128 * WTP], Dtl[128 * WTP], Xth[128 * WTP], Xtl[128 * WTP];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-  const int k0 = blockIdx.x * 128, co0 = blockIdx.y * 128;
-  const int pbeg = blockIdx.z * pix_per_split;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (g.xcd_nk > 0) {
+    // XCD-aware decode of a 1-D grid: blocks are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.  The pixel
+    // split is tied to the XCD, so an XCD's blocks -- all k / co tiles of ONE eighth of the pixels -- re-read a working set
+    // (that eighth of X and dY) that fits its L2 instead of streaming both whole tensors through every L2
+    const int id = blockIdx.x, xcd = id & 7, t = id >> 3, spx = g.xcd_sp >> 3;
+    bz = xcd + 8 * (t % spx);
+    const int tile = t / spx;
+    bx = tile % g.xcd_nk;
+    by = tile / g.xcd_nk;
+  }
+  const int k0 = bx * 128, co0 = by * 128;
+  const int pbeg = bz * pix_per_split;
   const int pend = min(g.M, pbeg + pix_per_split);
   if (pbeg >= pend) return;
   const int tap = k0 / g.Cin, ci0 = k0 - tap * g.Cin;
   const int tkh = tap / g.KW, tkw = tap - tkh * g.KW;
   const int pq = tid & 15, c4 = (tid >> 4) * 4;
-  const bool do_bias = dbias != nullptr && blockIdx.x == 0;
+  const bool do_bias = dbias != nullptr && bx == 0;
   float bsum[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 
   float4 dv0[4], dv1[4], xv0[4], xv1[4];
@@ -475,7 +488,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bx3_wide_kernel(const float* _
       atomicAdd(&dbias[co0 + tid], s2);
     }
   }
-  float* out = PART ? PART + (size_t)blockIdx.z * g.Cout * g.Ktot : dW;
+  float* out = PART ? PART + (size_t)bz * g.Cout * g.Ktot : dW;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -544,6 +557,18 @@ int focr_conv_wgrad_bx3(const float* x, const float* dy, float* dw, float* dbias
     const long need = focr_conv_wgrad_bx3_ws_floats(M, Cin, Cout, g.Ktot);
     float* part = (ws && need > 0 && ws_floats >= need) ? ws : nullptr;
     dim3 gridw(g.Ktot / 128, Cout / 128, sp);
+    // large layers (the SLD / text-focus ResNets: X and dY are 16 MB each and every tile re-reads them): eight pixel splits,
+    // one per XCD (see the kernel); needs >= 8 chunks of 64 pixels per split and no partial-slot path
+    static const int xcd_mode = getenv("FOCR_WGW_XCD") ? atoi(getenv("FOCR_WGW_XCD")) : 1;
+    if (xcd_mode && !part && (long)g.Ktot * Cout >= (1l << 22) && M >= 8 * 512) {   // (512 -> 512 is slower this way: 190 -> 212 us)
+      const int spx = 8 * xcd_mode;
+      pp = (((M + spx - 1) / spx + 63) / 64) * 64;
+      if ((long)pp * (spx - 1) < M) {
+        g.xcd_nk = g.Ktot / 128;
+        g.xcd_sp = spx;
+        gridw = dim3((g.Ktot / 128) * (Cout / 128) * spx, 1, 1);
+      }
+    }
     hipLaunchKernelGGL(conv_wgrad_bx3_wide_kernel, gridw, 256, 0, stream, x, dy, dw, dbias, part, g, ldd, pp);
     if (part) {
       const long n4 = (long)Cout * g.Ktot / 4;

@@ -31,4 +31,11 @@ for (n, h, w, cin, cout) in ((32, 16, 16, 256, 256), (32, 16, 16, 512, 512), (32
                           K._p(ws), nws, K._stream())
     med, mn = timeit(f)
     fl = 2.0 * m * 9 * cin * cout
-    print("%4d -> %4d  median %7.1f min %7.1f us  %6.1f TFLOP/s algorithmic" % (cin, cout, med, mn, fl / mn / 1e6))
+    err = ""
+    if cin == 256:                      # correctness against torch (fp64 on the host is too slow: fp32 conv backward on the device)
+        dw.zero_(); db.zero_(); f(); torch.cuda.synchronize()
+        ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double().cpu(), (cout, cin, 3, 3), dy.permute(0, 3, 1, 2).double().cpu(), padding=1)
+        got = dw.permute(0, 3, 1, 2).double().cpu()
+        err = "  rel-to-max err %.2e, bias err %.2e" % (float((got - ref).abs().max() / ref.abs().max()),
+                                                       float((db.double().cpu() - dy.double().sum((0, 1, 2)).cpu()).abs().max() / dy.double().sum((0, 1, 2)).abs().max().cpu()))
+    print("%4d -> %4d  median %7.1f min %7.1f us  %6.1f TFLOP/s algorithmic%s" % (cin, cout, med, mn, fl / mn / 1e6, err))
