@@ -85,6 +85,7 @@ SIGNATURES = {
     "focr_lstm_persistent_usable": [I, I],
     "focr_gru_bidir_fwd": [P, P, P, P, P, I, I, I, I, I, I, P],
     "focr_gru_bidir_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "focr_gru_whh_extract": [P, P, P, I, P],
     "focr_conv9x9_small_cout_fwd": [P, P, P, P, I, I, I, I, I, P],
     "focr_conv9x9_small_cout_wgrad": [P, P, P, P, I, I, I, I, I, I, P],
     "focr_conv9x9_small_cout_wgrad_ws": [P, P, P, P, P, L, I, I, I, I, I, P],

@@ -59,7 +59,13 @@ __device__ __forceinline__ void lw_split(const lw_f32x2 (&v)[8], int t, lw_bf16x
 // is 256 bytes, so the two lane quarters of a DMA piece fetch the same 64 columns (the LDS image keeps the 512-byte row
 // slots, columns 64.. are never read), all four waves read dY columns 0..63, and the wave pair (wi = 0 / 1) of a K half
 // takes the even / odd 16-row stages; the pair's tiles are added through LDS after the loop (fixed order: even + odd).
-template <bool HALF>
+// QUART (round 6): K = 64 AND a 64-wide Cout tile (grid.y = Cout / 64): the GRU blocks' weight gradients of TSRN -- W_ih
+// (64 -> 192), the 1x1 convolution (64 -> 64) and, as the diagonal blocks of the [192 x 64] cross product of the gate
+// gradients with h_prev of both directions, W_hh.  Both operands' rows are 256 bytes, both keep the 512-byte row slots
+// (lane quarters fetch the same 64 columns), all four waves own the SAME 64 x 64 tile and take every fourth 16-row
+// stage; waves 1-3 are folded into wave 0 through LDS after the loop (fixed order).  These layers ran on the generic
+// kernels at 67-99 us for 67-134 MB (profiles/r06c_c1_bygrid.txt).
+template <bool HALF, bool QUART = false>
 __global__ __launch_bounds__(256, 2) void linear_wgrad_stream_kernel(const float* __restrict__ X,
                                                                      const float* __restrict__ dY,
                                                                      float* __restrict__ PART, int M, int ldx, int ldd,
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_stream_kernel(const float
   extern __shared__ __attribute__((aligned(16))) unsigned char lw_smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int wi = wave >> 1, wj = wave & 1;
-  const int k0 = blockIdx.x * 128, co0 = blockIdx.y * 128;
+  const int k0 = QUART ? 0 : blockIdx.x * 128, co0 = blockIdx.y * (QUART ? 64 : 128);
   const int row_beg = blockIdx.z * rows_per_split;
   const int row_end = min(M, row_beg + rows_per_split);
   const int nchunks = (row_end - row_beg) / LW_ROWS;          // the launcher hands out multiples of 16 rows
@@ -81,7 +87,8 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_stream_kernel(const float
   for (int i = 0; i < 4; ++i) {
     const int P = wave + 4 * i, mat = P >> 3, q = P & 7;
     const int ld = mat ? ldx : ldd;
-    gp[i] = (mat ? X + k0 : dY + co0) + (size_t)(row_beg + 2 * q + lh) * ld + 4 * ((HALF && !mat) ? (li & 15) : li);
+    gp[i] = (mat ? X + k0 : dY + co0) + (size_t)(row_beg + 2 * q + lh) * ld +
+            4 * ((QUART || (HALF && !mat)) ? (li & 15) : li);
     gstep[i] = (size_t)LW_ROWS * ld;
     ldso[i] = mat * LW_MAT + q * LW_PIECE;
   }
@@ -104,11 +111,11 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_stream_kernel(const float
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   float bsum[2] = {0.f, 0.f};
-  const bool do_bias = want_bias && blockIdx.x == 0 && wj == 0;
+  const bool do_bias = want_bias && blockIdx.x == 0 && (QUART || wj == 0);
 
   // fragment read addresses inside a stage: rows 8 lh + j, columns 64 w + 2 li (+ t)
-  const unsigned aoff = lbase + (4 * lh) * LW_PIECE + ((HALF ? 0 : 64 * wi) + 2 * li) * 4;
-  const unsigned boff = lbase + LW_MAT + (4 * lh) * LW_PIECE + (64 * wj + 2 * li) * 4;
+  const unsigned aoff = lbase + (4 * lh) * LW_PIECE + (((HALF || QUART) ? 0 : 64 * wi) + 2 * li) * 4;
+  const unsigned boff = lbase + LW_MAT + (4 * lh) * LW_PIECE + ((QUART ? 0 : 64 * wj) + 2 * li) * 4;
 
 #pragma unroll
   for (int c = 0; c < LW_NS - 1; ++c)
@@ -121,7 +128,9 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_stream_kernel(const float
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();       // every wave's pieces of stage c are in LDS; stage c - 1 is free again
     if (c + LW_NS - 1 < nchunks) issue(c + LW_NS - 1);
-    if (HALF && (c & 1) != wi) continue;                      // (wave-uniform) the partner wave takes this stage
+    if (QUART) {
+      if ((c & 3) != wave) continue;                          // (wave-uniform) every wave takes every fourth stage
+    } else if (HALF && (c & 1) != wi) continue;               // (wave-uniform) the partner wave takes this stage
     const unsigned st = (unsigned)(c % LW_NS) * LW_STAGE;
     LwRaw raw;
     lw_read(raw, aoff + st, boff + st);
@@ -148,7 +157,34 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_stream_kernel(const float
         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
       }
   }
-  if (HALF) {
+  if (QUART) {
+    // waves 1..3 -> LDS -> added into wave 0 in wave order: the stage buffers are idle now (3 x 16.9 KB of the 67.5 KB)
+    __syncthreads();
+    if (wave > 0) {
+      float* red = reinterpret_cast<float*>(lw_smem) + (wave - 1) * (4 * 16 + 2) * 64 + lane;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((a * 2 + b) * 16 + r) * 64] = acc[a][b][r];
+      red[64 * 64] = bsum[0];
+      red[65 * 64] = bsum[1];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    for (int w = 0; w < 3; ++w) {
+      const float* red = reinterpret_cast<const float*>(lw_smem) + w * (4 * 16 + 2) * 64 + lane;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][b][r] += red[((a * 2 + b) * 16 + r) * 64];
+      bsum[0] += red[64 * 64];
+      bsum[1] += red[65 * 64];
+    }
+  } else if (HALF) {
     // odd-stage tiles (wi = 1) -> LDS -> added to the even-stage tiles (wi = 0): the stage buffers are idle now
     __syncthreads();
     float* red = reinterpret_cast<float*>(lw_smem) + wj * (4 * 16 + 2) * 64 + lane;
@@ -179,15 +215,15 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_stream_kernel(const float
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int co = co0 + (HALF ? 0 : 64 * wi) + 2 * i + a;
+      const int co = co0 + ((HALF || QUART) ? 0 : 64 * wi) + 2 * i + a;
       float2 v = make_float2(acc[a][0][r], acc[a][1][r]);
-      *reinterpret_cast<float2*>(slot + (size_t)co * K + k0 + 64 * wj + 2 * li) = v;
+      *reinterpret_cast<float2*>(slot + (size_t)co * K + k0 + (QUART ? 0 : 64 * wj) + 2 * li) = v;
     }
   if (do_bias) {
     bsum[0] += __shfl_xor(bsum[0], 32);
     bsum[1] += __shfl_xor(bsum[1], 32);
     if (lh == 0)
-      *reinterpret_cast<float2*>(slot + (size_t)Cout * K + co0 + (HALF ? 0 : 64 * wi) + 2 * li) = make_float2(bsum[0], bsum[1]);
+      *reinterpret_cast<float2*>(slot + (size_t)Cout * K + co0 + ((HALF || QUART) ? 0 : 64 * wi) + 2 * li) = make_float2(bsum[0], bsum[1]);
   }
 }
 
@@ -234,16 +270,20 @@ __global__ __launch_bounds__(256) void slot_reduce_kernel(const float* __restric
 #ifndef LW_BLOCKS
 #define LW_BLOCKS 512
 #endif
+static inline bool lw_quart(int K, int Cout) { return K == 64 && Cout % 64 == 0 && Cout <= 256; }
 static void lw_splits(long M, int K, int Cout, int& sp, int& rows) {
-  const int tiles = (K / 128) * (Cout >= 128 ? Cout / 128 : 1);
+  const int tiles = lw_quart(K, Cout) ? Cout / 64 : (K / 128) * (Cout >= 128 ? Cout / 128 : 1);
   sp = LW_BLOCKS / tiles;
   if (sp < 1) sp = 1;
   rows = (int)(((M + sp - 1) / sp + LW_ROWS - 1) / LW_ROWS) * LW_ROWS;
   if (rows < 4 * LW_ROWS) rows = 4 * LW_ROWS;
+  if (lw_quart(K, Cout) && rows < 16 * LW_ROWS) rows = 16 * LW_ROWS;      // four stages per wave at least
   sp = (int)((M + rows - 1) / rows);
 }
 int focr_linear_wgrad_eligible(long M, int K, int Cout, int ldx, int ldd) {
   static const bool half_ok = !(getenv("FOCR_LW_HALF") && getenv("FOCR_LW_HALF")[0] == '0');      // A/B: 128 -> 64 on the generic kernel
+  static const bool quart_ok = !(getenv("FOCR_LW_QUART") && getenv("FOCR_LW_QUART")[0] == '0');  // A/B: K = 64 layers on the generic kernels
+  if (lw_quart(K, Cout)) return quart_ok && M >= 4096 && M % LW_ROWS == 0 && ldx % 4 == 0 && ldd % 4 == 0;
   if (Cout == 64 && !half_ok) return 0;
   return M >= 1024 && M % LW_ROWS == 0 && K % 128 == 0 && (Cout % 128 == 0 || Cout == 64) && ldx % 4 == 0 && ldd % 4 == 0 &&
          (long)K * Cout <= 128 * 384;
@@ -266,11 +306,16 @@ int focr_linear_wgrad(const float* x, const float* dy, float* dw, float* dbias, 
     if (hipFuncSetAttribute((const void*)linear_wgrad_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             LW_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)linear_wgrad_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            LW_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)linear_wgrad_stream_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             LW_LDS) != hipSuccess)
       return 1;                                        // caller falls back to the generic weight-gradient kernel
     focr_dev_mark(attr_done);
   }
-  if (Cout == 64)
+  if (lw_quart(K, Cout))
+    hipLaunchKernelGGL((linear_wgrad_stream_kernel<false, true>), dim3(1, Cout / 64, sp), 256, LW_LDS, stream, x, dy, ws, (int)M,
+                       ldx, ldd, K, Cout, rows, dbias ? 1 : 0);
+  else if (Cout == 64)
     hipLaunchKernelGGL(linear_wgrad_stream_kernel<true>, dim3(K / 128, 1, sp), 256, LW_LDS, stream, x, dy, ws, (int)M, ldx,
                        ldd, K, Cout, rows, dbias ? 1 : 0);
   else

@@ -1230,6 +1230,30 @@ static bool gl_set_lds(KernT kern, size_t lds, focr_dev_flags& attr) {
   return true;
 }
 
+// dW_hh of both directions from the [192 x 64] cross product G = dgh^T [h_prev(dir 0) | h_prev(dir 1)] that ONE streaming
+// weight-gradient launch produces (linear_wgrad.hip, QUART mode): dW_hh[d][j][k] = G[96 d + j][32 d + k]; the off-diagonal
+// blocks (gate gradients of one direction against the other direction's state) are discarded.
+// cross also carries, behind the matrix, the 192 column sums of dgh (the bias output of the same launch) = db_hh of both
+// directions.
+__global__ __launch_bounds__(256) void gru_whh_extract_kernel(const float* __restrict__ G, float* __restrict__ dwhh,
+                                                              float* __restrict__ dbhh, int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;          // 2 * 96 * 32 = 6144 matrix elements + 192 bias elements
+  if (i < 6144) {
+    const int d = i / 3072, r = i - d * 3072, j = r >> 5, k = r & 31;
+    const float v = G[(96 * d + j) * 64 + 32 * d + k];
+    dwhh[i] = accumulate ? dwhh[i] + v : v;
+  } else if (i < 6144 + 192 && dbhh) {
+    const float v = G[192 * 64 + (i - 6144)];
+    dbhh[i - 6144] = accumulate ? dbhh[i - 6144] + v : v;
+  }
+}
+extern "C" int focr_gru_whh_extract(const float* cross, float* dwhh, float* dbhh, int accumulate, hipStream_t stream) {
+  FOCR_CHECK_ARG(cross && dwhh, "null pointer");
+  hipLaunchKernelGGL(gru_whh_extract_kernel, dim3(25), 256, 0, stream, cross, dwhh, dbhh, accumulate);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+
 extern "C" int focr_gru_bidir_fwd(const float* gx, const float* whh, const float* bhh, float* hseq,
                                   float* gates, int nseq, int T, int IC, int OS, int IS, int TS,
                                   hipStream_t stream) {

@@ -1932,6 +1932,9 @@ def lstm_recurrence(gx, whh, bhh, t_len, batch, st_t, st_b):
 # ----------------------------------------------------------------------------------------
 # bidirectional GRU of the TSRN blocks (recurrent part; the input projection is a `linear`)
 # ----------------------------------------------------------------------------------------
+_GRU_WHH_CROSS = os.environ.get("FOCR_GRU_WHH_CROSS", "1") != "0"
+
+
 class _GRURecur(torch.autograd.Function):
     """gx [rows,192] (= x W_ih^T + b_ih, both directions), whh [2,96,32], bhh [2,96] -> h [rows,64].
     Sequences are addressed in place on the NHWC map: row(n,t) = (n//IC)*OS + (n%IC)*IS + t*TS."""
@@ -1964,9 +1967,21 @@ class _GRURecur(torch.autograd.Function):
         pz = int(tw is not None and tb is not None)
         dwhh = tw if pz else torch.empty((2, 96, 32), device=dh.device)
         dbhh = tb if pz else torch.empty((2, 96), device=dh.device)
-        for d in (0, 1):     # dW_hh[d] = dgh[:, d]^T hprev[:, d]  -- the generic wgrad on strided views
-            _lib.call("focr_conv2d_wgrad", _po(hprev, 32 * d), _po(dgh, 96 * d), _po(dwhh, 96 * 32 * d),
-                      _po(dbhh, 96 * d), rows, 1, 1, 32, 96, 1, 1, 0, 0, 192, 64, pz, _NULL, 0, _stream())
+        nws = _lib.load().focr_conv2d_wgrad_ws_floats(rows, 1, 1, 64, 192, 1, 1, 0, 0)
+        if nws > 0 and _lib.get_precision() != 0 and rows >= 4096 and rows % 16 == 0 and _GRU_WHH_CROSS:
+            # both directions from ONE streaming pass over dgh [rows, 192] and h_prev [rows, 64]: the [192 x 64] cross
+            # product (its diagonal blocks are the two dW_hh, focr_gru_whh_extract) + the column sums of dgh = db_hh of both
+            # directions.  The two strided 96 x 32 launches on the generic fp32 kernel it replaces read the same rows twice
+            # at 73 us each (profiles/r06c_c1_bygrid.txt).
+            cross = torch.empty(192 * 64 + 192, device=dh.device)          # matrix, then the 192 bias sums (overwritten)
+            wsw = torch.empty(nws, device=dh.device)
+            _lib.call("focr_conv2d_wgrad", _p(hprev), _p(dgh), _p(cross), _po(cross, 192 * 64), rows, 1, 1, 64, 192, 1, 1,
+                      0, 0, 192, 64, 0, _p(wsw), nws, _stream())
+            _lib.call("focr_gru_whh_extract", _p(cross), _p(dwhh), _p(dbhh), pz, _stream())
+        else:
+            for d in (0, 1):     # dW_hh[d] = dgh[:, d]^T hprev[:, d]  -- the generic wgrad on strided views
+                _lib.call("focr_conv2d_wgrad", _po(hprev, 32 * d), _po(dgh, 96 * d), _po(dwhh, 96 * 32 * d),
+                          _po(dbhh, 96 * d), rows, 1, 1, 32, 96, 1, 1, 0, 0, 192, 64, pz, _NULL, 0, _stream())
         if pz:
             dwhh = dbhh = None
         return dgx, dwhh, dbhh, None, None, None, None, None, None

@@ -368,6 +368,11 @@ int focr_gru_bidir_fwd(const float* gx, const float* whh, const float* bhh, floa
 int focr_gru_bidir_bwd(const float* dhseq, const float* whh, const float* gates, const float* hseq,
                        float* dgx, float* dgh, float* hprev, int nseq, int T, int IC, int OS, int IS,
                        int TS, focr_stream_t stream);
+/* dW_hh [2][96][32] of both directions = the diagonal blocks of cross [192][64] = dgh^T [h_prev(dir 0) | h_prev(dir 1)], the
+ * weight gradient ONE focr_conv2d_wgrad call (1x1, Cin = 64, Cout = 192, dbias = cross + 192 * 64) produces from the two
+ * tensors focr_gru_bidir_bwd wrote; cross[192 * 64 ..] = that call's 192 bias sums = db_hh [2][96] (dbhh may be NULL);
+ * accumulate != 0 adds to dwhh / dbhh. */
+int focr_gru_whh_extract(const float* cross, float* dwhh, float* dbhh, int accumulate, focr_stream_t stream);
 
 /* ---- CTC: log_softmax + F.ctc_loss(blank 0, 'mean', zero_infinity) (label codec
  *      utils/utils_crnn.py:21-53).  logits/grad [T,B,C]; loss: 1 float; nll: B floats ------------ */

@@ -947,6 +947,62 @@ def test_gru(vertical):
     close(wih.grad, torch.cat([P["weight_ih_l0"].grad, P["weight_ih_l0_reverse"].grad]), 1e-4, what="gru dWih")
 
 
+@pytest.mark.parametrize("cout", [64, 192])
+def test_linear_wgrad_stream_k64(cout):
+    """the streaming weight-gradient kernel's K = 64 mode (linear_wgrad.hip QUART: 64-wide Cout tiles, four waves on one
+    tile over every fourth stage) behind focr_conv2d_wgrad: dW, db of a 1x1 layer 64 -> 64 / 192 over 8192 + 16 rows against
+    fp64, overwrite and accumulate forms, row pitches wider than the matrices"""
+    from fudanocr_amd import _lib
+    lib = _lib.load()
+    rows = 8192 + 16
+    x = rnd(rows, 80, seed=1)[:, :64]
+    dy = rnd(rows, cout + 16, seed=2)[:, :cout]
+    xd, dyd = dev(rnd(rows, 80, seed=1)), dev(rnd(rows, cout + 16, seed=2))
+    ref_w = dy.double().t() @ x.double()
+    ref_b = dy.double().sum(0)
+    nws = lib.focr_conv2d_wgrad_ws_floats(rows, 1, 1, 64, cout, 1, 1, 0, 0)
+    assert nws > 0
+    ws = torch.empty(nws, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    dw = torch.full((cout, 64), float("nan"), device="cuda")
+    db = torch.full((cout,), float("nan"), device="cuda")
+    _lib.call("focr_conv2d_wgrad", xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), db.data_ptr(), rows, 1, 1, 64, cout, 1, 1, 0,
+              0, cout + 16, 80, 0, ws.data_ptr(), nws, st)
+    close(dw, ref_w.float(), 2e-5, what="k64 wgrad")
+    close(db, ref_b.float(), 2e-5, what="k64 bias grad")
+    dw2, db2 = dw.clone(), db.clone()
+    _lib.call("focr_conv2d_wgrad", xd.data_ptr(), dyd.data_ptr(), dw2.data_ptr(), db2.data_ptr(), rows, 1, 1, 64, cout, 1, 1,
+              0, 0, cout + 16, 80, 1, ws.data_ptr(), nws, st)
+    close(dw2, 2 * ref_w.float(), 2e-5, what="k64 wgrad accumulate")
+    close(db2, 2 * ref_b.float(), 2e-5, what="k64 bias accumulate")
+
+
+def test_gru_whh_gradient_from_cross_product():
+    """dW_hh / db_hh of both GRU directions from ONE streaming pass (the [192 x 64] cross product of the gate gradients with
+    h_prev of both directions + focr_gru_whh_extract) against the per-direction definition in fp64, accumulate form
+    included"""
+    from fudanocr_amd import _lib
+    lib = _lib.load()
+    rows = 8192
+    dgh, hp = rnd(rows, 192, seed=3), rnd(rows, 64, seed=4)
+    ref_w = torch.stack([dgh[:, 96 * d:96 * d + 96].double().t() @ hp[:, 32 * d:32 * d + 32].double() for d in (0, 1)])
+    ref_b = dgh.double().sum(0).view(2, 96)
+    nws = lib.focr_conv2d_wgrad_ws_floats(rows, 1, 1, 64, 192, 1, 1, 0, 0)
+    ws = torch.empty(nws, device="cuda")
+    cross = torch.full((192 * 64 + 192,), float("nan"), device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    hpd, dghd = dev(hp), dev(dgh)                     # (named: a temporary would be freed before the kernel runs)
+    _lib.call("focr_conv2d_wgrad", hpd.data_ptr(), dghd.data_ptr(), cross.data_ptr(), cross.data_ptr() + 4 * 192 * 64,
+              rows, 1, 1, 64, 192, 1, 1, 0, 0, 192, 64, 0, ws.data_ptr(), nws, st)
+    dw = torch.ones(2, 96, 32, device="cuda")
+    db = torch.ones(2, 96, device="cuda")
+    _lib.call("focr_gru_whh_extract", cross.data_ptr(), dw.data_ptr(), db.data_ptr(), 1, st)
+    close(dw - 1, ref_w.float(), 2e-5, what="dW_hh (accumulated onto ones)")
+    close(db - 1, ref_b.float(), 2e-5, what="db_hh")
+    _lib.call("focr_gru_whh_extract", cross.data_ptr(), dw.data_ptr(), None, 0, st)
+    close(dw, ref_w.float(), 2e-5, what="dW_hh (overwrite)")
+
+
 @pytest.mark.parametrize("vertical", [True, False], ids=["vertical", "horizontal"])
 def test_gru_loader_waves_equal_single_wave(vertical):
     """tuning key 5: the GRU scans as loader / compute wave groups (operands DMA'd into an LDS ring by loader waves,
