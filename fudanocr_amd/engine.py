@@ -407,8 +407,13 @@ class TrainStep:
     def _rec_key(self, lr, hr, encoded):
         from . import _lib
         lib = _lib.load()
+        # everything a recording bakes into its launches' scalar arguments / launch list: shapes, arithmetic and kernel
+        # selection, the optimiser's hyper-parameters (a learning-rate change makes a new recording, never a silent no-op),
+        # which parameters are trained
         return (tuple(lr.shape), tuple(hr.shape), encoded is not None, lib.focr_get_precision(),
-                tuple(lib.focr_get_tuning(k) for k in range(6)), bool(self.dropout), bool(self.wgrad_side_stream))
+                tuple(lib.focr_get_tuning(k) for k in range(6)), bool(self.dropout), bool(self.wgrad_side_stream),
+                float(self.opt.lr), tuple(self.opt.betas), float(self.opt.eps), float(self.opt.max_norm),
+                sum(1 for p in self.flat.params if p.requires_grad))
 
     @staticmethod
     def _fill(st, lr, hr, encoded):

@@ -207,6 +207,21 @@ def test_recorded_step_shape_change_and_eval_between():
     with torch.no_grad():
         e3 = fresh(probe)
     assert torch.equal(e2, e3), (e2 - e3).abs().max().item()
+    # a changed learning rate is part of the recording's signature: the next steps warm up eagerly and record again -- the old
+    # recording (which carries the old rate as a kernel argument) is not reused
+    def three_steps(seed0):
+        before = step.flat.flat_param.clone()
+        for s in range(3):
+            l_, h_, lab_ = make_batch(4, seed0 + s)
+            step(l_.cuda(), h_.cuda(), lab_)
+        return float((step.flat.flat_param - before).abs().mean())
+
+    full = three_steps(50)                      # three replayed steps at the recorded rate 1e-4
+    assert len(step._recs) == 1
+    step.opt.lr = 2.5e-5
+    quarter = three_steps(60)                   # two eager warm-ups + a new recording at a quarter of the rate
+    assert len(step._recs) == 2
+    assert 0.15 * full < quarter < 0.4 * full, (full, quarter)
     step.replay = False
     l, h, labels = make_batch(4, 40)
     out = step(l.cuda(), h.cuda(), labels)
