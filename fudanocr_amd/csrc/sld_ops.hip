@@ -340,6 +340,146 @@ __global__ __launch_bounds__(256) void small_attn_bwd_q_kernel(
     dQ[(size_t)b * Lq * ldq + h * DK + (size_t)i * ldq + d] = acc * scale;
   }
 }
+// ---- DK = 64 (the 16 x 64 cross attention of the text- / stroke-focus recognizers over 256 image positions), round 6:
+// one block per (batch, head) walks over ALL query rows.  The per-row kernels above re-read the head's K and V (2 x 64 KB)
+// from L2 for every one of the ~11 query rows of every (batch, head): 2.9 GB per launch at B = 128, 255 us forward /
+// 479 us backward-q (profiles/r06b_tfl_bygrid.txt).  Here a thread keeps its key's K (forward) / V (backward) row in
+// registers for the whole launch and the other matrix lives in LDS (64 KB).  Scores, softmax, dropout bits and the
+// per-element formulas are those of the per-row kernels; the output sums run over four key quarters in a fixed order.
+#define SA64_LDS ((SA_LKMAX * 64 + 64 + SA_LKMAX + 4 * 64 + 8) * 4)
+__global__ __launch_bounds__(256) void small_attn_fwd_rows64_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, float* __restrict__ O,
+    float* __restrict__ P, float* __restrict__ Pd, int H, int Lq, int Lk, int ldq, int ldk, int ldo, float scale, int causal,
+    uint32_t drop_thr, float keep_scale, uint64_t seed, const uint64_t* __restrict__ epoch) {
+  seed = focr_epoch_seed(seed, epoch);
+  extern __shared__ __attribute__((aligned(16))) float sa_sm[];
+  float* Vs = sa_sm;                         // [Lk][64]
+  float* qs = Vs + SA_LKMAX * 64;            // [64]
+  float* ps = qs + 64;                       // [SA_LKMAX]
+  float* parts = ps + SA_LKMAX;              // [4][64]
+  float* red = parts + 4 * 64;               // [4 (+4)]
+  const int b = blockIdx.x / H, h = blockIdx.x % H, tid = threadIdx.x;
+  const float* qb = Q + (size_t)b * Lq * ldq + h * 64;
+  const float* kb = K + (size_t)b * Lk * ldk + h * 64;
+  const float* vb = V + (size_t)b * Lk * ldk + h * 64;
+  float* ob = O + (size_t)b * Lq * ldo + h * 64;
+  const size_t pbase = ((size_t)b * H + h) * Lq * Lk;
+  float4 kr[16];
+#pragma unroll
+  for (int d4 = 0; d4 < 16; ++d4)
+    kr[d4] = tid < Lk ? reinterpret_cast<const float4*>(kb + (size_t)tid * ldk)[d4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int idx = tid; idx < Lk * 16; idx += 256)
+    reinterpret_cast<float4*>(Vs)[idx] = reinterpret_cast<const float4*>(vb + (size_t)(idx >> 4) * ldk)[idx & 15];
+  const int d = tid & 63, part = tid >> 6;
+  for (int i = 0; i < Lq; ++i) {
+    __syncthreads();                                       // Vs ready (first row) / the previous row's parts consumed
+    if (tid < 64) qs[tid] = qb[(size_t)i * ldq + tid];
+    __syncthreads();
+    float s = -1e30f;
+    if (tid < Lk && (!causal || tid <= i)) {
+      float acc = 0.f;
+#pragma unroll
+      for (int d4 = 0; d4 < 16; ++d4)
+        acc += qs[4 * d4] * kr[d4].x + qs[4 * d4 + 1] * kr[d4].y + qs[4 * d4 + 2] * kr[d4].z + qs[4 * d4 + 3] * kr[d4].w;
+      s = acc * scale;
+    }
+    float mx = wave_max(s);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();                                       // red is reused by block_sum256
+    const float e = s > -1e29f ? expf(s - mx) : 0.f;
+    const float sum = block_sum256(e, red);
+    const float p = e / sum;
+    float pd = p;
+    if (drop_thr) {
+      const uint32_t r = rng_hash(seed, (pbase + (size_t)i * Lk + tid)) >> 16;
+      pd = r < drop_thr ? 0.f : p * keep_scale;
+    }
+    if (tid < Lk) {
+      P[pbase + (size_t)i * Lk + tid] = p;
+      Pd[pbase + (size_t)i * Lk + tid] = pd;
+      ps[tid] = pd;
+    }
+    __syncthreads();
+    const int kend = causal ? i + 1 : Lk;
+    float acc = 0.f;
+    for (int j = part * 64; j < min(kend, part * 64 + 64); ++j) acc += ps[j] * Vs[j * 64 + d];
+    parts[part * 64 + d] = acc;
+    __syncthreads();
+    if (tid < 64) ob[(size_t)i * ldo + tid] = (parts[tid] + parts[64 + tid]) + (parts[128 + tid] + parts[192 + tid]);
+  }
+}
+
+__global__ __launch_bounds__(256) void small_attn_bwd_q_rows64_kernel(
+    const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ dO, const float* __restrict__ P,
+    const float* __restrict__ Pd, const float* __restrict__ dMap, float* __restrict__ dQ, float* __restrict__ dS, int H,
+    int Lq, int Lk, int ldq, int ldk, int ldo, float scale, int causal) {
+  extern __shared__ __attribute__((aligned(16))) float sa_sm[];
+  float* Ks = sa_sm;                         // [Lk][64]
+  float* gs = Ks + SA_LKMAX * 64;            // [64]
+  float* dss = gs + 64;                      // [SA_LKMAX]
+  float* parts = dss + SA_LKMAX;             // [4][64]
+  float* red = parts + 4 * 64;
+  const int b = blockIdx.x / H, h = blockIdx.x % H, tid = threadIdx.x;
+  const float* kb = K + (size_t)b * Lk * ldk + h * 64;
+  const float* vb = V + (size_t)b * Lk * ldk + h * 64;
+  const float* gb = dO + (size_t)b * Lq * ldo + h * 64;
+  const size_t pbase = ((size_t)b * H + h) * Lq * Lk;
+  float4 vr[16];
+#pragma unroll
+  for (int d4 = 0; d4 < 16; ++d4)
+    vr[d4] = tid < Lk ? reinterpret_cast<const float4*>(vb + (size_t)tid * ldk)[d4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int idx = tid; idx < Lk * 16; idx += 256)
+    reinterpret_cast<float4*>(Ks)[idx] = reinterpret_cast<const float4*>(kb + (size_t)(idx >> 4) * ldk)[idx & 15];
+  const int d = tid & 63, part = tid >> 6;
+  for (int i = 0; i < Lq; ++i) {
+    __syncthreads();
+    if (tid < 64) gs[tid] = gb[(size_t)i * ldo + tid];
+    __syncthreads();
+    float dpd = 0.f, p = 0.f, pd = 0.f;
+    const bool vis = tid < Lk && (!causal || tid <= i);
+    if (vis) {
+      float acc = 0.f;
+#pragma unroll
+      for (int d4 = 0; d4 < 16; ++d4)
+        acc += gs[4 * d4] * vr[d4].x + gs[4 * d4 + 1] * vr[d4].y + gs[4 * d4 + 2] * vr[d4].z + gs[4 * d4 + 3] * vr[d4].w;
+      dpd = acc;
+      if (dMap) dpd += dMap[pbase + (size_t)i * Lk + tid];
+      p = P[pbase + (size_t)i * Lk + tid];
+      pd = Pd[pbase + (size_t)i * Lk + tid];
+    }
+    const float D = block_sum256(pd * dpd, red);
+    const float dp = (vis && p > 0.f) ? dpd * (pd / p) : 0.f;
+    const float dsv = vis ? p * (dp - D) : 0.f;
+    if (tid < Lk) {
+      dS[pbase + (size_t)i * Lk + tid] = dsv;
+      dss[tid] = dsv;
+    }
+    __syncthreads();
+    const int kend = causal ? i + 1 : Lk;
+    float acc = 0.f;
+    for (int j = part * 64; j < min(kend, part * 64 + 64); ++j) acc += dss[j] * Ks[j * 64 + d];
+    parts[part * 64 + d] = acc;
+    __syncthreads();
+    if (tid < 64)
+      dQ[(size_t)b * Lq * ldq + h * 64 + (size_t)i * ldq + tid] =
+          ((parts[tid] + parts[64 + tid]) + (parts[128 + tid] + parts[192 + tid])) * scale;
+  }
+}
+static bool sa_rows64_ready() {
+  static focr_dev_flags attr;
+  if (focr_dev_first(attr)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(small_attn_fwd_rows64_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, SA64_LDS) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(small_attn_bwd_q_rows64_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, SA64_LDS) != hipSuccess)
+      return false;
+    focr_dev_mark(attr);
+  }
+  return true;
+}
+
 // backward, pass 2: block (b, h, SA_JT keys) -> dK[j][:], dV[j][:] (sums over the query rows in index order)
 #define SA_JT 8
 template <int DK>
@@ -374,7 +514,10 @@ extern "C" int focr_small_attention_fwd(const float* q, const float* k, const fl
   const uint32_t thr = (uint32_t)(p_drop * 65536.f + 0.5f);
   FOCR_CHECK_ARG(thr < 65536u, "dropout probability rounds to 1");
   const float ks = thr ? 65536.f / (65536.f - (float)thr) : 1.f;
-  if (Dk == 64)
+  if (Dk == 64 && ldq % 4 == 0 && sa_rows64_ready())
+    hipLaunchKernelGGL(small_attn_fwd_rows64_kernel, dim3(B * H), 256, SA64_LDS, stream, q, k, v, o, p, pd, H, Lq, Lk, ldq,
+                       ldk, ldo, scale, causal, thr, ks, seed, focr_seed_epoch());
+  else if (Dk == 64)
     hipLaunchKernelGGL((small_attn_fwd_kernel<64>), dim3(B * H, Lq), 256, 0, stream, q, k, v, o, p, pd, H, Lq, Lk, ldq,
                        ldk, ldo, scale, causal, thr, ks, seed, focr_seed_epoch());
   else
@@ -394,8 +537,12 @@ extern "C" int focr_small_attention_bwd(const float* q, const float* k, const fl
   FOCR_CHECK_ARG(Lq <= 65535, "too many query rows for the launch grid");
   const dim3 gq(B * H, Lq), gkv(B * H, (Lk + SA_JT - 1) / SA_JT);
   if (Dk == 64) {
-    hipLaunchKernelGGL((small_attn_bwd_q_kernel<64>), gq, 256, 0, stream, k, v, d_o, p, pd, dmap, dq, ws, H, Lq, Lk, ldq,
-                       ldk, ldo, scale, causal);
+    if (sa_rows64_ready())
+      hipLaunchKernelGGL(small_attn_bwd_q_rows64_kernel, dim3(B * H), 256, SA64_LDS, stream, k, v, d_o, p, pd, dmap, dq, ws, H,
+                         Lq, Lk, ldq, ldk, ldo, scale, causal);
+    else
+      hipLaunchKernelGGL((small_attn_bwd_q_kernel<64>), gq, 256, 0, stream, k, v, d_o, p, pd, dmap, dq, ws, H, Lq, Lk, ldq,
+                         ldk, ldo, scale, causal);
     hipLaunchKernelGGL((small_attn_bwd_kv_kernel<64>), gkv, 256, 0, stream, q, d_o, pd, (const float*)ws, dk, dv, H, Lq, Lk,
                        ldq, ldk, ldo, scale, causal);
   } else {

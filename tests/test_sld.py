@@ -79,6 +79,24 @@ def test_sld_ops_against_float64():
         od.backward(go.float().cuda())
         for got, ref in ((qd.grad, q.grad), (kd.grad, k.grad), (vd.grad, v.grad)):
             assert (got.cpu().double() - ref).abs().max() < 2e-5 * (1 + ref.abs().max())
+    # 16 heads x 64 (the text- / stroke-focus recognizers' decoder): one block per (batch, head) over all query rows
+    # (csrc/sld_ops.hip small_attn_*_rows64_kernel), causal and cross forms, a gradient through the returned map as well
+    for lq, lk, causal in ((11, 11, True), (11, 256, False), (3, 130, False), (1, 1, True)):
+        q, k, v = rnd(2, lq, 1024).requires_grad_(True), rnd(2, lk, 1024).requires_grad_(True), rnd(2, lk, 1024).requires_grad_(True)
+        qh, kh, vh = (t.view(2, -1, 16, 64).transpose(1, 2) for t in (q, k, v))
+        s = qh @ kh.transpose(-1, -2) / 8.0
+        if causal:
+            s = s.masked_fill(~torch.tril(torch.ones(lq, lk, dtype=torch.bool)), float("-inf"))
+        p = torch.softmax(s, -1)
+        o = (p @ vh).transpose(1, 2).reshape(2, lq, 1024)
+        go, gm = rnd(2, lq, 1024), rnd(2, 16, lq, lk) * 0.1
+        ((o * go).sum() + (p * gm).sum()).backward()
+        qd, kd, vd = (t.detach().float().cuda().requires_grad_(True) for t in (q, k, v))
+        od, amap = ops.small_attention(qd, kd, vd, 16, causal=causal)
+        assert (od.cpu().double() - o).abs().max() < 2e-5 and (amap.cpu().double() - p).abs().max() < 1e-5
+        ((od * go.float().cuda()).sum() + (amap * gm.float().cuda()).sum()).backward()
+        for got, ref in ((qd.grad, q.grad), (kd.grad, k.grad), (vd.grad, v.grad)):
+            assert (got.cpu().double() - ref).abs().max() < 2e-5 * (1 + ref.abs().max())
     # dropout on the probabilities: expectation and backward consistency through the returned map
     qd, kd, vd = (rnd(2, 5, 1024).float().cuda().requires_grad_(True) for _ in range(3))
     od, amap = ops.small_attention(qd, kd, vd, 4, causal=False, p_drop=0.5)
