@@ -111,7 +111,15 @@ def test_train_mse_golden(arch, golden_dir, prec_mode):
     # fc2.weight.grad = sum_b dctrl[b]^T feat[b] cancels heavily across samples: one bilinear-cell
     # flip (fp32 rounding of a sampling coordinate) moves it by ~10 % of its max while d ctrl itself
     # agrees to <1 % (tools/diag_stn_grad.py); gate it loosely here, tightly through the norms below.
-    assert rel_to_max(P["stn_head.stn_fc2.weight"].grad, g["g_fc2_w"]) < 0.25
+    # (round 6: measured max 1.2e-2 .. 1.8e-2, 98 % quantile 2.6e-3 .. 5.4e-3, 90 % quantile 5e-4 .. 2.8e-3 over both
+    # architectures and modes 1 / 2 / 3 -- profiles/r06_test_margins.txt; the gates leave 3 x for a cell flip)
+    assert rel_to_max(P["stn_head.stn_fc2.weight"].grad, g["g_fc2_w"]) < 6e-2
+    assert rel_q(P["stn_head.stn_fc2.weight"].grad, g["g_fc2_w"], 0.98) < 1.5e-2
+    assert rel_q(P["stn_head.stn_fc2.weight"].grad, g["g_fc2_w"], 0.90) < 8e-3
+    _note("stn_fc2.weight grad vs fixture (%s, mode %d): max %.3e, q98 %.3e, q90 %.3e, median %.3e" % (
+        arch, prec_mode, rel_to_max(P["stn_head.stn_fc2.weight"].grad, g["g_fc2_w"]),
+        rel_q(P["stn_head.stn_fc2.weight"].grad, g["g_fc2_w"], 0.98), rel_q(P["stn_head.stn_fc2.weight"].grad, g["g_fc2_w"], 0.9),
+        rel_q(P["stn_head.stn_fc2.weight"].grad, g["g_fc2_w"], 0.5)))
     assert rel_to_max(P["block2.conv1.weight"].grad, g["g_b2c1_w"]) < 2e-2
     sd = net.state_dict()
     assert rel_to_max(sd["block2.bn1.running_mean"], g["bn_rm"]) < 1e-3
