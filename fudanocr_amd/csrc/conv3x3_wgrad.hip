@@ -13,6 +13,7 @@
 //   * next step's X / dY rows are prefetched into registers during the 108 MFMAs of the current one.
 // HBM/L2 traffic: X once, dY (1 + 2/rows_per_block) times.
 #include "focr_common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 wbf16x8;
 
@@ -57,7 +58,11 @@ __device__ __forceinline__ void stage_d(__bf16* Dh, __bf16* Dl, int c4, int pq, 
   }
 }
 // X row: three copies, copy kw holds X[px + kw - 1] at position px
-__device__ __forceinline__ void stage_x(__bf16* Xh, __bf16* Xl, int c4, int pq, const float4 (&r)[4]) {
+// keep_prev / keep_next (all ones or zero): the lane's left / right neighbour belongs to the same image row.  With several
+// narrow images side by side in the 64-pixel chunk (WIDE kernel below) the first / last quad lane of an image segment must
+// see a ZERO halo pixel, not the neighbouring image's edge.
+__device__ __forceinline__ void stage_x(__bf16* Xh, __bf16* Xl, int c4, int pq, const float4 (&r)[4],
+                                        uint32_t keep_prev = 0xffffffffu, uint32_t keep_next = 0xffffffffu) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     uint32_t h0, h1, l0, l1;
@@ -65,10 +70,10 @@ __device__ __forceinline__ void stage_x(__bf16* Xh, __bf16* Xl, int c4, int pq, 
     const int o = (c4 + e) * GP + 4 * pq;
     st2(&Xh[TILE_E + o], h0, h1);
     st2(&Xl[TILE_E + o], l0, l1);
-    st2(&Xh[o], __builtin_amdgcn_alignbit(h0, from_prev(h1), 16), __builtin_amdgcn_alignbit(h1, h0, 16));
-    st2(&Xl[o], __builtin_amdgcn_alignbit(l0, from_prev(l1), 16), __builtin_amdgcn_alignbit(l1, l0, 16));
-    st2(&Xh[2 * TILE_E + o], __builtin_amdgcn_alignbit(h1, h0, 16), __builtin_amdgcn_alignbit(from_next(h0), h1, 16));
-    st2(&Xl[2 * TILE_E + o], __builtin_amdgcn_alignbit(l1, l0, 16), __builtin_amdgcn_alignbit(from_next(l0), l1, 16));
+    st2(&Xh[o], __builtin_amdgcn_alignbit(h0, from_prev(h1) & keep_prev, 16), __builtin_amdgcn_alignbit(h1, h0, 16));
+    st2(&Xl[o], __builtin_amdgcn_alignbit(l0, from_prev(l1) & keep_prev, 16), __builtin_amdgcn_alignbit(l1, l0, 16));
+    st2(&Xh[2 * TILE_E + o], __builtin_amdgcn_alignbit(h1, h0, 16), __builtin_amdgcn_alignbit(from_next(h0) & keep_next, h1, 16));
+    st2(&Xl[2 * TILE_E + o], __builtin_amdgcn_alignbit(l1, l0, 16), __builtin_amdgcn_alignbit(from_next(l0) & keep_next, l1, 16));
   }
 }
 
@@ -85,11 +90,18 @@ extern "C" int focr_debug_c3w_stamps(unsigned long long* out) {
 // PART != nullptr: the block writes its 9 x 64 x 64 partial tile to PART[blockIdx.y][co tile] with plain stores (no
 // same-address atomics: 256 blocks adding into one 147 KB array cost as much as the rest of the kernel) and
 // conv3x3_c64_reduce_kernel folds them.  PART == nullptr: fp32 atomics into dW.
-__global__ __launch_bounds__(256) void conv3x3_c64_wgrad_kernel(const float* __restrict__ X,
-                                                                const float* __restrict__ dY, float* __restrict__ dW,
-                                                                float* __restrict__ dbias, float* __restrict__ PART,
-                                                                int N, int H, int W, int Cout, int ldx, int ldd,
-                                                                int rows_per_block) {
+// WIDE (round 6): the same kernel for Cin = 64 * gridDim.z on NARROW maps (the SLD / text-focus ResNets: 256 - 1024
+// channels on 16 x 16 and 8 x 8 maps).  A row step's 64-pixel chunk holds AB = 64 / W images side by side -- row iy of
+// images AB n .. AB n + AB - 1 --, so that the chunk is full (one image row alone would idle three quarters of every
+// MFMA at W = 16); "rows" count image GROUPS x H; the vertical structure (dY window, tap rows) is the same for all AB images;
+// the horizontal halo between neighbouring images is zeroed in stage_x.  blockIdx.z picks the 64-channel input slice;
+// partial tiles always go to PART (conv3x3_wide_reduce_kernel folds them into the [Cout][9][Cin] gradient).
+template <bool WIDE>
+__global__ __launch_bounds__(256) void conv3x3_c64_wgrad_kernel_t(const float* __restrict__ X,
+                                                                  const float* __restrict__ dY, float* __restrict__ dW,
+                                                                  float* __restrict__ dbias, float* __restrict__ PART,
+                                                                  int N, int H, int W, int Cout, int ldx, int ldd,
+                                                                  int rows_per_block, int AB) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
   __bf16* Xh = reinterpret_cast<__bf16*>(smem3);       // [3 kw copies][64 ci][GP]
   __bf16* Xl = Xh + 3 * TILE_E;
@@ -98,10 +110,19 @@ __global__ __launch_bounds__(256) void conv3x3_c64_wgrad_kernel(const float* __r
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   C3W_STAMP(0);
   const int co0 = blockIdx.x * 64;
-  const int R0 = blockIdx.y * rows_per_block, R1 = min(N * H, R0 + rows_per_block);
+  const int ci0 = WIDE ? blockIdx.z * 64 : 0;
+  const int R0 = blockIdx.y * rows_per_block, R1 = min((WIDE ? N / AB : N) * H, R0 + rows_per_block);
   if (R0 >= R1) return;
   const int pq = tid & 15, c4 = (tid >> 4) * 4;
-  const bool pxok = 4 * pq < W;                        // W % 4 == 0
+  const bool pxok = WIDE ? true : 4 * pq < W;          // W % 4 == 0 (WIDE: AB * W == 64, every quad lane is a pixel quad)
+  // WIDE: this lane's image inside the group and its pixel offset there; pixel index of (group row G) = rowpix(G) + apix
+  const int seg = WIDE ? W / 4 : 16, aimg = WIDE ? pq / seg : 0;
+  const int apix = WIDE ? aimg * H * W + (pq % seg) * 4 : 4 * pq;
+  const uint32_t keep_prev = (WIDE && pq % seg == 0) ? 0u : 0xffffffffu;
+  const uint32_t keep_next = (WIDE && pq % seg == seg - 1) ? 0u : 0xffffffffu;
+  auto rowpix = [&](int G) -> size_t {
+    return WIDE ? (size_t)((G / H) * AB * H + G % H) * W : (size_t)G * W;
+  };
   const int wi = wave >> 1, wj = wave & 1;
   const int aoff = (wi * 32 + li) * GP + 8 * lh, boff = (wj * 32 + li) * GP + 8 * lh;
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -115,13 +136,13 @@ __global__ __launch_bounds__(256) void conv3x3_c64_wgrad_kernel(const float* __r
   float4 xr[4], dr[4];
 #define LOAD_X(G)                                                                                        \
   {                                                                                                      \
-    const float* p_ = X + ((size_t)(G) * W + 4 * pq) * ldx + c4;                                         \
+    const float* p_ = X + (rowpix(G) + apix) * ldx + ci0 + c4;                                           \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) xr[j] =                                                \
         pxok ? *reinterpret_cast<const float4*>(p_ + (size_t)j * ldx) : make_float4(0.f, 0.f, 0.f, 0.f); \
   }
 #define LOAD_D_TO(G, R_)                                                                                 \
   {                                                                                                      \
-    const float* p_ = dY + ((size_t)(G) * W + 4 * pq) * ldd + co0 + c4;                                  \
+    const float* p_ = dY + (rowpix(G) + apix) * ldd + co0 + c4;                                          \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) R_[j] =                                                \
         pxok ? *reinterpret_cast<const float4*>(p_ + (size_t)j * ldd) : make_float4(0.f, 0.f, 0.f, 0.f); \
   }
@@ -187,7 +208,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64_wgrad_kernel(const float* __r
     }
     if (!v2) ZERO_D(g + 2)                             // above the image (slot of row g - 1): tap row kh = 2 likewise
     if (!have_x && C3W_LD) LOAD_X(g)
-    if (C3W_ST) stage_x(Xh, Xl, c4, pq, xr);
+    if (C3W_ST) stage_x(Xh, Xl, c4, pq, xr, keep_prev, keep_next);
     if (g == R0 + 1) C3W_STAMP(4);                     // second step staged (before its barrier)
     __syncthreads();
     if (first) C3W_STAMP(1);                           // primed: first barrier passed
@@ -235,7 +256,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64_wgrad_kernel(const float* __r
     if (first) C3W_STAMP(3);
   }
   C3W_STAMP(6);
-  if (dbias) {     // fold the 16 pixel-quad lanes of each column: 64 atomics per block
+  if (dbias && (!WIDE || blockIdx.z == 0)) {     // fold the 16 pixel-quad lanes of each column: 64 atomics per block
     float* red = reinterpret_cast<float*>(Xh);
 #pragma unroll
     for (int e = 0; e < 4; ++e) red[pq * 64 + c4 + e] = bsum[e];
@@ -253,7 +274,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64_wgrad_kernel(const float* __r
 #endif
   if (PART) {
     // slot layout = the dW slice of this co tile: [64 co][9][64 ci]
-    float* slot = PART + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (64 * 9 * 64);
+    float* slot = PART + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * gridDim.z + blockIdx.z) * (64 * 9 * 64);
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -271,6 +292,35 @@ __global__ __launch_bounds__(256) void conv3x3_c64_wgrad_kernel(const float* __r
       const int co = co0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       atomicAdd(&dW[((size_t)co * 9 + t) * 64 + ci], acc[t][r]);
     }
+}
+
+// WIDE: dW[co][tap][Cin] = sum over the row blocks of PART[row block][co tile][ci tile][64 co][9][64 ci], in row-block order
+__global__ __launch_bounds__(256) void conv3x3_wide_reduce_kernel(const float* __restrict__ PART, float* __restrict__ dW,
+                                                                  int ntco, int ntci, int nb, int accumulate) {
+  const int Cin = ntci * 64;
+  const long n4 = (long)ntco * 64 * 9 * Cin / 4;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;          // float4 index into dW
+  if (i >= n4) return;
+  const long e0 = i * 4;
+  const int ci = (int)(e0 % Cin), t = (int)((e0 / Cin) % 9), co = (int)(e0 / ((long)9 * Cin));
+  const size_t in_slot = ((size_t)(co & 63) * 9 + t) * 64 + (ci & 63);
+  const size_t tile = (size_t)(co >> 6) * ntci + (ci >> 6);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b = 0; b < nb; b += 4) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      v[u] = b + u < nb ? *reinterpret_cast<const float4*>(PART + (((size_t)(b + u) * ntco * ntci + tile) * (64 * 9 * 64) + in_slot))
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+  }
+  float4* o = reinterpret_cast<float4*>(dW) + i;
+  if (accumulate) {
+    const float4 p = *o;
+    s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+  }
+  *o = s;
 }
 
 // dW[co tile][i] = sum over the row blocks of PART[row block][co tile][i], in row-block order (round 4: was eight groups
@@ -308,6 +358,25 @@ __global__ __launch_bounds__(256) void conv3x3_c64_reduce_kernel(const float* __
   }
 }
 
+// WIDE applicability: 3x3 / pad 1, Cin and Cout multiples of 64 (Cin > 64), a map width that packs the 64-pixel chunk with
+// whole images (W in {8, 16, 32}), a batch that is a multiple of that packing, enough rows to fill the chip
+static int c3_wide_ab(int N, int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW, int ldd, int ldx) {
+  static const bool on = !(getenv("FOCR_C3W_WIDE") && getenv("FOCR_C3W_WIDE")[0] == '0');
+  if (!on || !(KH == 3 && KW == 3 && padH == 1 && padW == 1 && Cin > 64 && Cin % 64 == 0 && Cout % 64 == 0 &&
+               (W == 8 || W == 16 || W == 32) && ldx % 4 == 0 && ldd % 4 == 0))
+    return 0;
+  const int ab = 64 / W;
+  if (N % ab != 0 || (long)(N / ab) * H < 16) return 0;
+  return ab;
+}
+static void c3_wide_blocks(int N, int H, int Cin, int Cout, int ab, int& nb, int& rpb) {
+  const int rows = (N / ab) * H, pairs = (Cin / 64) * (Cout / 64);
+  nb = (256 + pairs - 1) / pairs;                 // >= one block per CU (110 KB of LDS each)
+  if (nb < 1) nb = 1;
+  if (nb > rows / 8) nb = rows / 8 > 0 ? rows / 8 : 1;      // at least 8 row steps per block (priming + epilogue amortised)
+  rpb = cdiv(rows, nb);
+  nb = cdiv(rows, rpb);
+}
 static bool c3_applicable(int W, int Cin, int Cout, int KH, int KW, int padH, int padW, int ldd, int ldx) {
   return KH == 3 && KW == 3 && padH == 1 && padW == 1 && Cin == 64 && Cout % 64 == 0 && W <= 64 && W % 4 == 0 &&
          ldx % 4 == 0 && ldd % 4 == 0;
@@ -323,6 +392,11 @@ static void c3_blocks(int N, int H, int Cout, int& nb, int& rpb) {
 
 // floats of workspace that make the 3x3 / Cin 64 weight gradient atomic-free (0: layer not handled by this file)
 long focr_conv3x3_c64_ws_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW) {
+  if (const int ab = c3_wide_ab(N, H, W, Cin, Cout, KH, KW, padH, padW, 4, 4)) {
+    int nb, rpb;
+    c3_wide_blocks(N, H, Cin, Cout, ab, nb, rpb);
+    return (long)nb * (Cout / 64) * (Cin / 64) * (64 * 9 * 64);
+  }
   if (!c3_applicable(W, Cin, Cout, KH, KW, padH, padW, 4, 4)) return 0;
   int nb, rpb;
   c3_blocks(N, H, Cout, nb, rpb);
@@ -333,21 +407,36 @@ long focr_conv3x3_c64_ws_floats(int N, int H, int W, int Cin, int Cout, int KH, 
 int focr_conv3x3_c64_wgrad(const float* x, const float* dy, float* dw, float* dbias, float* ws, long ws_floats, int N,
                            int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW, int ldd, int ldx,
                            hipStream_t stream) {
-  if (!c3_applicable(W, Cin, Cout, KH, KW, padH, padW, ldd, ldx)) return 0;
   static const size_t lds = (size_t)12 * TILE_E * sizeof(__bf16);
   static focr_dev_flags attr_set;
   if (focr_dev_first(attr_set)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_wgrad_kernel),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_wgrad_kernel_t<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_wgrad_kernel_t<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return 0;
     focr_dev_mark(attr_set);
   }
+  if (const int ab = c3_wide_ab(N, H, W, Cin, Cout, KH, KW, padH, padW, ldd, ldx)) {
+    int nb, rpb;
+    c3_wide_blocks(N, H, Cin, Cout, ab, nb, rpb);
+    const int ntco = Cout / 64, ntci = Cin / 64;
+    if (!ws || ws_floats < (long)nb * ntco * ntci * (64 * 9 * 64)) return 0;      // the wide kernel of conv_bx3.hip takes it
+    hipLaunchKernelGGL(conv3x3_c64_wgrad_kernel_t<true>, dim3(ntco, nb, ntci), 256, lds, stream, x, dy, dw, dbias, ws, N, H, W,
+                       Cout, ldx, ldd, rpb, ab);
+    const long n4 = (long)Cout * 9 * Cin / 4;
+    // (dW arrives zeroed -- prezeroed or memset by the caller -- and the other paths ADD into it: so does this one)
+    hipLaunchKernelGGL(conv3x3_wide_reduce_kernel, dim3((int)((n4 + 255) / 256)), 256, 0, stream, (const float*)ws, dw, ntco,
+                       ntci, nb, 1);
+    return 1;
+  }
+  if (!c3_applicable(W, Cin, Cout, KH, KW, padH, padW, ldd, ldx)) return 0;
   int nb, rpb;
   c3_blocks(N, H, Cout, nb, rpb);
   const int ntile = Cout / 64;
   float* part = (ws && ws_floats >= (long)nb * ntile * (64 * 9 * 64)) ? ws : nullptr;
-  hipLaunchKernelGGL(conv3x3_c64_wgrad_kernel, dim3(ntile, nb), 256, lds, stream, x, dy, dw, dbias, part, N, H, W,
-                     Cout, ldx, ldd, rpb);
+  hipLaunchKernelGGL(conv3x3_c64_wgrad_kernel_t<false>, dim3(ntile, nb), 256, lds, stream, x, dy, dw, dbias, part, N, H, W,
+                     Cout, ldx, ldd, rpb, 1);
   if (part)
     hipLaunchKernelGGL(conv3x3_c64_reduce_kernel, dim3(ntile * (64 * 9 * 64 / 4) / 8), 256, 0, stream, part, dw, ntile, nb);
   return 1;

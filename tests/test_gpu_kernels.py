@@ -98,6 +98,11 @@ CONV_CASES = [
     (8, 16, 50, 64, 128, 3, 3, 1, 1),     # halo kernel: CRNN conv1 shape (W = 50: ragged column tile), XCD tile order
     (3, 8, 25, 128, 256, 3, 3, 1, 1),     # halo kernel: two input-channel slices, several output groups
     (2, 4, 26, 256, 64, 3, 3, 1, 1),      # halo kernel: four slices, one row tile
+    (8, 16, 16, 128, 128, 3, 3, 1, 1),    # row-streaming 3x3 wgrad, WIDE form: 4 images abreast (W = 16), 2 x 2 channel slices
+    (16, 8, 8, 256, 64, 3, 3, 1, 1),      # ... 8 images abreast (W = 8), four input slices
+    (4, 5, 32, 128, 192, 3, 3, 1, 1),     # ... 2 images abreast (W = 32), odd height, three output tiles
+    (12, 16, 16, 192, 64, 3, 3, 1, 1),    # ... three groups of four images, three input slices
+    (6, 11, 16, 128, 128, 3, 3, 1, 1),    # batch not a multiple of the packing: the tile kernel of conv_bx3.hip takes it
     (9, 6, 33, 64, 64, 3, 3, 1, 1),       # halo kernel: H % 4 != 0, W = 33 (one valid pixel in the last tile)
     (128, 1, 4, 256, 256, 3, 3, 1, 1),    # split-K path: STN conv on the 1x4 map at the bench batch (16 tiles, 72 K chunks)
     (40, 2, 8, 128, 256, 3, 3, 1, 1),     # split-K path: ragged last row tile (M = 640), uneven split (36 chunks)

@@ -25,7 +25,7 @@ for (n, h, w, cin, cout) in ((32, 16, 16, 256, 256), (32, 16, 16, 512, 512), (32
     dw = torch.zeros(cout, 3, 3, cin, device=dev)
     db = torch.zeros(cout, device=dev)
     m = n * h * w
-    nws = _lib.load().focr_conv2d_wgrad_ws_floats(m, 3, 3, cin, cout, 3, 3, 1, 1)
+    nws = _lib.load().focr_conv2d_wgrad_ws_floats(n, h, w, cin, cout, 3, 3, 1, 1)
     ws = torch.empty(max(nws, 1), device=dev)
     f = lambda: _lib.call("focr_conv2d_wgrad", K._p(x), K._p(dy), K._p(dw), K._p(db), n, h, w, cin, cout, 3, 3, 1, 1, cout, cin, 1,
                           K._p(ws), nws, K._stream())
