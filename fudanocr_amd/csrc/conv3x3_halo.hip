@@ -166,6 +166,7 @@ __device__ __forceinline__ void h3_mfma_step(f32x16 (&acc)[2], const H3Frags<PLA
   return;
 #endif
   const hbf16x8 ah = __builtin_bit_cast(hbf16x8, f.a[0]);
+  // (alternating the two accumulators instead of three dependent products in a row: no change, profiles/r06_halo_interleave_ab.txt)
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const hbf16x8 bh = __builtin_bit_cast(hbf16x8, f.b[nt][0]);
@@ -186,6 +187,7 @@ struct H3Geom {
   int N, H, W, Cin, Cout, ldx, ldy, ldr;
   int tiles_x, tiles_y, cg_loop;   // cg_loop: 64-channel output groups walked inside one block (Cin == 64 only)
   int ksteps_total;                // 9 * Cin / 16
+  int tiles, gfast;                // gfast: 1-D grid, the output groups of one tile are neighbours on one XCD (see the decode)
 };
 
 #ifdef H3_TRACE
@@ -227,10 +229,25 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     for (int i = 0; i < H3_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);
 #endif
   // tile decode: the tiles of one image share halo rows/columns -> keep them on one XCD (block id % 8)
+  // Multi-slice layers (round 6, gfast): grid = tiles x groups in ONE dimension, and inside an XCD's share of it the
+  // output-channel group runs fastest -- the blocks that contract the SAME input tile against different weight panels are
+  // resident together on one XCD, so the tile's halo comes out of HBM / Infinity Cache once and is an L2 hit for the other
+  // groups (with the group in blockIdx.y the 2 x tiles resident blocks covered two groups, and every tile was fetched
+  // groups / 2 times at different moments of the launch).  The slice's weights of all groups (9 x 64 x Cout x 2 planes:
+  // 1.2 MB at Cout = 512) fit the XCD's L2 next to them.  Single-product launches with Cin >= 128 only: 512 -> 512 on
+  // 8 x 32 maps at B = 128 215 -> 202 us, 512 -> 1024 407 -> 382, 128 -> 128 on 16 x 64 70.5 -> 65.8; the split-product
+  // launches, three times the MFMAs per staged byte, do not wait for the halo and lose 0-3 % (profiles/r06_halo_group_fast_ab.txt).
   const int tpi = g.tiles_x * g.tiles_y;
-  int img, tile;
+  int img, tile, id, cgb;
+  if (g.gfast) {
+    const int ngr = g.Cout >> 6, L = blockIdx.x, j = L >> 3;
+    cgb = j % ngr;
+    id = (j / ngr) * 8 + (L & 7);
+  } else {
+    id = blockIdx.x;
+    cgb = blockIdx.y;
+  }
   {
-    const int id = blockIdx.x;
     if ((g.N & 7) == 0) {
       const int xcd = id & 7, t = id >> 3;
       tile = t % tpi;
@@ -322,7 +339,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       aoff[kw][kk] = lds0 + ((wave * RPW + li / TP) * HP + (li % TP) + kw) * 128 +
                      (((2 * kk + lh) ^ ((((li % TP) + kw) >> 1) & 7)) << 4);
   const unsigned boff = lds0 + HALO + lane * 16;
-  const int cg0 = blockIdx.y * g.cg_loop;
+  const int cg0 = cgb * g.cg_loop;
   constexpr int RS = 3 * PLANES;                    // LDS reads per k-step
 
   constexpr int NW = NP / 4;                        // DMA instructions per wave and chunk
@@ -437,7 +454,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         __syncthreads();
         if (tid < 128) {
           const float v = red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];      // fixed order
-          stats[((size_t)blockIdx.x * g.Cout + cg * 64 + (tid >> 1)) * 2 + (tid & 1)] = v;
+          stats[((size_t)id * g.Cout + cg * 64 + (tid >> 1)) * 2 + (tid & 1)] = v;
         }
       }
     } else {
@@ -499,7 +516,10 @@ static int launch_h3(const float* x, const __bf16* wf, const float* bias, const 
   // leaves too few blocks to fill the chip
   const int tiles = N * g.tiles_x * g.tiles_y;
   g.cg_loop = (Cin == 64 && tiles >= 512 && !stats) ? groups : 1;   // the statistics epilogue reuses the halo's LDS
-  dim3 grid(tiles, groups / g.cg_loop);
+  static const bool gfast_on = !(getenv("FOCR_H3_GROUP_FAST") && getenv("FOCR_H3_GROUP_FAST")[0] == '0');
+  g.tiles = tiles;
+  g.gfast = (gfast_on && PLANES == 1 && Cin >= 128 && g.cg_loop == 1 && groups > 1 && tiles % 8 == 0 && (long)tiles * groups < (1l << 31)) ? 1 : 0;
+  dim3 grid(g.gfast ? tiles * groups : tiles, g.gfast ? 1 : groups / g.cg_loop);
   hipLaunchKernelGGL((conv3x3_halo_kernel<PLANES, TP>), grid, 256, LDS, stream, x, wf, bias, residual, y, stats, g, alpha,
                      relu);
   return 1;

@@ -135,7 +135,10 @@ def test_conv2d(case, precision):
 @pytest.mark.parametrize("shape", [(8, 16, 64, 64, 64), (3, 7, 37, 128, 64), (2, 16, 64, 64, 256),
                                    # narrow maps (round 6): 8 x 16 and 16 x 8 tile shapes, ragged heights / widths
                                    (4, 16, 16, 128, 128), (3, 11, 13, 64, 128), (5, 8, 8, 256, 64), (2, 19, 5, 64, 64),
-                                   (3, 1, 16, 64, 64), (2, 33, 9, 128, 64)])
+                                   (3, 1, 16, 64, 64), (2, 33, 9, 128, 64),
+                                   # multi-slice, several output groups, tiles % 8 == 0: the single-product launch orders its
+                                   # blocks group-fastest inside an XCD (three groups: not a power of two; N % 8 == 0 and != 0)
+                                   (8, 8, 32, 128, 192), (4, 16, 32, 192, 128)])
 def test_halo_conv_c_abi(shape):
     """focr_conv3x3_frag_fwd through the C ABI: prepared (fragment-ordered, pre-split) weights, both plane counts,
     fused residual / relu / alpha, the flipped (data-gradient) weight form and the per-tile BatchNorm partial sums."""
