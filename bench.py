@@ -248,6 +248,10 @@ def main():
                          "--text_focus) / StrokeFocusLoss (text-gestalt), on name-keyed recognizer weights (SURVEY 8f N1)")
     ap.add_argument("--arch", default=None, help="tbsrn | tsrn (c1 = --arch tsrn)")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the configuration's)")
+    ap.add_argument("--mask", action="store_true",
+                    help="c1 / c2 / c3 with the reference's --mask (main.py:31): four input / output channels, the mask channel of "
+                         "dataset.py:146-151 appended to the synthetic LR / HR batches (not a BASELINE configuration; the JSON "
+                         "line names it in config.workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16x3-dgrad16",
                     choices=["bf16x3-dgrad16", "bf16x3", "bf16x3-allsplit", "fp32"],
@@ -373,9 +377,12 @@ def main():
         from fudanocr_amd.engine import TrainStep
         from fudanocr_amd.smoke import build_models
         from fudanocr_amd.utils.synth import make_batch
-        net, rec, crit = build_models(dev, arch, with_crnn=(cfg != "c2"))
+        net, rec, crit = build_models(dev, arch, with_crnn=(cfg != "c2"), mask=args.mask)
         step_ = TrainStep(net, crit, dropout=True, wgrad_side_stream=side)
         lr, hr, labels = make_batch(batch, 1234 + rank)
+        if args.mask:
+            from fudanocr_amd.utils.synth import with_mask
+            lr, hr = with_mask(lr), with_mask(hr)
         lr, hr = lr.to(dev), hr.to(dev)
         enc = crit.encode(labels, dev) if cfg != "c2" else None
 
@@ -619,6 +626,8 @@ def main():
                     "c5": "stroke-level-decomposition transformer recognizer train step (BASELINE configs[4]): "
                           "ResNet-[3,4,6,3] encoder + attention decoder, cross-entropy over ragged stroke sequences, "
                           "Adadelta, 3x32x32 inputs"}[cfg]
+        if args.mask and cfg in ("c1", "c2", "c3"):
+            workload += "; --mask variant (4 input / output channels, main.py:31) -- not a BASELINE configuration"
         res = {
             "metric": "training images/sec (stroke-level-decomposition recognizer step)" if cfg == "c5" else
                       "training images/sec (16x64->32x128 SR step, %s criterion)" % ("text-focus" if cfg == "tfl" else
@@ -653,7 +662,7 @@ def main():
         }
         if comm_info is not None:
             res.update(comm_info)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.mask:
             res["cpu_baseline"] = cpu_baseline_guarded(cfg)
         print(json.dumps(res))
     if world > 1:

@@ -90,10 +90,15 @@ __global__ __launch_bounds__(64 * NTILE) void conv9x9_cin3_bx3_kernel(const floa
   }
 }
 
+int focr_conv9x9_cin4_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cout,
+                          int ldy, float alpha, hipStream_t stream);
+
 // used by focr_conv2d_fwd (conv_igemm.hip); returns 1 if the layer was handled here
 int focr_conv9x9_cin3_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y, int N,
                           int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW, int ldx, int ldy,
                           float alpha, int relu, hipStream_t stream) {
+  if (KH == 9 && KW == 9 && padH == 4 && padW == 4 && Cin == 4 && ldx == 4 && !residual && !relu)   // --mask: conv9x9_cin4.hip
+    return focr_conv9x9_cin4_fwd(x, w, bias, y, N, H, W, Cout, ldy, alpha, stream);
   if (!(KH == 9 && KW == 9 && padH == 4 && padW == 4 && Cin == 3 && ldx == 3 && Cout % 32 == 0 && !residual && !relu &&
         (W == 64 || W == 128)))
     return 0;

@@ -207,7 +207,7 @@ __device__ __forceinline__ void split8(const float4 a, const float4 b, obf16x8& 
 
 __global__ __launch_bounds__(64 * WAVES9) void conv9x9_out_fwd_bx3_kernel(
     const float* __restrict__ X, const float* __restrict__ Wt, const float* __restrict__ bias, float* __restrict__ Y,
-    int H, int W, int Cout, int T, int RR, int R, int units) {
+    int H, int W, int Cout, int ldy, int T, int RR, int R, int units) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem9[];
   __bf16* Wh = reinterpret_cast<__bf16*>(smem9);          // [9][32][WBP]
   __bf16* Wl = Wh + 9 * 32 * WBP;
@@ -310,9 +310,9 @@ __global__ __launch_bounds__(64 * WAVES9) void conv9x9_out_fwd_bx3_kernel(
     }
     const int oyd = iy - 4;                                // slot 8 is complete
     if (oyd >= r0 && oyd < r1) {
-      float* yp = Y + (((size_t)n * H + oyd) * W + OT * t) * Cout;
-      if (v0) yp[o0] = w0[8] + bs0;
-      if (v1) yp[o1] = w1[8] + bs1;
+      float* yp = Y + (((size_t)n * H + oyd) * W + OT * t) * ldy;        // ldy: pixel pitch of Y (> Cout: a channel slice)
+      if (v0) yp[oxl0 * ldy + co0] = w0[8] + bs0;
+      if (v1) yp[oxl1 * ldy + co1] = w1[8] + bs1;
     }
 #pragma unroll
     for (int k = 8; k > 0; --k) { w0[k] = w0[k - 1]; w1[k] = w1[k - 1]; }
@@ -326,8 +326,12 @@ extern "C" int focr_colsum(const float* x, float* out, long rows, int C, int ld,
 extern "C" int focr_conv9x9_small_cout_fwd(const float* x, const float* w, const float* bias, float* y, int N,
                                            int H, int W, int Cin, int Cout, hipStream_t stream) {
   FOCR_CHECK_ARG(x && w && y, "null pointer");
-  if (Cin != C9 || Cout < 1 || Cout > 3 || W + 8 > MAXT * 32 || W * Cout > 640) {
-    focr_set_error("focr_conv9x9_small_cout_fwd: needs Cin == 64, Cout <= 3, W <= 152");
+  // Cout == 4 (the reference's --mask: a fourth, mask channel, main.py:31): 36 (co, kw) columns do not fit one 32-wide
+  // MFMA tile and two tiles' weights (166 KB of split planes) do not fit the LDS -> two launches of two channels each,
+  // writing channel slices of the 4-pitch output (split-bf16 kernel only; precision mode 0 keeps the generic kernel)
+  const bool four = Cout == 4 && focr_get_precision() != 0;
+  if (Cin != C9 || Cout < 1 || (Cout > 3 && !four) || W + 8 > MAXT * 32 || W * Cout > 640) {
+    focr_set_error("focr_conv9x9_small_cout_fwd: needs Cin == 64, Cout <= 3 (4 in precision modes 1-3), W <= 152");
     return FOCR_EUNSUPPORTED;
   }
   if (focr_get_precision() != 0) {
@@ -348,8 +352,10 @@ extern "C" int focr_conv9x9_small_cout_fwd(const float* x, const float* w, const
     const int R = cdiv(H, RR);
     RR = cdiv(H, R);
     const int units = N * RR * T;
-    hipLaunchKernelGGL(conv9x9_out_fwd_bx3_kernel, dim3(cdiv(units, WAVES9)), 64 * WAVES9, lds, stream, x, w, bias, y,
-                       H, W, Cout, T, RR, R, units);
+    const int cl = four ? 2 : Cout;                   // channels per launch
+    for (int c0 = 0; c0 < Cout; c0 += cl)
+      hipLaunchKernelGGL(conv9x9_out_fwd_bx3_kernel, dim3(cdiv(units, WAVES9)), 64 * WAVES9, lds, stream, x,
+                         w + (size_t)c0 * 81 * C9, bias ? bias + c0 : nullptr, y + c0, H, W, cl, Cout, T, RR, R, units);
     FOCR_LAUNCH_CHECK();
     return FOCR_OK;
   }
@@ -396,13 +402,17 @@ extern "C" int focr_conv9x9_small_cout_wgrad(const float* x, const float* dy, fl
 // =======================================================================================
 #define W9_MAXW 128
 #define W9_XTP (W9_MAXW + 8)                 // bf16 pitch of a transposed channel row: 272 B, conflict-free ds_read_b128
-#define W9_GLEN ((W9_MAXW + 8) * 3 + 4)      // floats of one staged dY row (4-pixel halo each side, Cout <= 3); % 4 == 0
+#define W9_GLEN ((W9_MAXW + 8) * 4)          // words of one staged dY row (4-pixel halo each side, pixel pitch <= 4); % 4 == 0
 #define W9_THREADS 192
 
 __global__ __launch_bounds__(W9_THREADS) void conv9x9_out_wgrad_bx3_kernel(const float* __restrict__ X,
                                                                            const float* __restrict__ dY,
                                                                            float* __restrict__ PART, int N, int H, int W,
-                                                                           int Cout, int rows_per_block, long slot_floats) {
+                                                                           int Cout, int GST, int c0, int rows_per_block,
+                                                                           long slot_floats) {
+  // GST: pixel pitch of dY = its channel count; this launch takes channels c0 .. c0 + Cout - 1 of it (GST == Cout, c0 == 0
+  // for the three-channel layer; the four-channel --mask layer runs as two launches of two channels: 36 (co, kw) rows do
+  // not fit the 32-row M tile).  The dY rows are staged whole, at their own pitch.
   __shared__ __attribute__((aligned(16))) __bf16 Xth[C9 * W9_XTP], Xtl[C9 * W9_XTP];
   // the nine dY rows, split ONCE while staged: one 32-bit word per value = bf16 hi | bf16 lo << 16 (a lane's A fragment is eight
   // words at a 3-word stride; separating the planes costs one v_perm per word pair instead of a 24-instruction split per
@@ -412,7 +422,6 @@ __global__ __launch_bounds__(W9_THREADS) void conv9x9_out_wgrad_bx3_kernel(const
   const int row0 = blockIdx.x * rows_per_block, row1 = min(N * H, row0 + rows_per_block);
   const int jco = li / 9, jkw = li - jco * 9;
   const bool jok = li < Cout * 9;
-  const int glen = (W + 8) * Cout;
   f32x16 acc[3][2];
 #pragma unroll
   for (int a = 0; a < 3; ++a)
@@ -423,30 +432,31 @@ __global__ __launch_bounds__(W9_THREADS) void conv9x9_out_wgrad_bx3_kernel(const
   // A-fragment base: pixel (16 s + 8 lh + e) - kw + 4 of the halo-padded row, channel co
   // (lanes j >= Cout * 9 feed output rows that are never stored: they read what lane (co 0, kw 0) reads -- a broadcast, no
   // extra bank -- instead of a zero word of their own)
-  const int abase = jok ? (8 * lh - jkw + 8) * Cout + jco : (8 * lh + 8) * Cout;
-  const int astep = Cout, asstep = 16 * Cout;
+  const int abase = (jok ? (8 * lh - jkw + 8) * GST + jco : (8 * lh + 8) * GST) + c0;
+  const int astep = GST, asstep = 16 * GST;
   // the halo cells (4 pixels left / right of every staged dY row) are zero for the whole launch
-  for (int i = tid; i < 9 * 8 * Cout; i += W9_THREADS) {
-    const int kh = i / (8 * Cout), g = i - kh * 8 * Cout;
-    Gs[kh][g < 4 * Cout ? g : (W + 4) * Cout + (g - 4 * Cout)] = 0u;
+  for (int i = tid; i < 9 * 8 * GST; i += W9_THREADS) {
+    const int kh = i / (8 * GST), g = i - kh * 8 * GST;
+    Gs[kh][g < 4 * GST ? g : (W + 4) * GST + (g - 4 * GST)] = 0u;
   }
   // ---- this thread's staging items are the same for every row: up to 6 (pixel pair, 4 channels) patches of the input row
-  // and up to 5 float4 of the nine dY rows (a dY row is W * Cout contiguous floats)
-  const int nxi = (W / 2) * 16, qpr = W * Cout / 4, ndi = 9 * qpr;
-  int dkh[5], dq[5];
+  // and up to 6 float4 of the nine dY rows (a dY row is W * GST contiguous floats)
+  constexpr int DU = 6;
+  const int nxi = (W / 2) * 16, qpr = W * GST / 4, ndi = 9 * qpr;
+  int dkh[DU], dq[DU];
 #pragma unroll
-  for (int u = 0; u < 5; ++u) {
+  for (int u = 0; u < DU; ++u) {
     const int i = tid + u * W9_THREADS;
     dkh[u] = i < ndi ? i / qpr : -1;
     dq[u] = i < ndi ? i - dkh[u] * qpr : 0;
   }
-  float4 xa[6], xb[6], dv[5];
-  // bias gradient: channel of element 4 q of a dY row is (4 q) % Cout; the per-thread sums are kept per channel SLOT
-  // (slot c = channel c for Cout == 3; for Cout < 3 the unused slots stay zero) and folded at the end
-  float bs[3] = {0.f, 0.f, 0.f};
-  int bch[5];
+  float4 xa[6], xb[6], dv[DU];
+  // bias gradient: channel of element 4 q of a dY row is (4 q) % GST; the per-thread sums are kept per channel SLOT
+  // (slot c = channel c of dY; unused slots stay zero) and folded at the end
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
+  int bch[DU];
 #pragma unroll
-  for (int u = 0; u < 5; ++u) bch[u] = (4 * dq[u]) % Cout;
+  for (int u = 0; u < DU; ++u) bch[u] = (4 * dq[u]) % GST;
   auto load_row = [&](int row) {
     const int n = row / H, iy = row - n * H;
     const float* xrow = X + (size_t)row * W * C9;
@@ -463,10 +473,10 @@ __global__ __launch_bounds__(W9_THREADS) void conv9x9_out_wgrad_bx3_kernel(const
       }
     }
 #pragma unroll
-    for (int u = 0; u < 5; ++u) {
+    for (int u = 0; u < DU; ++u) {
       const int oy = iy - dkh[u] + 4;
       const bool ok = dkh[u] >= 0 && (unsigned)oy < (unsigned)H;
-      dv[u] = ok ? *reinterpret_cast<const float4*>(dY + ((size_t)n * H + oy) * W * Cout + 4 * dq[u])
+      dv[u] = ok ? *reinterpret_cast<const float4*>(dY + ((size_t)n * H + oy) * W * GST + 4 * dq[u])
                  : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
@@ -487,14 +497,14 @@ __global__ __launch_bounds__(W9_THREADS) void conv9x9_out_wgrad_bx3_kernel(const
       }
     }
 #pragma unroll
-    for (int u = 0; u < 5; ++u)
+    for (int u = 0; u < DU; ++u)
       if (dkh[u] >= 0) {
         focr_bf16x2 h0, l0, h1, l1;
         focr_split2(f32x2{dv[u].x, dv[u].y}, h0, l0);
         focr_split2(f32x2{dv[u].z, dv[u].w}, h1, l1);
         const uint32_t ha = __builtin_bit_cast(uint32_t, h0), la = __builtin_bit_cast(uint32_t, l0);
         const uint32_t hb = __builtin_bit_cast(uint32_t, h1), lb = __builtin_bit_cast(uint32_t, l1);
-        *reinterpret_cast<uint4*>(&Gs[dkh[u]][4 * Cout + 4 * dq[u]]) =
+        *reinterpret_cast<uint4*>(&Gs[dkh[u]][4 * GST + 4 * dq[u]]) =
             make_uint4(__builtin_amdgcn_perm(la, ha, 0x05040100u), __builtin_amdgcn_perm(la, ha, 0x07060302u),
                        __builtin_amdgcn_perm(lb, hb, 0x05040100u), __builtin_amdgcn_perm(lb, hb, 0x07060302u));
         if (dkh[u] == 4) {                                // tap row kh = 4 is dY row iy itself: every pixel exactly once
@@ -505,7 +515,8 @@ __global__ __launch_bounds__(W9_THREADS) void conv9x9_out_wgrad_bx3_kernel(const
             bs[0] += c == 0 ? ev[e] : 0.f;
             bs[1] += c == 1 ? ev[e] : 0.f;
             bs[2] += c == 2 ? ev[e] : 0.f;
-            c = c + 1 == Cout ? 0 : c + 1;
+            bs[3] += c == 3 ? ev[e] : 0.f;
+            c = c + 1 == GST ? 0 : c + 1;
           }
         }
       }
@@ -566,11 +577,11 @@ __global__ __launch_bounds__(W9_THREADS) void conv9x9_out_wgrad_bx3_kernel(const
     float* red = reinterpret_cast<float*>(Xth);
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 3; ++c) red[c * W9_THREADS + tid] = bs[c];
+    for (int c = 0; c < 4; ++c) red[c * W9_THREADS + tid] = bs[c];
     __syncthreads();
     if (tid < Cout) {
       float t = 0.f;
-      for (int i = 0; i < W9_THREADS; ++i) t += red[tid * W9_THREADS + i];
+      for (int i = 0; i < W9_THREADS; ++i) t += red[(c0 + tid) * W9_THREADS + i];
       slot[(size_t)Cout * 81 * C9 + tid] = t;
     }
   }
@@ -596,6 +607,7 @@ __global__ __launch_bounds__(256) void conv9x9_out_wgrad_fold_kernel(const float
       sacc.x += v[0];
       if (Cout > 1) sacc.y += v[1];
       if (Cout > 2) sacc.z += v[2];
+      if (Cout > 3) sacc.w += v[3];
     }
   }
   red[g][e] = sacc;
@@ -610,6 +622,7 @@ __global__ __launch_bounds__(256) void conv9x9_out_wgrad_fold_kernel(const float
       dbias[0] = t.x;
       if (Cout > 1) dbias[1] = t.y;
       if (Cout > 2) dbias[2] = t.z;
+      if (Cout > 3) dbias[3] = t.w;
     }
   }
 }
@@ -631,18 +644,23 @@ extern "C" int focr_conv9x9_small_cout_wgrad_ws(const float* x, const float* dy,
                                                 long ws_floats, int N, int H, int W, int Cin, int Cout,
                                                 hipStream_t stream) {
   FOCR_CHECK_ARG(x && dy && dw && ws, "null pointer");
-  if (Cin != C9 || Cout < 1 || Cout > 3 || W > W9_MAXW || W % 32 || focr_get_precision() == 0) {
-    focr_set_error("focr_conv9x9_small_cout_wgrad_ws: needs Cin == 64, Cout <= 3, W %% 32 == 0, W <= 128, precision != 0");
+  if (Cin != C9 || Cout < 1 || Cout > 4 || W > W9_MAXW || W % 32 || focr_get_precision() == 0) {
+    focr_set_error("focr_conv9x9_small_cout_wgrad_ws: needs Cin == 64, Cout <= 4, W %% 32 == 0, W <= 128, precision != 0");
     return FOCR_EUNSUPPORTED;
   }
   int nb, rpb;
   w9_plan(N, H, nb, rpb);
-  const long slot = (long)Cout * 81 * C9 + 4;
-  FOCR_CHECK_ARG(ws_floats >= (long)nb * slot, "workspace too small");
-  hipLaunchKernelGGL(conv9x9_out_wgrad_bx3_kernel, dim3(nb), W9_THREADS, 0, stream, x, dy, ws, N, H, W, Cout, rpb, slot);
-  const long n_dw4 = (long)Cout * 81 * C9 / 4;
-  hipLaunchKernelGGL(conv9x9_out_wgrad_fold_kernel, dim3((int)((n_dw4 + 1 + 7) / 8)), 256, 0, stream, (const float*)ws, dw,
-                     dbias, n_dw4, slot, nb, Cout);
+  FOCR_CHECK_ARG(ws_floats >= (long)nb * ((long)Cout * 81 * C9 + 4), "workspace too small");
+  // Cout == 4 (--mask): two launches of two channels each (see the kernel), the workspace re-used in stream order
+  const int cl = Cout == 4 ? 2 : Cout;
+  const long slot = (long)cl * 81 * C9 + 4;
+  const long n_dw4 = (long)cl * 81 * C9 / 4;
+  for (int c0 = 0; c0 < Cout; c0 += cl) {
+    hipLaunchKernelGGL(conv9x9_out_wgrad_bx3_kernel, dim3(nb), W9_THREADS, 0, stream, x, dy, ws, N, H, W, cl, Cout, c0, rpb,
+                       slot);
+    hipLaunchKernelGGL(conv9x9_out_wgrad_fold_kernel, dim3((int)((n_dw4 + 1 + 7) / 8)), 256, 0, stream, (const float*)ws,
+                       dw + (size_t)c0 * 81 * C9, dbias ? dbias + c0 : nullptr, n_dw4, slot, nb, cl);
+  }
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }

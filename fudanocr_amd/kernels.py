@@ -495,8 +495,10 @@ def _halo_ok(h, w, cin, cout, kh, kw, ph, pw):
 
 
 def _is_out_layer(cin, cout, kh, kw, ph, pw, w, residual, alpha, relu):
-    """SR output layer shape handled by csrc/conv9x9_out.hip (taps folded into the MFMA N dim)."""
-    return (kh == 9 and kw == 9 and ph == 4 and pw == 4 and cin == 64 and cout <= 3 and w % 32 == 0
+    """SR output layer shape handled by csrc/conv9x9_out.hip (taps folded into the MFMA N dim); the four-channel layer of
+    the reference's --mask (main.py:31) on the split-bf16 kernels only (two launches of two channels each)."""
+    return (kh == 9 and kw == 9 and ph == 4 and pw == 4 and cin == 64 and w % 32 == 0
+            and (cout <= 3 or (cout == 4 and _lib.get_precision() != 0 and _C9_WGRAD_BX3))
             and w <= 128 and residual is None and alpha == 1.0 and not relu)
 
 

@@ -3,16 +3,16 @@ against the CPU oracle (fp32 torch restatement pinned to the reference's golden 
 import torch
 
 
-def build_models(device, arch="tbsrn", with_crnn=True):
+def build_models(device, arch="tbsrn", with_crnn=True, mask=False):
     from .loss.ctc_focus_loss import CTCFocusLoss
     from .model import tbsrn
     from .model.crnn import crnn
     from .utils.weight_fill import fill_module_
     if arch == "tbsrn":
-        net = tbsrn.TBSRN(STN=True)
+        net = tbsrn.TBSRN(STN=True, mask=mask)
     else:
         from .model import tsrn
-        net = tsrn.TSRN(STN=True)
+        net = tsrn.TSRN(STN=True, mask=mask)
     fill_module_(net)
     net = net.to(device)
     rec = None

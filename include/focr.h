@@ -137,8 +137,9 @@ int focr_conv3x3_frag_fwd(const float* x, const void* wfrag, const float* bias, 
                           int ldy, int ldr, int ldx, focr_stream_t stream);
 /* out[c] = sum_r x[r*ld + c]   (bias gradients) */
 int focr_colsum(const float* x, float* out, long rows, int C, int ld, focr_stream_t stream);
-/* specialised 9x9, pad 4, Cin=64 -> Cout<=3|4 convolution (SR output layer, model/tsrn.py:43):
- * the 9 horizontal taps are folded into the MFMA N dimension ((co,kw) = 27..36 columns) */
+/* specialised 9x9, pad 4, Cin=64 -> Cout<=3 convolution (SR output layer, model/tsrn.py:43):
+ * the 9 horizontal taps are folded into the MFMA N dimension ((co,kw) = 27 of 32 columns).  Cout == 4 (the reference's
+ * --mask, main.py:31) in precision modes 1-3: two launches of two channels each, forward and the _ws weight gradient */
 int focr_conv9x9_small_cout_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H,
                                 int W, int Cin, int Cout, focr_stream_t stream);
 int focr_conv9x9_small_cout_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N, int H,

@@ -108,6 +108,12 @@ CONV_CASES = [
     (40, 2, 8, 128, 256, 3, 3, 1, 1),     # split-K path: ragged last row tile (M = 640), uneven split (36 chunks)
     (5, 16, 64, 3, 32, 3, 3, 1, 1),       # STN conv1: tiny-Cin weight gradient (conv3x3_cin_small_wgrad.hip), several images per block
     (3, 5, 10, 4, 32, 3, 3, 1, 1),        # the same with the mask channel, odd sizes, one image row per block
+    # the reference's --mask (main.py:31): four-channel forms of the two 9x9 layers
+    (2, 16, 64, 4, 64, 9, 9, 4, 4),       # block1 with the mask channel: conv9x9_cin4.hip, W = 64
+    (2, 32, 128, 4, 64, 9, 9, 4, 4),      # ... W = 128 (= the data gradient of the four-channel output layer)
+    (3, 7, 64, 4, 32, 9, 9, 4, 4),        # ... odd height, one channel group, several row ranges
+    (1, 32, 128, 64, 4, 9, 9, 4, 4),      # block8.1 with the mask channel: two launches of two channels (conv9x9_out.hip)
+    (3, 16, 64, 64, 4, 9, 9, 4, 4),       # ... W = 64, several images
 ]
 
 
