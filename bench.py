@@ -369,10 +369,12 @@ def main():
         step_ = TrainStep(net, crit, dropout=True, wgrad_side_stream=side)
         lr, hr, labels = make_batch(batch, 1234 + rank)
         lr, hr = lr.to(dev), hr.to(dev)
-        enc = None
+        # labels -> one padded device tensor (loss/padded_labels.py), once, as a data loader would per batch: with it the
+        # step has no label-dependent shapes and the engine records it like the CTC step
+        enc = crit.encode_for_replay(labels, dev)
 
         def step():
-            return step_(lr, hr, labels)
+            return step_(lr, hr, encoded=enc)
     else:
         from fudanocr_amd.engine import TrainStep
         from fudanocr_amd.smoke import build_models

@@ -111,6 +111,9 @@ SIGNATURES = {
     "focr_l1_fwd": [P, P, P, P, L, P],
     "focr_l1_bwd": [P, P, P, P, L, P],
     "focr_weight_cross_entropy_fwd": [P, P, P, P, P, P, L, I, P],
+    "focr_l1_masked_fwd": [P, P, P, P, L, I, I, P, P],
+    "focr_l1_masked_bwd": [P, P, P, P, L, I, I, P, P],
+    "focr_weight_cross_entropy_masked_fwd": [P, P, P, P, P, P, L, I, P, P],
     "focr_set_precision": [I],
     "focr_set_tuning": [I, I],
     "focr_comm_unique_id": [P],

@@ -622,3 +622,98 @@ extern "C" int focr_weight_cross_entropy_fwd(const float* logits, const long lon
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
 }
+
+// ---- the same two losses on PADDED label layouts (round 6): what depends on the batch's labels is data, not shape.
+// The focus losses' recognizer decodes [B, L] teacher-forcing positions with L = the longest label of the batch
+// (text_focus_loss.py:62-81), its attention-map L1 is a mean over all B x 16 x L x 256 entries and the cross entropy a mean over
+// the sum(len) real positions -- so every launch of the step changes shape with the labels and the step could not be recorded
+// (csrc/replay.hip).  Here L is a capacity (labels padded to a bucket), and a three-word device plan carries the real
+// numbers: plan[0] = longest label, plan[1] = number of real positions.  Padded decoder positions see the causal mask, so
+// they do not touch the real ones; these kernels leave them out of the sums, the means and the gradients.
+// a, b: [outer][L][inner]; positions j >= plan[0] do not count; mean over outer * plan[0] * inner entries
+__global__ __launch_bounds__(256) void l1_masked_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                float* __restrict__ part, long n, int L, int inner,
+                                                                const long long* __restrict__ plan) {
+  __shared__ float red[4];
+  const int lmax = (int)plan[0];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    if ((int)((i / inner) % L) < lmax) s += fabsf(a[i] - b[i]);
+  s = block_sum256(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(64) void l1_masked_fold_kernel(const float* __restrict__ part, float* __restrict__ out, int nb,
+                                                            long outer_inner, const long long* __restrict__ plan) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 64) s += part[i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) out[0] = s / ((float)outer_inner * (float)plan[0]);
+}
+__global__ __launch_bounds__(256) void l1_masked_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            const float* __restrict__ g, float* __restrict__ db, long n,
+                                                            int L, int inner, long outer_inner,
+                                                            const long long* __restrict__ plan) {
+  const int lmax = (int)plan[0];
+  const float k = g[0] / ((float)outer_inner * (float)lmax);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float d = b[i] - a[i];
+    db[i] = (int)((i / inner) % L) < lmax ? (d > 0.f ? k : (d < 0.f ? -k : 0.f)) : 0.f;
+  }
+}
+extern "C" int focr_l1_masked_fwd(const float* a, const float* b, float* out, float* ws, long outer, int L, int inner,
+                                  const long long* plan, hipStream_t stream) {
+  FOCR_CHECK_ARG(a && b && out && ws && plan && outer > 0 && L > 0 && inner > 0, "bad argument (ws: 256 floats)");
+  const long n = outer * L * inner;
+  hipLaunchKernelGGL(l1_masked_partial_kernel, dim3(L1_BLOCKS), 256, 0, stream, a, b, ws, n, L, inner, plan);
+  hipLaunchKernelGGL(l1_masked_fold_kernel, dim3(1), 64, 0, stream, (const float*)ws, out, L1_BLOCKS, outer * inner, plan);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+extern "C" int focr_l1_masked_bwd(const float* a, const float* b, const float* g, float* db, long outer, int L, int inner,
+                                  const long long* plan, hipStream_t stream) {
+  FOCR_CHECK_ARG(a && b && g && db && plan && outer > 0 && L > 0 && inner > 0, "bad argument");
+  const long n = outer * L * inner;
+  long gr = (n + 255) / 256;
+  if (gr > 2048) gr = 2048;
+  hipLaunchKernelGGL(l1_masked_bwd_kernel, dim3((int)gr), 256, 0, stream, a, b, g, db, n, L, inner, outer * inner, plan);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}
+// weight_cross_entropy over padded rows: target < 0 marks a padded position (no loss, zero gradient); mean over plan[1] rows
+__global__ __launch_bounds__(64) void wce_rows_masked_kernel(const float* __restrict__ x, const long long* __restrict__ target,
+                                                             const float* __restrict__ table, float* __restrict__ nll,
+                                                             float* __restrict__ grad, int C,
+                                                             const long long* __restrict__ plan) {
+  const long r = blockIdx.x;
+  const int c = threadIdx.x, t = (int)target[r];
+  if (t < 0) {                                                        // (block-uniform)
+    if (c < C) grad[r * C + c] = 0.f;
+    if (c == 0) nll[r] = 0.f;
+    return;
+  }
+  const float inv = 1.f / (float)plan[1];
+  const float v = c < C ? x[r * C + c] : -1e30f;
+  const float mx = wave_max(v);
+  const float e = c < C ? table[t * C + c] * expf(v - mx) : 0.f;
+  const float sum = wave_sum(e);
+  if (c < C) grad[r * C + c] = (e / sum - (c == t ? 1.f : 0.f)) * inv;
+  const float picked = wave_sum(c == t ? e : 0.f);
+  if (c == 0) nll[r] = -logf(picked / sum);
+}
+__global__ __launch_bounds__(64) void ce_masked_fold_kernel(const float* __restrict__ nll, float* __restrict__ loss, long rows,
+                                                            const long long* __restrict__ plan) {
+  float acc = 0.f;
+  for (long r = threadIdx.x; r < rows; r += 64) acc += nll[r];
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) loss[0] = acc / (float)plan[1];
+}
+extern "C" int focr_weight_cross_entropy_masked_fwd(const float* logits, const long long* target, const float* table,
+                                                    float* loss, float* nll_ws, float* grad, long rows, int C,
+                                                    const long long* plan, hipStream_t stream) {
+  FOCR_CHECK_ARG(logits && target && table && loss && nll_ws && grad && plan && rows > 0 && C > 1 && C <= 64,
+                 "need 2 <= C <= 64");
+  hipLaunchKernelGGL(wce_rows_masked_kernel, dim3((int)rows), 64, 0, stream, logits, target, table, nll_ws, grad, C, plan);
+  hipLaunchKernelGGL(ce_masked_fold_kernel, dim3(1), 64, 0, stream, (const float*)nll_ws, loss, rows, plan);
+  FOCR_LAUNCH_CHECK();
+  return FOCR_OK;
+}

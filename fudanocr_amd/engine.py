@@ -152,8 +152,9 @@ class TrainStep:
     stream, so these collectives overlap the remaining backward kernels."""
 
     REPLAY_WARMUP = 2      # eager steps per input signature before the step is recorded (lazy tables, workspaces)
-    MAX_RECORDINGS = 3     # signatures kept (each recording owns a private memory pool of the step's temporaries): e.g. the
-    #                        full batch, an epoch's short last batch, a second precision mode; further signatures step eagerly
+    MAX_RECORDINGS = 5     # signatures kept (each recording owns a private memory pool of the step's temporaries): e.g. the
+    #                        full batch, an epoch's short last batch, a second precision mode -- or, with the focus losses, the
+    #                        label-capacity buckets of the full batch (8 / 16 / 24 / 32 characters); further signatures step eagerly
 
     def __init__(self, model, crit, lr=1e-4, betas=(0.5, 0.999), max_norm=0.25, process_group=None,
                  wgrad_side_stream=True, n_buckets=4, dropout=True, boundaries=("block3", "block6"),
@@ -410,7 +411,8 @@ class TrainStep:
         # everything a recording bakes into its launches' scalar arguments / launch list: shapes, arithmetic and kernel
         # selection, the optimiser's hyper-parameters (a learning-rate change makes a new recording, never a silent no-op),
         # which parameters are trained
-        return (tuple(lr.shape), tuple(hr.shape), encoded is not None, lib.focr_get_precision(),
+        return (tuple(lr.shape), tuple(hr.shape), encoded.key() if hasattr(encoded, "key") else encoded is not None,
+                lib.focr_get_precision(),
                 tuple(lib.focr_get_tuning(k) for k in range(6)), bool(self.dropout), bool(self.wgrad_side_stream),
                 float(self.opt.lr), tuple(self.opt.betas), float(self.opt.eps), float(self.opt.max_norm),
                 sum(1 for p in self.flat.params if p.requires_grad))
@@ -421,7 +423,9 @@ class TrainStep:
             st["lr"].copy_(lr, non_blocking=True)
         if hr is not st["hr"]:
             st["hr"].copy_(hr, non_blocking=True)
-        if encoded is not None and encoded is not st["enc"]:
+        if encoded is not None and encoded is not st["enc"] and hasattr(encoded, "copy_into"):
+            encoded.copy_into(st["enc"])                 # loss/padded_labels.py: one packed tensor
+        elif encoded is not None and encoded is not st["enc"]:
             t, l, o = encoded[0], encoded[1], encoded[2]
             st["enc"][0][:t.numel()].copy_(t, non_blocking=True)
             st["enc"][1].copy_(l, non_blocking=True)
@@ -432,7 +436,9 @@ class TrainStep:
         import warnings
         from . import replay
         st = {"lr": torch.empty_like(lr), "hr": torch.empty_like(hr), "enc": None}
-        if encoded is not None:
+        if encoded is not None and hasattr(encoded, "static_like"):
+            st["enc"] = encoded.static_like()
+        elif encoded is not None:
             cap = max(int(encoded[0].numel()), lr.shape[0] * 32)
             st["enc"] = (torch.zeros(cap, device=lr.device, dtype=encoded[0].dtype), torch.zeros_like(encoded[1]),
                          torch.zeros_like(encoded[2]))
@@ -467,8 +473,13 @@ class TrainStep:
         return None if st is None else (st["lr"], st["hr"], st["enc"])
 
     def _call_recorded(self, images_lr, images_hr, label_strs, encoded):
-        if encoded is None and label_strs is not None and getattr(self.crit, "recognizer", [None])[0] is not None:
-            encoded = self.crit.encode(label_strs, images_lr.device)
+        if encoded is None and label_strs is not None:
+            # the criterion's labels as device tensors a recording can keep a static copy of: the focus losses pad them to a
+            # capacity bucket (loss/padded_labels.py), the CTC criterion packs them (ctc_focus_loss.encode)
+            if hasattr(self.crit, "encode_for_replay"):
+                encoded = self.crit.encode_for_replay(label_strs, images_lr.device)
+            elif getattr(self.crit, "recognizer", [None])[0] is not None:
+                encoded = self.crit.encode(label_strs, images_lr.device)
         key = self._rec_key(images_lr, images_hr, encoded)
         st = self._recs.get(key)
         if st is None:
@@ -478,7 +489,8 @@ class TrainStep:
             st = self._record(key, images_lr, images_hr, encoded)
             if st is None:
                 return self._step(images_lr, images_hr, label_strs, encoded)
-        if encoded is not None and encoded is not st["enc"] and encoded[0].numel() > st["enc"][0].numel():
+        if encoded is not None and encoded is not st["enc"] and (
+                not encoded.fits(st["enc"]) if hasattr(encoded, "fits") else encoded[0].numel() > st["enc"][0].numel()):
             return self._step(images_lr, images_hr, label_strs, encoded)       # more label characters than the static buffer
         self._fill(st, images_lr, images_hr, encoded)
         st["rec"].launch()

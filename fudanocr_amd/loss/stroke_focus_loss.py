@@ -116,17 +116,31 @@ class StrokeFocusLoss(nn.Module):
         length_tensor._focr_host = length
         return length_tensor, torch.from_numpy(input_tensor).to(self.device), text_gt.to(self.device)
 
+    # ---- recordable step (engine.TrainStep): the labels as a PaddedLabels batch, the forward as kernel launches only
+    REPLAY_SAFE = True                 # forward(sr, hr, None, encoded) launches kernels only
+    LABEL_BUCKET = 32                  # stroke sequences are long (a ten-letter word: ~40 strokes)
+
+    def encode(self, label, device=None, bucket=0):
+        """label_stroke_encoder (reference :49-80) as one padded device tensor (loss/padded_labels.py)"""
+        from .padded_labels import PaddedLabels
+        label = ["".join(self.dic[c] for c in one if c in self.dic) + "0" for one in label]
+        return PaddedLabels.build([[self.english_stroke_dict[c] for c in s] for s in label], device or self.device, bucket)
+
+    def encode_for_replay(self, label, device=None):
+        if not getattr(self.args, "text_focus", False):
+            return None
+        return self.encode(label, device, self.LABEL_BUCKET)
+
     def forward(self, sr_img, hr_img, label, encoded=None):
         mse_loss = K.mse_loss(sr_img, hr_img)
         if not getattr(self.args, "text_focus", False):
             return mse_loss, mse_loss, -1, -1
-        length_tensor, input_tensor, _ = self.label_stroke_encoder(label)
+        enc = encoded if encoded is not None else self.encode(label, sr_img.device)
         tr = self.transformer
         with torch.no_grad():
-            _, word_attention_map_gt, _ = tr(to_gray_tensor(hr_img), length_tensor, input_tensor, test=False,
-                                             want_correct=self.correct_flag)
-        _, word_attention_map_pred, _ = tr(to_gray_tensor(sr_img), length_tensor, input_tensor, test=False,
-                                           want_correct=self.correct_flag)
-        attention_loss = ops.l1_loss(word_attention_map_gt, word_attention_map_pred)
+            _, word_attention_map_gt = tr.forward_padded(to_gray_tensor(hr_img), enc.text_input)
+        _, word_attention_map_pred = tr.forward_padded(to_gray_tensor(sr_img), enc.text_input)
+        # nn.L1Loss over the [B, 16, max(len), 256] maps (reference :105), read out of the padded layout
+        attention_loss = ops.l1_loss_masked(word_attention_map_gt, word_attention_map_pred, enc.plan)
         loss = mse_loss + attention_loss * float(getattr(self.args, "stroke_lambda", 50))
         return loss, mse_loss, attention_loss, -1

@@ -119,17 +119,35 @@ class TextFocusLoss(nn.Module):
         length_tensor._focr_host = length
         return length_tensor, torch.from_numpy(input_tensor).to(self.device), text_gt.to(self.device)
 
+    # ---- recordable step (engine.TrainStep): the labels as a PaddedLabels batch, the forward as kernel launches only
+    REPLAY_SAFE = True                 # forward(sr, hr, None, encoded) launches kernels only
+    LABEL_BUCKET = 8                   # label capacity of a recording: longest label rounded up to a multiple of this
+
+    def encode(self, label, device=None, bucket=0):
+        """the reference's filtering + `-` terminator (text_focus_loss.py:88) and label_encoder (:62-81) as one padded
+        device tensor (loss/padded_labels.py); bucket = 0: capacity = the longest label, i.e. the reference's shapes"""
+        from .padded_labels import PaddedLabels
+        label = [str_filt(i, "lower") + "-" for i in label]
+        return PaddedLabels.build([[self.english_dict[c] for c in s] for s in label], device or self.device, bucket)
+
+    def encode_for_replay(self, label, device=None):
+        if not getattr(self.args, "text_focus", False):
+            return None
+        return self.encode(label, device, self.LABEL_BUCKET)
+
     def forward(self, sr_img, hr_img, label, encoded=None):
         mse_loss = K.mse_loss(sr_img, hr_img)
         if not getattr(self.args, "text_focus", False):
             return mse_loss, mse_loss, -1, -1
-        label = [str_filt(i, "lower") + "-" for i in label]
-        length_tensor, input_tensor, text_gt = self.label_encoder(label)
+        enc = encoded if encoded is not None else self.encode(label, sr_img.device)
         tr = self.transformer
         with torch.no_grad():
-            _, word_attention_map_gt, _ = tr(to_gray_tensor(hr_img), length_tensor, input_tensor, test=False)
-        sr_pred, word_attention_map_pred, _ = tr(to_gray_tensor(sr_img), length_tensor, input_tensor, test=False)
-        attention_loss = ops.l1_loss(word_attention_map_gt, word_attention_map_pred)
-        recognition_loss = ops.weight_cross_entropy(sr_pred, text_gt, self.weight_table())
+            _, word_attention_map_gt = tr.forward_padded(to_gray_tensor(hr_img), enc.text_input)
+        sr_logits, word_attention_map_pred = tr.forward_padded(to_gray_tensor(sr_img), enc.text_input)
+        # nn.L1Loss over the [B, 16, max(len), 256] maps and weight_cross_entropy over the sum(len) real positions
+        # (text_focus_loss.py:92-93), read out of the padded layout
+        attention_loss = ops.l1_loss_masked(word_attention_map_gt, word_attention_map_pred, enc.plan)
+        recognition_loss = ops.weight_cross_entropy_masked(sr_logits.reshape(enc.batch * enc.cap, -1), enc.text_gt,
+                                                           self.weight_table(), enc.plan)
         loss = mse_loss + attention_loss * 10 + recognition_loss * 0.0005
         return loss, mse_loss, attention_loss, recognition_loss

@@ -90,17 +90,23 @@ class Transformer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
-    def forward(self, image, text_length, text_input, test=False, attention_map=None):
-        """-> (probs_res [sum L, 37], word_attention_map [B,16,L,256], None); test=True: the padded logits"""
+    def forward_padded(self, image, text_input, attention_map=None):
+        """the network on a padded teacher-forcing matrix -> (logits [B, L, 37], word_attention_map [B,16,L,256]); no
+        label-dependent shapes, nothing on the host (loss/padded_labels.py)"""
         conv_feature = self.encoder(image)
         emb = self.embedding_word(text_input)
         pos = self.pe(emb)
         b, length, _ = emb.shape
         x = K.concat_pe(emb.reshape(1, b * length, -1), pos.reshape(b * length, -1)).view(b, length, -1)
         x, word_attention_map = self.decoder(x, conv_feature, attention_map=attention_map)
-        logits = self.generator_word(x)
+        return self.generator_word(x), word_attention_map
+
+    def forward(self, image, text_length, text_input, test=False, attention_map=None):
+        """-> (probs_res [sum L, 37], word_attention_map [B,16,L,256], None); test=True: the padded logits"""
+        logits, word_attention_map = self.forward_padded(image, text_input, attention_map=attention_map)
         if test:
             return logits
+        b, length = logits.shape[0], logits.shape[1]
         lens = getattr(text_length, "_focr_host", None)
         if lens is None:
             lens = [int(v) for v in text_length.tolist()]

@@ -35,10 +35,9 @@ class Transformer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
-    def forward(self, image, text_length, text_input, test=False, attention_map=None, want_correct=True):
-        """-> (probs_res [sum L, 10], word_attention_map [B,16,L,256], correct_list); test=True: the padded logits.
-        want_correct=False (used by StrokeFocusLoss, whose correct_flag is off) skips the host read-back of
-        correct_list and returns None in its place: no device synchronisation inside the training step."""
+    def forward_padded(self, image, text_input, attention_map=None):
+        """the network on a padded teacher-forcing matrix -> (logits [B, L, 10], word_attention_map [B,16,L,256]); no
+        label-dependent shapes, nothing on the host (loss/padded_labels.py)"""
         if image.shape[1] == 4:                       # reference :363-367: the mask channel is dropped, RGB -> luma
             image = K.bicubic_gray(image, image.shape[3])
         conv_feature = self.encoder(image)
@@ -47,7 +46,14 @@ class Transformer(nn.Module):
         b, length, _ = emb.shape
         x = K.concat_pe(emb.reshape(1, b * length, -1), pos.reshape(b * length, -1)).view(b, length, -1)
         x, word_attention_map = self.decoder(x, conv_feature, attention_map=attention_map)
-        logits = self.generator_word_with_upperword(x)
+        return self.generator_word_with_upperword(x), word_attention_map
+
+    def forward(self, image, text_length, text_input, test=False, attention_map=None, want_correct=True):
+        """-> (probs_res [sum L, 10], word_attention_map [B,16,L,256], correct_list); test=True: the padded logits.
+        want_correct=False (used by StrokeFocusLoss, whose correct_flag is off) skips the host read-back of
+        correct_list and returns None in its place: no device synchronisation inside the training step."""
+        logits, word_attention_map = self.forward_padded(image, text_input, attention_map=attention_map)
+        b, length = logits.shape[0], logits.shape[1]
         if test:
             return logits
         lens = getattr(text_length, "_focr_host", None)

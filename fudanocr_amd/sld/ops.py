@@ -216,3 +216,61 @@ class _WeightCE(torch.autograd.Function):
 def weight_cross_entropy(logits, target, table):
     """loss/weight_ce_loss.py:38-45 with the [C, C] weight table as an argument"""
     return _WeightCE.apply(logits, target, table)
+
+
+class _L1Masked(torch.autograd.Function):
+    """l1_loss on padded maps [outer, L, inner]: positions j >= plan[0] (device int64) are outside the sum, the mean and the
+    gradient (csrc/sld_ops.hip: the recordable form of the focus losses)"""
+
+    @staticmethod
+    def forward(ctx, a, b, plan):
+        a, b = a.contiguous(), b.contiguous()
+        _chk(a, b)
+        inner, length = a.shape[-1], a.shape[-2]
+        outer = a.numel() // (inner * length)
+        out = torch.empty(1, device=a.device)
+        ws = torch.empty(256, device=a.device)
+        _lib.call("focr_l1_masked_fwd", _p(a), _p(b), _p(out), _p(ws), outer, length, inner, _ip(plan), _stream())
+        ctx.save_for_backward(a, b, plan)
+        ctx.cfg = (outer, length, inner)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, plan = ctx.saved_tensors
+        outer, length, inner = ctx.cfg
+        db = torch.empty_like(b)
+        _lib.call("focr_l1_masked_bwd", _p(a), _p(b), _p(g.contiguous().reshape(1)), _p(db), outer, length, inner, _ip(plan),
+                  _stream())
+        return None, db, None
+
+
+def l1_loss_masked(a_const, b, plan):
+    return _L1Masked.apply(a_const, b, plan)
+
+
+class _WeightCEMasked(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, table, plan):
+        logits = logits.contiguous()
+        _chk(logits, table)
+        rows, c = logits.shape
+        loss = torch.empty(1, device=logits.device)
+        ws = torch.empty(rows, device=logits.device)
+        grad = torch.empty_like(logits)
+        _lib.call("focr_weight_cross_entropy_masked_fwd", _p(logits), _ip(target), _p(table), _p(loss), _p(ws), _p(grad), rows,
+                  c, _ip(plan), _stream())
+        ctx.save_for_backward(grad)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        out = torch.empty_like(grad)
+        _lib.call("focr_scale_dev", _p(grad), _p(g.contiguous().reshape(1)), _p(out), grad.numel(), _stream())
+        return out, None, None, None
+
+
+def weight_cross_entropy_masked(logits, target_padded, table, plan):
+    """weight_cross_entropy over padded rows [B * L, C]: target < 0 = padding; mean over plan[1] (device int64) rows"""
+    return _WeightCEMasked.apply(logits, target_padded, table, plan)

@@ -456,6 +456,17 @@ int focr_l1_fwd(const float* a, const float* b, float* out, float* ws, long n, f
 int focr_l1_bwd(const float* a, const float* b, const float* g, float* db, long n, focr_stream_t stream);
 int focr_weight_cross_entropy_fwd(const float* logits, const long long* target, const float* table, float* loss,
                                   float* nll_ws, float* grad, long rows, int C, focr_stream_t stream);
+/* the same two losses on PADDED label layouts (recordable step: shapes do not depend on the batch's labels).  plan: device
+ * int64 [>= 2] = {longest label of the batch, number of real label positions}.  L1: a, b [outer][L][inner], positions
+ * j >= plan[0] are left out of the sum, the mean (outer * plan[0] * inner entries) and the gradient; weighted CE: rows with
+ * target < 0 are padding, mean over plan[1] rows.  text_focus_loss.py:62-99 with L = a capacity instead of max(len). */
+int focr_l1_masked_fwd(const float* a, const float* b, float* out, float* ws, long outer, int L, int inner,
+                       const long long* plan, focr_stream_t stream);
+int focr_l1_masked_bwd(const float* a, const float* b, const float* g, float* db, long outer, int L, int inner,
+                       const long long* plan, focr_stream_t stream);
+int focr_weight_cross_entropy_masked_fwd(const float* logits, const long long* target, const float* table, float* loss,
+                                         float* nll_ws, float* grad, long rows, int C, const long long* plan,
+                                         focr_stream_t stream);
 
 /* ---- data-parallel gradient exchange (RCCL over xGMI; replaces nn.DataParallel's gather of the gradients,
  * reference interfaces/base.py:178-179).  One communicator per process = per GPU.  RCCL is bound at run time.

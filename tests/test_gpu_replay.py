@@ -288,3 +288,66 @@ def test_sld_recorded_step_equals_eager():
         assert float((p_r - p_e).abs().max()) <= 1e-4 * float(p_e.abs().max()), s_
         moved = (w_e - snap[0]).abs()
         assert float((w_r - w_e).abs().mean()) <= 0.02 * float(moved.mean()), s_
+
+
+@pytest.mark.parametrize("kind", ["tfl", "sfl"])
+def test_recorded_focus_step_equals_eager(kind):
+    """The reference's real training criteria (main.py --text_focus: TextFocusLoss; text-gestalt: StrokeFocusLoss) as a
+    RECORDED step: labels padded to a capacity bucket (loss/padded_labels.py) so that no launch depends on the batch's
+    labels.  A cycle of batches with DIFFERENT labels -- different lengths inside one bucket, and a second bucket -- each
+    step taken twice from the same restored state, re-issued from the recording and launched from Python: same loss terms,
+    gradient norm, update and SR output.  Dropout on."""
+    import types
+    from fudanocr_amd.engine import TrainStep
+    from fudanocr_amd.loss.stroke_focus_loss import StrokeFocusLoss, standin_decomposition
+    from fudanocr_amd.loss.text_focus_loss import TextFocusLoss
+    from fudanocr_amd.utils.weight_fill import fill_module_
+    dev = torch.device("cuda", 0)
+    net, _, _ = build("tbsrn", False)
+    if kind == "tfl":
+        from fudanocr_amd.loss.transformer import Transformer
+        tr = fill_module_(Transformer()).to(dev).eval()
+        crit = TextFocusLoss(types.SimpleNamespace(text_focus=True), transformer=tr, device=dev,
+                             weight_table=torch.rand(37, 37, generator=torch.Generator().manual_seed(3)) + 0.5)
+        long_label = "abcdefghij0123"                        # 15 symbols with the terminator: the second bucket (16)
+    else:
+        from fudanocr_amd.loss.transformer_english_decomposition import Transformer
+        tr = fill_module_(Transformer()).to(dev).eval()
+        crit = StrokeFocusLoss(types.SimpleNamespace(text_focus=True, stroke_lambda=50), transformer=tr, device=dev,
+                               decomposition=standin_decomposition())
+        long_label = "abcdefghijklmnopqrstuvwxyz"            # well over 32 strokes: the second bucket
+    for p in tr.parameters():
+        p.requires_grad = False
+    lr_ = 1e-4
+    step = TrainStep(net, crit, lr=lr_, dropout=True, replay=True, seed=5)
+    caps = set()
+    n_replayed = 0
+    short = [["ab1", "c", "de", "f9z"], ["q", "rs7", "tu", "v"], ["w0", "xyz", "a", "bc"]]       # <= 4 symbols: first bucket
+    for s in range(14):
+        l, h, _ = make_batch(4, 500 + s % 4)
+        labels = [long_label, "ab", "c", "d1"] if s % 3 == 2 else short[(s // 3 + s % 3) % 3]
+        l, h = l.cuda(), h.cuda()
+        caps.add(crit.encode_for_replay(labels, dev).cap)
+        if s < 2:
+            step(l, h, labels)           # the engine's lazy tables (attention keep-bit buffers, fragment / flip tables) fill here
+            continue
+        snap = _snapshot(step, net)
+        res = {}
+        for how in ("replay", "eager"):
+            _restore(step, net, snap)
+            step.replay = how == "replay"
+            step.recorded = None
+            out = step(l, h, labels)
+            res[how] = (out["loss"].item(), out["mse"].item(), step.opt.grad_norm().item(), step.flat.flat_param.clone(),
+                        out["sr"].clone(), step.recorded is not None)
+        step.replay = True
+        (l_r, m_r, g_r, p_r, sr_r, was_rec), (l_e, m_e, g_e, p_e, sr_e, _) = res["replay"], res["eager"]
+        n_replayed += int(was_rec)
+        assert abs(l_r - l_e) <= 2e-6 * abs(l_e) and abs(m_r - m_e) <= 2e-6 * abs(m_e), (s, l_r, l_e)
+        assert abs(g_r - g_e) <= 1e-4 * abs(g_e), (s, g_r, g_e)
+        d = (p_r - p_e).abs()
+        moved = (p_e - snap[0]).abs()
+        assert float(d.max()) <= 2.5 * lr_ and float(d.mean()) <= 0.02 * float(moved.mean()), (s, d.max(), d.mean())
+        assert float((sr_r - sr_e).abs().max()) <= 1e-5 * float(sr_e.abs().max()), s
+    assert len(caps) == 2, caps                                # two buckets were exercised ...
+    assert n_replayed >= 4 and len(step._recs) == 2, (n_replayed, len(step._recs))     # ... and both were recorded and re-issued

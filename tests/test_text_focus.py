@@ -441,3 +441,89 @@ def test_stroke_focus_loss_golden(golden_dir, mode):
         assert off[2] == -1 and off[3] == -1 and abs(off[0].item() - g["losses"][1]) < 1e-3 * g["losses"][1]
     finally:
         _lib.set_precision(old)
+
+
+@pytest.mark.gpu
+def test_masked_focus_losses_match_the_packed_forms():
+    """focr_l1_masked_* / focr_weight_cross_entropy_masked_fwd (padded label layout, the real extents in a device plan) against
+    torch on the packed layout the reference uses (text_focus_loss.py:92-93: L1 over [B,16,max(len),256], weighted CE over
+    the sum(len) real rows): values and gradients; the padded part gets exactly zero gradient."""
+    from fudanocr_amd import _lib
+    from fudanocr_amd.loss.padded_labels import PaddedLabels
+    from fudanocr_amd.sld import ops
+    _lib.load()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(5)
+    ids = [[3, 7, 1, 0], [5, 0], [9, 9, 2, 4, 6, 1, 0], [8, 0], [1, 2, 3, 0]]
+    B, C = len(ids), 37
+    for bucket in (0, 8, 16):
+        enc = PaddedLabels.build(ids, dev, bucket)
+        L, lmax, total = enc.cap, 7, sum(len(s) for s in ids)
+        assert (L == 7 if bucket == 0 else L == bucket) and enc.plan[:2].tolist() == [lmax, total]
+        assert enc.text_input[2].tolist()[:7] == [0, 9, 9, 2, 4, 6, 1] and enc.text_input[1].tolist()[:3] == [0, 5, 0]
+        a = torch.rand(B, 16, L, 256, generator=g).to(dev)
+        b = torch.rand(B, 16, L, 256, generator=g).to(dev).requires_grad_(True)
+        loss = ops.l1_loss_masked(a, b, enc.plan)
+        (loss * 3.0).backward()
+        bd = b.detach().double().cpu().requires_grad_(True)
+        ref = (a.double().cpu()[:, :, :lmax] - bd[:, :, :lmax]).abs().mean()
+        (ref * 3.0).backward()
+        assert abs(loss.item() - ref.item()) <= 1e-6 * ref.item()
+        assert float((b.grad.double().cpu() - bd.grad).abs().max()) <= 1e-6 * float(bd.grad.abs().max())
+        assert float(b.grad[:, :, lmax:].abs().max()) == 0.0 if L > lmax else True
+        # weighted cross entropy: padded rows against the packed op on the gathered rows
+        table = (torch.rand(C, C, generator=g) + 0.5).to(dev)
+        x = torch.randn(B * L, C, generator=g).to(dev).requires_grad_(True)
+        lw = ops.weight_cross_entropy_masked(x, enc.text_gt, table, enc.plan)
+        (lw * 2.0).backward()
+        rows = [i * L + j for i, s in enumerate(ids) for j in range(len(s))]
+        xp = x.detach()[rows].clone().requires_grad_(True)
+        lp = ops.weight_cross_entropy(xp, torch.tensor([c for s in ids for c in s], device=dev), table)
+        (lp * 2.0).backward()
+        assert abs(lw.item() - lp.item()) <= 1e-6 * abs(lp.item())
+        assert float((x.grad[rows] - xp.grad).abs().max()) <= 1e-6 * float(xp.grad.abs().max())
+        pad = sorted(set(range(B * L)) - set(rows))
+        assert float(x.grad[pad].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["tfl", "sfl"])
+def test_focus_loss_padding_is_neutral(kind):
+    """the criterion on labels padded to a capacity bucket (what a recorded step uses) gives the loss terms and the SR
+    gradient of the reference-shaped batch (capacity = longest label): padded decoder positions sit behind the causal mask,
+    and the masked losses leave them out"""
+    import types
+    from fudanocr_amd import _lib
+    from fudanocr_amd.loss.stroke_focus_loss import StrokeFocusLoss, standin_decomposition
+    from fudanocr_amd.loss.text_focus_loss import TextFocusLoss
+    from fudanocr_amd.utils.weight_fill import fill_module_
+    _lib.load()
+    dev = torch.device("cuda", 0)
+    if kind == "tfl":
+        from fudanocr_amd.loss.transformer import Transformer
+        tr = fill_module_(Transformer()).to(dev).eval()
+        crit = TextFocusLoss(types.SimpleNamespace(text_focus=True), transformer=tr,
+                             weight_table=torch.rand(37, 37, generator=torch.Generator().manual_seed(3)) + 0.5)
+    else:
+        from fudanocr_amd.loss.transformer_english_decomposition import Transformer
+        tr = fill_module_(Transformer()).to(dev).eval()
+        crit = StrokeFocusLoss(types.SimpleNamespace(text_focus=True, stroke_lambda=50), transformer=tr,
+                               decomposition=standin_decomposition())
+    for p in tr.parameters():
+        p.requires_grad = False
+    _, hr, labels = make_batch(6, 99)
+    hr = hr.to(dev)
+    sr0 = (hr + 0.05 * torch.randn(hr.shape, generator=torch.Generator().manual_seed(1)).to(dev)).clamp(0, 1)
+    res = []
+    lmax = crit.encode(labels, dev, 0).cap
+    for bucket in (0, lmax + 3, 2 * lmax + 5):            # capacity = the longest label, then two larger ones
+        enc = crit.encode(labels, dev, bucket)
+        sr = sr0.clone().requires_grad_(True)
+        loss, mse, att, rec = crit(sr, hr, None, enc)
+        loss.backward()
+        res.append((enc.cap, loss.item(), att.item(), rec.item() if torch.is_tensor(rec) else 0.0, sr.grad.clone()))
+    assert res[0][0] < res[1][0] < res[2][0]
+    for cap, l, a, r, gr in res[1:]:
+        assert abs(l - res[0][1]) <= 1e-6 * abs(res[0][1]) and abs(a - res[0][2]) <= 2e-6 * abs(res[0][2])
+        assert abs(r - res[0][3]) <= 2e-6 * abs(res[0][3]) + 1e-12
+        assert float((gr - res[0][4]).abs().max()) <= 1e-5 * float(res[0][4].abs().max())
