@@ -225,7 +225,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   // experiment (tools/gpu/r03_call19.sh): delay the second resident block of every CU (ids t and t + 32 of an XCD share a
   // CU, see the trace) so that its staging overlaps the first one's contraction.  No gain at any delay: flat up to
   // 3.4 us, then slower by the delay.
-  if (((blockIdx.x >> 3) >> 5) & 1)
+  // (round 6, tools/gpu/r06_call40.sh: the same on the multi-slice layers, linear block id)
+  if ((((blockIdx.x + gridDim.x * blockIdx.y) >> 3) >> 5) & 1)
     for (int i = 0; i < H3_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);
 #endif
   // tile decode: the tiles of one image share halo rows/columns -> keep them on one XCD (block id % 8)
