@@ -152,9 +152,9 @@ class TrainStep:
     stream, so these collectives overlap the remaining backward kernels."""
 
     REPLAY_WARMUP = 2      # eager steps per input signature before the step is recorded (lazy tables, workspaces)
-    MAX_RECORDINGS = 5     # signatures kept (each recording owns a private memory pool of the step's temporaries): e.g. the
+    MAX_RECORDINGS = 6     # signatures kept (each recording owns a private memory pool of the step's temporaries): e.g. the
     #                        full batch, an epoch's short last batch, a second precision mode -- or, with the focus losses, the
-    #                        label-capacity buckets of the full batch (8 / 16 / 24 / 32 characters); further signatures step eagerly
+    #                        label-capacity buckets of the full batch (text-focus: multiples of 4 symbols); further signatures step eagerly
 
     def __init__(self, model, crit, lr=1e-4, betas=(0.5, 0.999), max_norm=0.25, process_group=None,
                  wgrad_side_stream=True, n_buckets=4, dropout=True, boundaries=("block3", "block6"),

@@ -118,7 +118,9 @@ class StrokeFocusLoss(nn.Module):
 
     # ---- recordable step (engine.TrainStep): the labels as a PaddedLabels batch, the forward as kernel launches only
     REPLAY_SAFE = True                 # forward(sr, hr, None, encoded) launches kernels only
-    LABEL_BUCKET = 32                  # stroke sequences are long (a ten-letter word: ~40 strokes)
+    # stroke sequences are long (a ten-letter word: ~30 strokes) but a padded position is as dear as in the text-focus loss
+    # (B = 128: 41.3 ms at 4, 41.6 at 8, 42.8 at 16, 45.2 at 32: profiles/r06_label_bucket_sweep.txt)
+    LABEL_BUCKET = int(os.environ.get("FOCR_LABEL_BUCKET", "8"))
 
     def encode(self, label, device=None, bucket=0):
         """label_stroke_encoder (reference :49-80) as one padded device tensor (loss/padded_labels.py)"""

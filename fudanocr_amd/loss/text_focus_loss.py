@@ -121,7 +121,10 @@ class TextFocusLoss(nn.Module):
 
     # ---- recordable step (engine.TrainStep): the labels as a PaddedLabels batch, the forward as kernel launches only
     REPLAY_SAFE = True                 # forward(sr, hr, None, encoded) launches kernels only
-    LABEL_BUCKET = 8                   # label capacity of a recording: longest label rounded up to a multiple of this
+    # label capacity of a recording: the batch's longest label rounded up to a multiple of this.  A padded position costs the
+    # decoder 0.16 ms per 128 samples (profiles/r06_label_bucket_sweep.txt: B = 128 38.3 ms at 4, 38.9 at 8 / 16, 41.1 at 32);
+    # a finer bucket costs recordings (engine.TrainStep.MAX_RECORDINGS, then eager steps)
+    LABEL_BUCKET = int(os.environ.get("FOCR_LABEL_BUCKET", "4"))
 
     def encode(self, label, device=None, bucket=0):
         """the reference's filtering + `-` terminator (text_focus_loss.py:88) and label_encoder (:62-81) as one padded

@@ -318,6 +318,7 @@ def test_recorded_focus_step_equals_eager(kind):
         long_label = "abcdefghijklmnopqrstuvwxyz"            # well over 32 strokes: the second bucket
     for p in tr.parameters():
         p.requires_grad = False
+    crit.LABEL_BUCKET = 8 if kind == "tfl" else 32           # (pinned: the schedule below is built around two capacities)
     lr_ = 1e-4
     step = TrainStep(net, crit, lr=lr_, dropout=True, replay=True, seed=5)
     caps = set()
