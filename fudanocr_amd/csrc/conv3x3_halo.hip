@@ -42,9 +42,21 @@ __host__ __device__ constexpr int h3_tp_for(int W) { return W <= 8 ? 8 : (W <= 1
 #define H3_KSC 2                                   // MFMA k-steps (16 channels) per weight chunk
 #define H3_NCHUNK 18                               // 9 taps x 4 k-steps / 2
 #ifndef H3_DIST
-#define H3_DIST 2                                  // weight chunks in flight ahead of the one being contracted
+#define H3_DIST 2                                  // weight chunks in flight ahead of the one being contracted (two planes)
 #endif
-#define H3_NBUF (H3_DIST + 1)                      // weight chunk buffers: chunk c + H3_DIST is in flight while c is contracted
+#ifndef H3_DIST1
+#define H3_DIST1 5                                 // ... single-product launches (round 6)
+#endif
+// Weight chunk buffers: chunk c + DIST is in flight while c is contracted.  The buffer index of a chunk is (c % NBUF) with c
+// counted per slice, so NBUF must divide the 18 chunks of a slice (3, 6, 9).  Two planes: 3 buffers of 8 KB -- deeper costs
+// the second resident block (76.8 -> 101 KB of LDS) and loses (437 -> 524 us on 512 -> 512, B = 128).  One plane: chunks are
+// 4 KB and the launch moves a third of the MFMAs per weight byte, so the DMA latency shows: 6 buffers (50.7 KB, still two
+// blocks per CU).
+template <int PLANES> struct H3Cfg {
+  static constexpr int DIST = PLANES == 1 ? H3_DIST1 : H3_DIST;
+  static constexpr int NBUF = DIST + 1;
+  static_assert(H3_NCHUNK % NBUF == 0, "chunk buffers must divide the chunks of a slice");
+};
 
 // byte offset (inside one halo plane) of the 16-byte chunk c (channels 8c..8c+7) of halo pixel (r, p):
 // a pixel is 128 B; the chunk index is XORed with bits 1..3 of p so that the 16 lanes of a ds_read_b128 group
@@ -137,7 +149,7 @@ template <int PLANES, int C, int J, int HP = H3_HP>
 __device__ __forceinline__ void h3_read_step(H3Frags<PLANES>& f, const unsigned (&aoff)[3][4], unsigned boff) {
   constexpr int l = H3_KSC * C + J, tap = l >> 2, kk = l & 3, kh = tap / 3, kw = tap - 3 * kh;
   constexpr int ao = kh * (HP * 128);
-  constexpr int bo = (C % H3_NBUF) * (2 * H3_KSC * PLANES * 1024);
+  constexpr int bo = (C % H3Cfg<PLANES>::NBUF) * (2 * H3_KSC * PLANES * 1024);
   h3_ldsr<ao>(f.a[0], aoff[kw][kk]);
   if (PLANES == 2) h3_ldsr<ao + H3_PLANE_BYTES>(f.a[1], aoff[kw][kk]);
   h3_ldsr<bo + ((0 * H3_KSC + J) * PLANES + 0) * 1024>(f.b[0][0], boff);
@@ -208,6 +220,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   constexpr int RPW = 32 / TP;                     // image rows of a wave's 32-pixel M tile
   constexpr int NP = 2 * H3_KSC * PLANES;          // 1 KB weight pieces per chunk (2 column tiles x 3 k-steps x planes)
   constexpr int BBUF = NP * 1024;
+  constexpr int DIST = H3Cfg<PLANES>::DIST, NBUF = H3Cfg<PLANES>::NBUF;
   constexpr int HALO = PLANES * H3_PLANE_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char h3_smem[];   // [halo planes][B buf 0][B buf 1]
   unsigned char* const bbase = h3_smem + HALO;
@@ -345,7 +358,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
   constexpr int NW = NP / 4;                        // DMA instructions per wave and chunk
 #pragma unroll
-  for (int c = 0; c < H3_DIST; ++c) issue_chunk(cg0, 0, c, c);
+  for (int c = 0; c < DIST; ++c) issue_chunk(cg0, 0, c, c);
   for (int gi = 0; gi < g.cg_loop; ++gi) {
     const int cg = cg0 + gi;
     f32x16 acc[2];
@@ -382,13 +395,13 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       // vmcnt: the pieces of C+2 stay in flight), barrier | read fa<-step0 of chunk C+1 | MFMA fb
 #define H3_CHUNK(C)                                                                              \
   {                                                                                              \
-    if ((C) + H3_DIST < H3_NCHUNK) issue_chunk(cg, s, (C) + H3_DIST, ((C) + H3_DIST) % H3_NBUF); \
-    else if (more) issue_chunk(ncg, nsl, (C) + H3_DIST - H3_NCHUNK, ((C) + H3_DIST) % H3_NBUF);  \
+    if ((C) + DIST < H3_NCHUNK) issue_chunk(cg, s, (C) + DIST, ((C) + DIST) % NBUF);             \
+    else if (more) issue_chunk(ncg, nsl, (C) + DIST - H3_NCHUNK, ((C) + DIST) % NBUF);           \
     h3_read_step<PLANES, (C), 1, HP>(fb, aoff, boff);                                               \
     h3_wait<PLANES, RS>(fa);                                                                     \
     h3_mfma_step<PLANES>(acc, fa);                                                               \
     h3_wait<PLANES, 0>(fb);                                                                      \
-    if ((C) + H3_DIST < H3_NCHUNK || more) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((H3_DIST - 1) * NW) : "memory"); \
+    if ((C) + DIST < H3_NCHUNK || more) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((DIST - 1) * NW) : "memory"); \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
     __builtin_amdgcn_s_barrier();                                                                \
     if ((C) + 1 < H3_NCHUNK) h3_read_step<PLANES, ((C) + 1) % H3_NCHUNK, 0, HP>(fa, aoff, boff);     \
@@ -498,7 +511,7 @@ template <int PLANES, int TP>
 static int launch_h3(const float* x, const __bf16* wf, const float* bias, const float* residual, float* y, float* stats,
                      int N, int H, int W, int Cin, int Cout, int ldx, int ldy, int ldr, float alpha, int relu,
                      hipStream_t stream) {
-  constexpr int LDS = PLANES * H3_PLANE_BYTES + H3_NBUF * (2 * H3_KSC * PLANES) * 1024;
+  constexpr int LDS = PLANES * H3_PLANE_BYTES + H3Cfg<PLANES>::NBUF * (2 * H3_KSC * PLANES) * 1024;
   constexpr int TR = 128 / TP;
   static focr_dev_flags attr_set;
   if (focr_dev_first(attr_set)) {

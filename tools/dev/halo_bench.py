@@ -19,7 +19,8 @@ def timeit(fn, iters=20, warm=5):
     return ts[len(ts) // 2] * 1e3, ts[0] * 1e3
 
 
-SHAPES = ((128, 8, 32, 512, 512), (128, 8, 32, 256, 256), (128, 8, 32, 512, 1024), (128, 16, 64, 128, 128), (128, 16, 64, 64, 128),
+SHAPES = ((16, 8, 32, 512, 512), (16, 8, 32, 256, 256), (16, 8, 32, 512, 1024), (16, 16, 64, 128, 128), (8, 16, 16, 512, 512),
+          (128, 8, 32, 512, 512), (128, 8, 32, 256, 256), (128, 8, 32, 512, 1024), (128, 16, 64, 128, 128), (128, 16, 64, 64, 128),
           (32, 16, 16, 512, 512), (32, 16, 16, 256, 256), (32, 8, 8, 1024, 1024), (128, 16, 64, 64, 64))
 for (n, h, w, cin, cout) in SHAPES:
     x = torch.randn(n, h, w, cin, device=dev, generator=g)
