@@ -562,7 +562,8 @@ def main():
                     fa * len(fwd), 0.0, sum(fwd), len(fwd), 3 if bx3 else 1)
             r["launches_per_step"] = len(fwd) // args.steps
             also.append(r)
-            single = mode >= 2 and _lib.load().focr_get_tuning(3) == 2
+            _v3 = _lib.load().focr_get_tuning(3)
+            single = mode >= 2 and (_v3 == 2 or (_v3 == 4 and batch * 4 >= 128))
             # backward = 2 x forward algorithmic flops (dV, dP, dK, dQ products); the score recomputation is
             # executed work, not algorithmic work: it is counted in executed_frac only
             r = row("attn_bwd1_bx3_kernel (single pass: dQ, dK, dV from ONE S / dP evaluation; algorithmic flops = 2x the "

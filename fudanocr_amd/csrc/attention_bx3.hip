@@ -1244,7 +1244,12 @@ int focr_attn_bwd_bx3(const float* q, const float* k, const float* v, const floa
     return 0;
   }
 #endif
-  if (fast && focr_get_tuning(FOCR_TUNE_ATTN_BWD_DQ_VARIANT) == 2 && Ntok % 256 == 0) {
+  // Variant (tuning key 3): 4 (default) = by grid size.  The single pass launches ONE block per (batch, head) that walks all
+  // key chunks and query tiles: 157 us whatever the batch up to B * H = 128 blocks (a quarter of the CUs at the reference
+  // README's batch 16), where the two-pass kernels (one block per 128 / 256 queries) take 78 / 101 / 137 / 163 us at
+  // B = 8 / 16 / 24 / 32 -- and 611 against 412 at B = 128 (profiles/r06_attn_bwd_batch.txt).  2 = single pass always.
+  const int variant = focr_get_tuning(FOCR_TUNE_ATTN_BWD_DQ_VARIANT);
+  if (fast && (variant == 2 || (variant == 4 && B * H >= 128)) && Ntok % 256 == 0) {
     // single pass: dQ, dK, dV from one S / dP evaluation (attention_bwd1_bx3.h); 138.5 KB of LDS per block.  The
     // attribute is per device: set on every call (a host-side table lookup) rather than cached in a process-wide flag.
     // Mode 3 (bf16 data gradients): dP = dO V^T as a single bf16 product (template flag DP1).
@@ -1283,7 +1288,7 @@ int focr_attn_bwd_bx3(const float* q, const float* k, const float* v, const floa
     if (launched) return 0;
   }
   dim3 grid(B * H * (Ntok / 128));
-  const bool dq2 = focr_get_tuning(FOCR_TUNE_ATTN_BWD_DQ_VARIANT) == 1 && Ntok % 256 == 0;      // two query tiles per wave in the dQ pass
+  const bool dq2 = variant != 0 && Ntok % 256 == 0;      // two query tiles per wave in the dQ pass
 #define LAUNCH_BWD(DR, FA)                                                                                        \
   do {                                                                                                            \
     hipLaunchKernelGGL((attn_bwd_dkv_bx3_kernel<DR, FA, false>), grid, 256, 0, stream, q, k, v, d_o, lse, dwork, dk, dv, \

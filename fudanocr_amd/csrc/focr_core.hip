@@ -55,7 +55,7 @@ extern "C" int focr_get_precision(void) { return g_precision.load(std::memory_or
 //   5 "gru_loader"          2: 16-sequence compute waves on the 16x16x32 MFMA + one loader wave (default)
 //                            1: TSRN GRU scans as loader / compute wave pairs (operands of the next steps DMA'd into an LDS
 //                            ring by a second wave, rnn.hip)   0: single-wave scans with register prefetch (rounds 1-5)
-static std::atomic<int> g_tuning[FOCR_TUNING_COUNT] = {{1}, {1}, {1}, {2}, {2}, {2}};
+static std::atomic<int> g_tuning[FOCR_TUNING_COUNT] = {{1}, {1}, {1}, {4}, {2}, {2}};
 extern "C" int focr_set_tuning(int key, int value) {
   if (key < 0 || key >= FOCR_TUNING_COUNT) {
     focr_set_error("focr_set_tuning: unknown key %d", key);

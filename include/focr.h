@@ -48,9 +48,10 @@ int focr_set_precision(int mode);
  * kernel (0); key 1: attention forward with 256-query (1, default) / 128-query (0) blocks / look-ahead scores (2);
  * key 2: persistent LSTM scan, one launch per layer (1, default; 2 = the same with the agent-scope release in every step even
  * when a group's 8 blocks share an XCD) or one launch per time step (0);
- * key 3: attention backward: 2 (default) = single pass, dQ / dK / dV from one S / dP evaluation (precision modes 2 / 3
+ * key 3: attention backward: 2 = single pass, dQ / dK / dV from one S / dP evaluation (precision modes 2 / 3
  * and Ntok % 256 == 0, otherwise as 1); 1 = two passes (dK/dV, then dQ with 256-query blocks); 0 = two passes,
- * 128-query dQ blocks; key 4: the 256-query attention forward: 2 (default) = keep-word scalar requests behind the K-fragment
+ * 128-query dQ blocks; 4 (default) = 2 when the launch has at least 128 (batch, head) blocks, else 1 (one block per (batch, head)
+ * leaves most CUs idle at small batches); key 4: the 256-query attention forward: 2 (default) = keep-word scalar requests behind the K-fragment
  * reads (travelling under the score MFMAs) + softmax on scores relative to the running reference (cross-half max exchange
  * only in the rescale branch); 1 = the keep-word schedule alone; 0 = requests in front of the fragment reads (round 1-4).
  * Values 0 and 1 are bit-identical; 2 agrees with them to rounding whenever a rescale happens.

@@ -473,7 +473,7 @@ def test_attention_backward_single_pass(p, t):
         close(g3, qkv.grad, gtol(3), what="single-pass, mode 3 (single-bf16 dP): d qkv vs fp64")
         assert torch.equal(g3[..., 256:], res[2][1][..., 256:]), "dV does not depend on dP"
     finally:
-        _lib.call("focr_set_tuning", 3, 2)
+        _lib.call("focr_set_tuning", 3, 4)       # the default: variant by grid size
         _lib.set_precision(2)
 
 
