@@ -568,6 +568,53 @@ def test_full_size_step_vs_oracle(cfg):
         _lib.set_precision(old)
 
 
+def test_full_size_step_vs_oracle_mask():
+    """The reference's `--mask` (main.py:31: a fourth, binarised-luma input / output channel, dataset.py:146-151) on the c3
+    step at B = 64 against the CPU oracle: both 9 x 9 layers run on their four-channel kernels (conv9x9_cin4.hip forward and
+    output-layer data gradient; conv9x9_out.hip as two launches of two channels, forward and weight gradient).  SR pixels,
+    losses, pre-clip gradient norm, and the gradients of the two 9 x 9 layers element-wise."""
+    from fudanocr_amd import _lib
+    from fudanocr_amd.engine import TrainStep
+    from fudanocr_amd.smoke import build_models
+    from fudanocr_amd.utils.synth import with_mask
+    from fudanocr_amd.utils.weight_fill import fill_dict_
+    from oracle import sr_oracle as O
+    b = 64
+    old = _lib.get_precision()
+    _lib.set_precision(3)
+    try:
+        net, rec, crit = build_models(torch.device("cuda:0"), "tbsrn", mask=True)
+        step = TrainStep(net, crit, dropout=False)
+        lr, hr, labels = make_batch(b, 2027)
+        lr, hr = with_mask(lr), with_mask(hr)
+        out = step(lr.cuda(), hr.cuda(), labels)
+        torch.cuda.synchronize()
+        P = O.make_params(O.schema_sr("tbsrn", in_planes=4))
+        fill_dict_({k: v.data for k, v in P.items()})
+        C = O.make_params(O.schema_crnn(), requires_grad=False)
+        fill_dict_(C)
+        tgt, tlen = O.encode_labels(labels)
+        with _oracle_threads():
+            loss, mse, ctc, sr = O.step_loss(P, "tbsrn", lr, hr, C, tgt, tlen, True, 0.0, 5, True)
+            (loss * 100).backward()
+        gn = float(torch.sqrt(sum((v.grad.double() ** 2).sum() for v in P.values() if v.requires_grad and v.grad is not None)))
+        e_sr = rel_to_max(out["sr"], sr.detach())
+        e_loss = abs(out["loss"].item() - loss.item()) / abs(loss.item())
+        e_ctc = abs(out["ctc"].item() - ctc.item()) / abs(ctc.item())
+        e_gn = abs(step.opt.grad_norm().item() - gn) / gn
+        named = dict(net.named_parameters())
+        nine = [n for n, p in named.items() if p.dim() == 4 and p.shape[-1] == 9]
+        errs = [(n, rel_to_max(named[n].grad, P[n].grad)) for n in nine]
+        _note("full_size_step_vs_oracle --mask (B = %d, mode 3): sr %.2e loss %.2e ctc %.2e grad-norm %.2e; 9x9 weight gradients %s"
+              % (b, e_sr, e_loss, e_ctc, e_gn, [(n, tuple(named[n].shape), "%.2e" % e) for n, e in errs]))
+        assert out["sr"].shape[1] == 4 and len(nine) == 2, nine
+        assert e_sr < 1e-3 and e_loss < 1e-3 and e_ctc < 1e-3, (e_sr, e_loss, e_ctc)
+        assert e_gn < 2e-2, e_gn
+        assert max(e for _, e in errs) < 1e-2, errs
+    finally:
+        _lib.set_precision(old)
+
+
 def test_full_size_step_vs_oracle_tsrn():
     """The TSRN variant of configs[2] (`bench.py --config c1`: TSRN + frozen CRNN-CTC, per-GPU batch 128) at its FULL size
     against the CPU oracle's step, in the bench's arithmetic mode (3): SR pixels, losses, pre-clip gradient norm, and the
