@@ -29,6 +29,7 @@ SIGNATURES = {
     "focr_weight_prep_frag_batched": [P, I, L, P],
     "focr_conv3x3_frag_tiles": [I, I, I],
     "focr_conv3x3_frag_fwd": [P, P, P, P, P, P, I, I, I, I, I, F, I, I, I, I, I, P],
+    "focr_conv3x3_frag_fwd_masked": [P, P, P, P, P, I, I, I, I, I, F, I, I, I, I, P, I, P],
     "focr_attention_fwd": [P, P, P, P, P, P, I, I, I, I, I, F, F, U, P],
     "focr_attention_dropout_mask": [P, I, I, I, F, U, P],
     "focr_attention_fwd_premasked": [P, P, P, P, P, P, I, I, I, I, I, F, F, P],

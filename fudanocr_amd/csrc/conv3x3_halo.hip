@@ -200,6 +200,7 @@ struct H3Geom {
   int tiles_x, tiles_y, cg_loop;   // cg_loop: 64-channel output groups walked inside one block (Cin == 64 only)
   int ksteps_total;                // 9 * Cin / 16
   int tiles, gfast;                // gfast: 1-D grid, the output groups of one tile are neighbours on one XCD (see the decode)
+  int ldm;                         // pixel pitch of the mask source (epilogue: output kept where mask > 0, else 0)
 };
 
 #ifdef H3_TRACE
@@ -215,7 +216,10 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ R, float* __restrict__ Y,
                                                               float* __restrict__ stats, H3Geom g, float alpha,
-                                                              int relu) {
+                                                              int relu, const float* __restrict__ Mk) {
+  // Mk (round 6, data-gradient launches): the layer's INPUT x = relu(...) of the forward pass.  The gradient this launch
+  // produces is the gradient of that relu's output; keeping it only where x > 0 IS the producer's relu backward, so the
+  // producer skips its own pass (kernels.StepContext.premasked) -- one launch and one read + write of the tensor less per layer.
   constexpr int TR = 128 / TP, HR = TR + 2, HP = TP + 2;      // tile rows, halo rows / pixels per halo row
   constexpr int RPW = 32 / TP;                     // image rows of a wave's 32-pixel M tile
   constexpr int NP = 2 * H3_KSC * PLANES;          // 1 KB weight pieces per chunk (2 column tiles x 3 k-steps x planes)
@@ -424,6 +428,16 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       // its own 8 KB of it, so that a lane owns 4 consecutive channels of one pixel: 16-byte residual loads and
       // output stores (a pixel's 256 B row is one contiguous access of 16 lanes) instead of 32 + 32 scalar ones
       float* const tw = reinterpret_cast<float*>(h3_smem) + wave * (32 * 64);
+      float4 mv[8];                               // mask source values (requested here, under the transposition)
+      if (Mk) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int m = 4 * i + epq, ox = x0 + m % TP, oyy = oy + m / TP;
+          const bool ok = oyy < g.H && ox < g.W;
+          const size_t pix = (size_t)(img * g.H + (ok ? oyy : 0)) * g.W + (ok ? ox : 0);
+          mv[i] = *reinterpret_cast<const float4*>(Mk + pix * g.ldm + eco);
+        }
+      }
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -440,6 +454,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         float4 v = make_float4(alpha * a.x + bv.x + rv[i].x, alpha * a.y + bv.y + rv[i].y, alpha * a.z + bv.z + rv[i].z,
                                alpha * a.w + bv.w + rv[i].w);
         if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        if (Mk)
+          v = make_float4(mv[i].x > 0.f ? v.x : 0.f, mv[i].y > 0.f ? v.y : 0.f, mv[i].z > 0.f ? v.z : 0.f,
+                          mv[i].w > 0.f ? v.w : 0.f);
         const int m = 4 * i + pq, oyy = oy + m / TP;
         if (oyy < g.H && x0 + m % TP < g.W) {
           const size_t pix = (size_t)(img * g.H + oyy) * g.W + x0e + m % TP;
@@ -491,7 +508,11 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
           const int m = (r & 3) + 8 * (r >> 2) + 4 * lh, ox = x0 + m % TP, oyy = oy + m / TP;
           float v = alpha * acc[nt][r] + b + rv[r];
           if (relu) v = fmaxf(v, 0.f);
-          if (oyy < g.H && ox < g.W) Y[((size_t)(img * g.H + oyy) * g.W + ox) * g.ldy + co] = v;
+          if (oyy < g.H && ox < g.W) {
+            const size_t pix = (size_t)(img * g.H + oyy) * g.W + ox;
+            if (Mk && !(Mk[pix * g.ldm + co] > 0.f)) v = 0.f;
+            Y[pix * g.ldy + co] = v;
+          }
         }
       }
     }
@@ -510,7 +531,7 @@ int focr_conv3x3_halo_eligible(int H, int W, int Cin, int Cout, int KH, int KW, 
 template <int PLANES, int TP>
 static int launch_h3(const float* x, const __bf16* wf, const float* bias, const float* residual, float* y, float* stats,
                      int N, int H, int W, int Cin, int Cout, int ldx, int ldy, int ldr, float alpha, int relu,
-                     hipStream_t stream) {
+                     hipStream_t stream, const float* mask = nullptr, int ldm = 0) {
   constexpr int LDS = PLANES * H3_PLANE_BYTES + H3Cfg<PLANES>::NBUF * (2 * H3_KSC * PLANES) * 1024;
   constexpr int TR = 128 / TP;
   static focr_dev_flags attr_set;
@@ -522,6 +543,7 @@ static int launch_h3(const float* x, const __bf16* wf, const float* bias, const 
   }
   H3Geom g;
   g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ldx = ldx; g.ldy = ldy; g.ldr = ldr;
+  g.ldm = ldm;
   g.tiles_x = (W + TP - 1) / TP;
   g.tiles_y = (H + TR - 1) / TR;
   g.ksteps_total = 9 * Cin / 16;
@@ -535,17 +557,17 @@ static int launch_h3(const float* x, const __bf16* wf, const float* bias, const 
   g.gfast = (gfast_on && PLANES == 1 && Cin >= 128 && g.cg_loop == 1 && groups > 1 && tiles % 8 == 0 && (long)tiles * groups < (1l << 31)) ? 1 : 0;
   dim3 grid(g.gfast ? tiles * groups : tiles, g.gfast ? 1 : groups / g.cg_loop);
   hipLaunchKernelGGL((conv3x3_halo_kernel<PLANES, TP>), grid, 256, LDS, stream, x, wf, bias, residual, y, stats, g, alpha,
-                     relu);
+                     relu, mask);
   return 1;
 }
 template <int PLANES>
 static int launch_h3_shape(const float* x, const __bf16* wf, const float* bias, const float* residual, float* y, float* stats,
                            int N, int H, int W, int Cin, int Cout, int ldx, int ldy, int ldr, float alpha, int relu,
-                           hipStream_t stream) {
+                           hipStream_t stream, const float* mask, int ldm) {
   switch (h3_tp_for(W)) {
-    case 8: return launch_h3<PLANES, 8>(x, wf, bias, residual, y, stats, N, H, W, Cin, Cout, ldx, ldy, ldr, alpha, relu, stream);
-    case 16: return launch_h3<PLANES, 16>(x, wf, bias, residual, y, stats, N, H, W, Cin, Cout, ldx, ldy, ldr, alpha, relu, stream);
-    default: return launch_h3<PLANES, 32>(x, wf, bias, residual, y, stats, N, H, W, Cin, Cout, ldx, ldy, ldr, alpha, relu, stream);
+    case 8: return launch_h3<PLANES, 8>(x, wf, bias, residual, y, stats, N, H, W, Cin, Cout, ldx, ldy, ldr, alpha, relu, stream, mask, ldm);
+    case 16: return launch_h3<PLANES, 16>(x, wf, bias, residual, y, stats, N, H, W, Cin, Cout, ldx, ldy, ldr, alpha, relu, stream, mask, ldm);
+    default: return launch_h3<PLANES, 32>(x, wf, bias, residual, y, stats, N, H, W, Cin, Cout, ldx, ldy, ldr, alpha, relu, stream, mask, ldm);
   }
 }
 
@@ -553,11 +575,11 @@ static int launch_h3_shape(const float* x, const __bf16* wf, const float* bias, 
 // of stat rows (tiles) through *stat_rows.  planes: 2 = split products, 1 = single bf16.
 int focr_conv3x3_halo(const float* x, const void* wfrag, const float* bias, const float* residual, float* y,
                       float* stats, int N, int H, int W, int Cin, int Cout, int ldx, int ldy, int ldr, float alpha,
-                      int relu, int planes, hipStream_t stream) {
+                      int relu, int planes, hipStream_t stream, const float* mask = nullptr, int ldm = 0) {
   const __bf16* wf = reinterpret_cast<const __bf16*>(wfrag);
   if (planes == 1)
-    return launch_h3_shape<1>(x, wf, bias, residual, y, stats, N, H, W, Cin, Cout, ldx, ldy, ldr, alpha, relu, stream);
-  return launch_h3_shape<2>(x, wf, bias, residual, y, stats, N, H, W, Cin, Cout, ldx, ldy, ldr, alpha, relu, stream);
+    return launch_h3_shape<1>(x, wf, bias, residual, y, stats, N, H, W, Cin, Cout, ldx, ldy, ldr, alpha, relu, stream, mask, ldm);
+  return launch_h3_shape<2>(x, wf, bias, residual, y, stats, N, H, W, Cin, Cout, ldx, ldy, ldr, alpha, relu, stream, mask, ldm);
 }
 int focr_conv3x3_halo_tiles(int N, int H, int W) {
   const int tp = h3_tp_for(W), tr = 128 / tp;
@@ -599,9 +621,10 @@ extern "C" int focr_weight_prep_frag_batched(const void* descs_dev, int n, long 
 
 extern "C" int focr_conv3x3_frag_tiles(int N, int H, int W) { return focr_conv3x3_halo_tiles(N, H, W); }
 
-extern "C" int focr_conv3x3_frag_fwd(const float* x, const void* wfrag, const float* bias, const float* residual,
+static int conv3x3_frag_fwd_impl(const float* x, const void* wfrag, const float* bias, const float* residual,
                                      float* y, float* stats, int N, int H, int W, int Cin, int Cout, float alpha,
-                                     int relu, int planes, int ldy, int ldr, int ldx, hipStream_t stream) {
+                                     int relu, int planes, int ldy, int ldr, int ldx, const float* mask, int ldm,
+                                     hipStream_t stream) {
   FOCR_CHECK_ARG(x && wfrag && y && N > 0, "null pointer");
   if (ldy <= 0) ldy = Cout;
   if (ldr <= 0) ldr = Cout;
@@ -609,11 +632,29 @@ extern "C" int focr_conv3x3_frag_fwd(const float* x, const void* wfrag, const fl
   FOCR_CHECK_ARG(focr_conv3x3_halo_eligible(H, W, Cin, Cout, 3, 3, 1, 1, ldx), "layer shape not supported");
   FOCR_CHECK_ARG(ldy % 4 == 0 && ldr % 4 == 0 && ldy >= Cout && ldr >= Cout && ldx >= Cin, "bad row pitch");
   FOCR_CHECK_ARG(planes == 1 || planes == 2, "planes must be 1 or 2");
+  if (mask && ldm <= 0) ldm = Cout;
+  FOCR_CHECK_ARG(!mask || (ldm % 4 == 0 && ldm >= Cout && (reinterpret_cast<uintptr_t>(mask) & 15) == 0), "bad mask pitch / alignment");
   if (!focr_conv3x3_halo(x, wfrag, bias, residual, y, stats, N, H, W, Cin, Cout, ldx, ldy, ldr, alpha, relu, planes,
-                         stream)) {
+                         stream, mask, ldm)) {
     focr_set_error("focr_conv3x3_frag_fwd: launch setup failed");
     return FOCR_EHIP;
   }
   FOCR_LAUNCH_CHECK();
   return FOCR_OK;
+}
+
+extern "C" int focr_conv3x3_frag_fwd(const float* x, const void* wfrag, const float* bias, const float* residual,
+                                     float* y, float* stats, int N, int H, int W, int Cin, int Cout, float alpha,
+                                     int relu, int planes, int ldy, int ldr, int ldx, hipStream_t stream) {
+  return conv3x3_frag_fwd_impl(x, wfrag, bias, residual, y, stats, N, H, W, Cin, Cout, alpha, relu, planes, ldy, ldr, ldx,
+                               nullptr, 0, stream);
+}
+// as focr_conv3x3_frag_fwd, and the output is kept only where mask[pixel][channel] > 0 (mask: [N][H][W][ldm >= Cout] fp32):
+// the relu backward of the layer that produced this launch's input, applied to the data gradient it produces
+extern "C" int focr_conv3x3_frag_fwd_masked(const float* x, const void* wfrag, const float* bias, const float* residual,
+                                            float* y, int N, int H, int W, int Cin, int Cout, float alpha, int planes,
+                                            int ldy, int ldr, int ldx, const float* mask, int ldm, hipStream_t stream) {
+  FOCR_CHECK_ARG(mask, "null mask");
+  return conv3x3_frag_fwd_impl(x, wfrag, bias, residual, y, nullptr, N, H, W, Cin, Cout, alpha, 0, planes, ldy, ldr, ldx, mask,
+                               ldm, stream);
 }

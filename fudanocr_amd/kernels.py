@@ -502,12 +502,19 @@ def _is_out_layer(cin, cout, kh, kw, ph, pw, w, residual, alpha, relu):
             and w <= 128 and residual is None and alpha == 1.0 and not relu)
 
 
-def _conv_fwd_raw(x4, w_ohwi, bias, residual, cout, kh, kw, ph, pw, alpha, relu, frag=None, planes=2, stats=None):
+def _conv_fwd_raw(x4, w_ohwi, bias, residual, cout, kh, kw, ph, pw, alpha, relu, frag=None, planes=2, stats=None,
+                  mask=None):
     """frag: fragment-ordered bf16 weights (FragTable) -> halo kernel with `planes` products' worth of operand planes;
-    stats: optional [tiles, cout, 2] per-tile (sum, sum of squares) output for a following BatchNorm."""
+    stats: optional [tiles, cout, 2] per-tile (sum, sum of squares) output for a following BatchNorm;
+    mask (halo kernel only): contiguous [n, oh, ow, cout] tensor, the output is kept where mask > 0 (a producer's relu
+    backward in this data gradient's epilogue)."""
     n, h, w, cin = x4.shape
     oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
     y = torch.empty((n, oh, ow, cout), device=x4.device, dtype=torch.float32)
+    if frag is not None and mask is not None:
+        _lib.call("focr_conv3x3_frag_fwd_masked", _p(x4), ctypes.c_void_p(frag.data_ptr()), _p(bias), _p(residual), _p(y),
+                  n, h, w, cin, cout, float(alpha), int(planes), 0, 0, 0, _p(mask), 0, _stream())
+        return y
     if frag is not None:
         _lib.call("focr_conv3x3_frag_fwd", _p(x4), ctypes.c_void_p(frag.data_ptr()), _p(bias), _p(residual), _p(y),
                   _p(stats), n, h, w, cin, cout, float(alpha), int(relu), int(planes), 0, 0, 0, _stream())
@@ -688,8 +695,13 @@ class _Conv2d(torch.autograd.Function):
                 # data gradient on the halo kernel: flipped weights in fragment order; a single bf16 product under
                 # precision mode 3 (csrc/focr_core.hip), split products otherwise
                 wf = _frag_weights(step, weight, wk, cout, kh, kw, cin, True)
+                # the input was a relu output with THIS layer as its only gradient source (conv2d(fuse_input_relu=True): a
+                # parked shortcut gradient, if any, arrives as radd): its relu backward rides in this launch's epilogue
+                msk = x4 if (ctx.in_relu_scale == 1.0 and x4.is_contiguous() and _HALO_MASK) else None
                 dx4 = _conv_fwd_raw(dy4, None, None, radd, cin, kh, kw, 1, 1, alpha, False, frag=wf,
-                                    planes=1 if _lib.get_precision() == 3 else 2)
+                                    planes=1 if _lib.get_precision() == 3 else 2, mask=msk)
+                if msk is not None:
+                    step.mark_premasked(dx4)
             else:
                 persistent = weight.is_leaf and wk.data_ptr() == weight.data_ptr()
                 wd = step.flips.lookup(wk, cout, kh, kw, cin, not weight.requires_grad) \
@@ -709,8 +721,20 @@ class _Conv2d(torch.autograd.Function):
         return dx, dw, db, dres, None, None, None, None, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, pad=(0, 0), residual=None, alpha=1.0, relu=False, take_deferred=False):
-    return _Conv2d.apply(x, weight, bias, residual, pad, alpha, relu, 0.0, take_deferred, False)
+_HALO_MASK = os.environ.get("FOCR_HALO_MASK", "1") != "0"      # A/B: relu backward as its own launch
+
+
+def conv2d(x, weight, bias=None, pad=(0, 0), residual=None, alpha=1.0, relu=False, take_deferred=False,
+           defer_residual=False, fuse_input_relu=False):
+    """fuse_input_relu: x is the output of a relu `conv2d` AND every gradient of x arrives through THIS call (it is x's
+    only consumer, or the other one is a shortcut whose gradient is parked with defer_residual and taken here with
+    take_deferred): on a halo-kernel layer the data gradient applies that relu's backward in its epilogue and the
+    producer skips its own pass.  Opt-in, as with `linear`: the model code knows the wiring."""
+    scale = float(getattr(x, "_focr_relu_scale", 0.0)) if fuse_input_relu else 0.0
+    out = _Conv2d.apply(x, weight, bias, residual, pad, alpha, relu, 0.0, take_deferred, defer_residual, False, scale)
+    if relu and torch.is_grad_enabled():
+        out._focr_relu_scale = 1.0
+    return out
 
 
 def linear(x, weight, bias=None, residual=None, alpha=1.0, relu=False, dropout=0.0, take_deferred=False,
@@ -871,7 +895,8 @@ def _conv_bn_folded(conv, bn):
     return hit[1], hit[2]
 
 
-def conv_bn(x, conv, bn, act=ACT_NONE, residual=None, take_deferred=False, relu_out=False):
+def conv_bn(x, conv, bn, act=ACT_NONE, residual=None, take_deferred=False, relu_out=False, defer_residual=False,
+            fuse_input_relu=False):
     """act(bn(conv(x))) [+ residual] for a Conv2d / BatchNorm2d module pair (tbsrn.py:246-249, tsrn.py:89-93).  In
     training mode on a halo-kernel layer the convolution's epilogue emits the per-tile sums the BatchNorm needs, so
     the two statistics passes over the conv output disappear.
@@ -880,7 +905,7 @@ def conv_bn(x, conv, bn, act=ACT_NONE, residual=None, take_deferred=False, relu_
     if conv_bn_foldable(conv, bn, x) and (relu_out or residual is None) and act in (ACT_NONE, ACT_RELU):
         wf, bf = _conv_bn_folded(conv, bn)
         return conv2d(x, wf, bf, pad=conv.padding, residual=residual, relu=bool(relu_out) or act == ACT_RELU,
-                      take_deferred=take_deferred)
+                      take_deferred=take_deferred, defer_residual=defer_residual, fuse_input_relu=fuse_input_relu)
     if relu_out:
         raise RuntimeError("conv_bn(relu_out=True) needs a foldable layer (check conv_bn_foldable first)")
     training = bn.training or not bn.track_running_stats

@@ -28,11 +28,20 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        if K.conv_bn_foldable(self.conv2, self.bn2, x) and K.conv_bn_foldable(self.conv1, self.bn1, x):
+            # frozen, eval-mode block (the recognizers inside the text- / stroke-focus losses): relu(bn2(conv2) + residual)
+            # is one convolution launch on folded weights.  Backward (only data gradients exist): with an identity
+            # shortcut every gradient of x arrives through conv1 -- the shortcut's is parked by conv2 and added in conv1's
+            # data-gradient epilogue -- so that epilogue can also apply the relu backward of the layer that produced x; `out`
+            # has conv2 as its only consumer, the same there: two relu-backward launches and one gradient add per block gone
+            ident = self.downsample is None
+            out = K.conv_bn(x, self.conv1, self.bn1, act=K.ACT_RELU, take_deferred=ident, fuse_input_relu=ident)
+            residual = x if ident else K.conv_bn(x, self.downsample[0], self.downsample[1])
+            return K.conv_bn(out, self.conv2, self.bn2, residual=residual, relu_out=True, defer_residual=ident,
+                             fuse_input_relu=True)
         out = K.conv_bn(x, self.conv1, self.bn1, act=K.ACT_RELU)
         residual = x if self.downsample is None else K.conv_bn(x, self.downsample[0], self.downsample[1])
         if K.conv_bn_foldable(self.conv2, self.bn2, out):
-            # frozen, eval-mode block (the recognizers inside the text- / stroke-focus losses): relu(bn2(conv2) + residual)
-            # is one convolution launch on folded weights
             return K.conv_bn(out, self.conv2, self.bn2, residual=residual, relu_out=True)
         out = K.conv_bn(out, self.conv2, self.bn2)
         return ops.add_relu(out, residual)

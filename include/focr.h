@@ -136,6 +136,12 @@ int focr_conv3x3_frag_tiles(int N, int H, int W);
 int focr_conv3x3_frag_fwd(const float* x, const void* wfrag, const float* bias, const float* residual, float* y,
                           float* stats, int N, int H, int W, int Cin, int Cout, float alpha, int relu, int planes,
                           int ldy, int ldr, int ldx, focr_stream_t stream);
+/* the same launch with a relu-backward mask in its epilogue: the output (the data gradient of a layer whose INPUT was a relu
+ * output) is kept where mask[pixel][channel] > 0, else 0 -- the producing layer's relu backward without its own pass
+ * (ResNet basic blocks of the frozen focus-loss recognizers, loss/transformer.py:90-139); mask: [N][H][W][ldm >= Cout] fp32 */
+int focr_conv3x3_frag_fwd_masked(const float* x, const void* wfrag, const float* bias, const float* residual, float* y,
+                                 int N, int H, int W, int Cin, int Cout, float alpha, int planes, int ldy, int ldr, int ldx,
+                                 const float* mask, int ldm, focr_stream_t stream);
 /* out[c] = sum_r x[r*ld + c]   (bias gradients) */
 int focr_colsum(const float* x, float* out, long rows, int C, int ld, focr_stream_t stream);
 /* specialised 9x9, pad 4, Cin=64 -> Cout<=3 convolution (SR output layer, model/tsrn.py:43):

@@ -185,6 +185,16 @@ def test_halo_conv_c_abi(shape):
     _lib.call("focr_conv3x3_frag_fwd", vp(gyd), vp(wff), None, None, vp(dx), None, n, h, w, cout, cin, 1.0, 0, 2, 0, 0, 0,
               st)
     close(dx.permute(0, 3, 1, 2), xg.grad, 1e-4, what="halo dgrad")
+    # the same launch with a relu-backward mask + a parked shortcut gradient in its epilogue: (dgrad + r) where m > 0, else 0
+    m = dev(rnd(n, h, w, cin, seed=6))
+    rr = dev(rnd(n, h, w, cin, seed=7))
+    dxm = torch.full((n, h, w, cin), float("nan"), device="cuda")
+    for planes, tol in ((2, 1e-4), (1, 4e-3)):
+        _lib.call("focr_conv3x3_frag_fwd_masked", vp(gyd), vp(wff), None, vp(rr), vp(dxm), n, h, w, cout, cin, 1.0, planes, 0, 0,
+                  0, vp(m), 0, st)
+        want = torch.where(m > 0, xg.grad.permute(0, 2, 3, 1).cuda().float() + rr, torch.zeros_like(rr))
+        close(dxm, want, tol, what="halo dgrad with mask, planes=%d" % planes)
+        assert float(dxm[m <= 0].abs().max()) == 0.0
     del k
 
 
