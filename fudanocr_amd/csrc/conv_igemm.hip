@@ -452,6 +452,9 @@ __global__ __launch_bounds__(256) void tiny_linear_kernel(const float* __restric
   }
 }
 
+int focr_gemm_big_bx3(const float* x, const float* w, const float* bias, const float* residual, float* y, long M, int K,
+                      int N, int ldx, int ldy, int ldr, float alpha, int relu, hipStream_t stream);
+
 static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, const float* residual, float* y, int N,
                            int H, int W, int Cin, int Cout, int KH, int KW, int padH, int padW, float alpha, int relu,
                            int ldy, int ldr, int ldx, float* ws, long ws_floats, hipStream_t stream) {
@@ -466,6 +469,11 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, co
   if (focr_get_precision() != 0 &&
       focr_conv9x9_cin3_fwd(x, w, bias, residual, y, N, H, W, Cin, Cout, KH, KW, padH, padW, g.ldx, g.ldy, alpha, relu,
                             stream)) {
+    FOCR_LAUNCH_CHECK();
+    return FOCR_OK;
+  }
+  if (vec && focr_get_precision() != 0 && KH == 1 && KW == 1 && padH == 0 && padW == 0 &&
+      focr_gemm_big_bx3(x, w, bias, residual, y, g.M, Cin, Cout, g.ldx, g.ldy, g.ldr, alpha, relu, stream)) {   // gemm_big.hip
     FOCR_LAUNCH_CHECK();
     return FOCR_OK;
   }

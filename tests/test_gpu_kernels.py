@@ -114,6 +114,9 @@ CONV_CASES = [
     (3, 7, 64, 4, 32, 9, 9, 4, 4),        # ... odd height, one channel group, several row ranges
     (1, 32, 128, 64, 4, 9, 9, 4, 4),      # block8.1 with the mask channel: two launches of two channels (conv9x9_out.hip)
     (3, 16, 64, 64, 4, 9, 9, 4, 4),       # ... W = 64, several images
+    # large plain GEMMs (1 x 1 layers with many rows: the recognizers' K / V projections) on the 256 x 128 tile kernel
+    (32, 8, 32, 256, 1024, 1, 1, 0, 0),   # gemm_big.hip: M = 8192, 32 x 8 tiles
+    (25, 11, 31, 320, 768, 1, 1, 0, 0),   # ... ragged last row block (M = 8525), ten K chunks, six column tiles
 ]
 
 
