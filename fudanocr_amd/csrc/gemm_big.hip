@@ -111,7 +111,9 @@ __global__ __launch_bounds__(512, 1) void gemm_big_bx3_kernel(const float* __res
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
         }
     }
-    if (more) store_chunk((c + 1) & 1);   // the other stage: last read in iteration c - 1, every wave is past that barrier
+    // (the other stage: last read in iteration c - 1, every wave is past that barrier.  Storing between the two k-steps, under
+    // the first one's MFMAs, measured 3-8 % SLOWER: profiles/r06_gemm_big_store_mid.txt)
+    if (more) store_chunk((c + 1) & 1);
     __syncthreads();
   }
   // C tile (a, b) of this wave: rows m0 + 64 wm + 32 a + (r & 3) + 8 (r >> 2) + 4 lh, column n0 + 64 wn + 32 b + li
