@@ -211,7 +211,10 @@ __device__ unsigned long long* h3_trace_buf;
 #define H3_STAMP(k)
 #endif
 
-template <int PLANES, int TP = H3_TP>
+// MASK is a template parameter, not a run-time test: with `if (Mk)` around the eight mask registers EVERY instantiation
+// spilled (private segment 20-100 -> 336-420 B, 8 -> 86-105 spilled VGPRs; the 64 -> 64 layer 43 -> 55 us alone,
+// profiles/r06f_*) -- the unmasked kernel is the round-5 kernel, register for register.
+template <int PLANES, int TP = H3_TP, bool MASK = false>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_kernel(const float* __restrict__ X, const __bf16* __restrict__ Wf,
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ R, float* __restrict__ Y,
@@ -428,11 +431,13 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       // its own 8 KB of it, so that a lane owns 4 consecutive channels of one pixel: 16-byte residual loads and
       // output stores (a pixel's 256 B row is one contiguous access of 16 lanes) instead of 32 + 32 scalar ones
       float* const tw = reinterpret_cast<float*>(h3_smem) + wave * (32 * 64);
-      float4 mv[8];                               // mask source values (requested here, under the transposition)
-      if (Mk) {
+      float4 mv[MASK ? 8 : 1];                    // mask source values (requested here, under the transposition)
+      if (MASK) {
+        int x0m = x0, oym = oy;                   // opaque: these addresses are formed HERE, not hoisted above the main loop
+        asm volatile("" : "+v"(x0m), "+v"(oym));
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int m = 4 * i + epq, ox = x0 + m % TP, oyy = oy + m / TP;
+        for (int i = 0; i < (MASK ? 8 : 0); ++i) {
+          const int m = 4 * i + epq, ox = x0m + m % TP, oyy = oym + m / TP;
           const bool ok = oyy < g.H && ox < g.W;
           const size_t pix = (size_t)(img * g.H + (ok ? oyy : 0)) * g.W + (ok ? ox : 0);
           mv[i] = *reinterpret_cast<const float4*>(Mk + pix * g.ldm + eco);
@@ -454,9 +459,10 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         float4 v = make_float4(alpha * a.x + bv.x + rv[i].x, alpha * a.y + bv.y + rv[i].y, alpha * a.z + bv.z + rv[i].z,
                                alpha * a.w + bv.w + rv[i].w);
         if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-        if (Mk)
-          v = make_float4(mv[i].x > 0.f ? v.x : 0.f, mv[i].y > 0.f ? v.y : 0.f, mv[i].z > 0.f ? v.z : 0.f,
-                          mv[i].w > 0.f ? v.w : 0.f);
+        if (MASK) {
+          const float4 mk = mv[MASK ? i : 0];
+          v = make_float4(mk.x > 0.f ? v.x : 0.f, mk.y > 0.f ? v.y : 0.f, mk.z > 0.f ? v.z : 0.f, mk.w > 0.f ? v.w : 0.f);
+        }
         const int m = 4 * i + pq, oyy = oy + m / TP;
         if (oyy < g.H && x0 + m % TP < g.W) {
           const size_t pix = (size_t)(img * g.H + oyy) * g.W + x0e + m % TP;
@@ -510,7 +516,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
           if (relu) v = fmaxf(v, 0.f);
           if (oyy < g.H && ox < g.W) {
             const size_t pix = (size_t)(img * g.H + oyy) * g.W + ox;
-            if (Mk && !(Mk[pix * g.ldm + co] > 0.f)) v = 0.f;
+            if (MASK && !(Mk[pix * g.ldm + co] > 0.f)) v = 0.f;
             Y[pix * g.ldy + co] = v;
           }
         }
@@ -536,7 +542,9 @@ static int launch_h3(const float* x, const __bf16* wf, const float* bias, const 
   constexpr int TR = 128 / TP;
   static focr_dev_flags attr_set;
   if (focr_dev_first(attr_set)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<PLANES, TP>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<PLANES, TP, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<PLANES, TP, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return 0;
     focr_dev_mark(attr_set);
@@ -556,8 +564,12 @@ static int launch_h3(const float* x, const __bf16* wf, const float* bias, const 
   g.tiles = tiles;
   g.gfast = (gfast_on && PLANES == 1 && Cin >= 128 && g.cg_loop == 1 && groups > 1 && tiles % 8 == 0 && (long)tiles * groups < (1l << 31)) ? 1 : 0;
   dim3 grid(g.gfast ? tiles * groups : tiles, g.gfast ? 1 : groups / g.cg_loop);
-  hipLaunchKernelGGL((conv3x3_halo_kernel<PLANES, TP>), grid, 256, LDS, stream, x, wf, bias, residual, y, stats, g, alpha,
-                     relu, mask);
+  if (mask)
+    hipLaunchKernelGGL((conv3x3_halo_kernel<PLANES, TP, true>), grid, 256, LDS, stream, x, wf, bias, residual, y, stats, g,
+                       alpha, relu, mask);
+  else
+    hipLaunchKernelGGL((conv3x3_halo_kernel<PLANES, TP, false>), grid, 256, LDS, stream, x, wf, bias, residual, y, stats, g,
+                       alpha, relu, mask);
   return 1;
 }
 template <int PLANES>
