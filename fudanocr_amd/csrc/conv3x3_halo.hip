@@ -214,7 +214,10 @@ __device__ unsigned long long* h3_trace_buf;
 // MASK is a template parameter, not a run-time test: with `if (Mk)` around the eight mask registers EVERY instantiation
 // spilled (private segment 20-100 -> 336-420 B, 8 -> 86-105 spilled VGPRs; the 64 -> 64 layer 43 -> 55 us alone,
 // profiles/r06f_*) -- the unmasked kernel is the round-5 kernel, register for register.
-template <int PLANES, int TP = H3_TP, bool MASK = false>
+// RES: the launch has a residual operand.  Launches without one -- most of the SR network's -- take the instantiation
+// that does not carry its eight float4 per lane at all (161-179 VGPRs): 64 -> 64 at B = 128 42.6 -> 37.4 us,
+// c3 -1.6 %, c5 -2.2 %, c1 -2.5 % (profiles/r06_halo_nores_ab.txt).
+template <int PLANES, int TP = H3_TP, bool MASK = false, bool RES = true>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_kernel(const float* __restrict__ X, const __bf16* __restrict__ Wf,
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ R, float* __restrict__ Y,
@@ -373,11 +376,11 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    // residual values of the transposed epilogue (lane = 4 channels of pixel 4 i + lane / 16): requested before the
-    // last slice's contraction, consumed after it
+    // residual values of the transposed epilogue (lane = 4 channels of pixel 4 i + lane / 16): requested and consumed in the
+    // epilogue (see there)
     // (default shape: a wave's pixel m = 0..31 is (row y0 + wave, column x0 + m); narrow shapes: RPW rows of TP pixels)
     const int ec4 = lane & 15, epq = lane >> 4, eco = cg * 64 + ec4 * 4, oy = y0 + wave * RPW;
-    float4 rv[8];
+    float4 rv[RES ? 8 : 1];
     for (int s = 0; s < nslices; ++s) {
 #ifndef H3_ABL_STAGE
       if (gi == 0 || nslices > 1) stage_halo(s);    // Cin == 64: the halo stays for every output group
@@ -385,15 +388,6 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                              // halo + first chunk of the slice visible
       H3_STAMP(1);
-      if (s == nslices - 1 && g.cg_loop == 1) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int m = 4 * i + epq, ox = x0 + m % TP, oyy = oy + m / TP;
-          const bool ok = oyy < g.H && ox < g.W;
-          const size_t pix = (size_t)(img * g.H + (ok ? oyy : 0)) * g.W + (ok ? ox : 0);
-          rv[i] = R ? *reinterpret_cast<const float4*>(R + pix * g.ldr + eco) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      }
       const bool more = (s + 1 < nslices) || (gi + 1 < g.cg_loop);
       const int ncg = s + 1 < nslices ? cg : cg + 1, nsl = s + 1 < nslices ? s + 1 : 0;
       H3Frags<PLANES> fa, fb;                       // fa: step 0 of a chunk, fb: step 1
@@ -431,6 +425,22 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       // its own 8 KB of it, so that a lane owns 4 consecutive channels of one pixel: 16-byte residual loads and
       // output stores (a pixel's 256 B row is one contiguous access of 16 lanes) instead of 32 + 32 scalar ones
       float* const tw = reinterpret_cast<float*>(h3_smem) + wave * (32 * 64);
+      // The residual is requested HERE, after the contraction (round 6).  Through round 5 it was requested before the last
+      // slice's contraction and consumed after it: 32 registers live across the main loop of a kernel at the 256-VGPR limit
+      // -- the source of every spill this kernel had (20-24 VGPRs, 84-100 B of scratch per thread = ~10 MB of writes per
+      // launch).  Requested late the launch waits for it under the LDS transposition instead, and every instantiation is
+      // spill-free: tfl 37.2 -> 36.6 ms, sfl 40.9 -> 40.3 (profiles/r06_halo_late_res_ab.txt).
+      if (RES) {
+        int x0r = x0, oyr = oy;
+        asm volatile("" : "+v"(x0r), "+v"(oyr));
+#pragma unroll
+        for (int i = 0; i < (RES ? 8 : 0); ++i) {
+          const int m = 4 * i + epq, ox = x0r + m % TP, oyy = oyr + m / TP;
+          const bool ok = oyy < g.H && ox < g.W;
+          const size_t pix = (size_t)(img * g.H + (ok ? oyy : 0)) * g.W + (ok ? ox : 0);
+          rv[RES ? i : 0] = R ? *reinterpret_cast<const float4*>(R + pix * g.ldr + eco) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
       float4 mv[MASK ? 8 : 1];                    // mask source values (requested here, under the transposition)
       if (MASK) {
         int x0m = x0, oym = oy;                   // opaque: these addresses are formed HERE, not hoisted above the main loop
@@ -456,8 +466,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const float4 a = *reinterpret_cast<const float4*>(tw + (4 * i + pq) * 64 + c4 * 4);
-        float4 v = make_float4(alpha * a.x + bv.x + rv[i].x, alpha * a.y + bv.y + rv[i].y, alpha * a.z + bv.z + rv[i].z,
-                               alpha * a.w + bv.w + rv[i].w);
+        const float4 rr = RES ? rv[RES ? i : 0] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v = make_float4(alpha * a.x + bv.x + rr.x, alpha * a.y + bv.y + rr.y, alpha * a.z + bv.z + rr.z,
+                               alpha * a.w + bv.w + rr.w);
         if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
         if (MASK) {
           const float4 mk = mv[MASK ? i : 0];
@@ -507,7 +518,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
           const int m = (r & 3) + 8 * (r >> 2) + 4 * lh, ox = x0 + m % TP, oyy = oy + m / TP;
           const bool ok = oyy < g.H && ox < g.W;
           const size_t pix = (size_t)(img * g.H + (ok ? oyy : 0)) * g.W + (ok ? ox : 0);
-          rv[r] = R ? R[pix * g.ldr + co] : 0.f;
+          rv[r] = (RES && R) ? R[pix * g.ldr + co] : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -542,9 +553,11 @@ static int launch_h3(const float* x, const __bf16* wf, const float* bias, const 
   constexpr int TR = 128 / TP;
   static focr_dev_flags attr_set;
   if (focr_dev_first(attr_set)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<PLANES, TP, false>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<PLANES, TP, false, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<PLANES, TP, true>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<PLANES, TP, false, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<PLANES, TP, true, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return 0;
     focr_dev_mark(attr_set);
@@ -564,12 +577,16 @@ static int launch_h3(const float* x, const __bf16* wf, const float* bias, const 
   g.tiles = tiles;
   g.gfast = (gfast_on && PLANES == 1 && Cin >= 128 && g.cg_loop == 1 && groups > 1 && tiles % 8 == 0 && (long)tiles * groups < (1l << 31)) ? 1 : 0;
   dim3 grid(g.gfast ? tiles * groups : tiles, g.gfast ? 1 : groups / g.cg_loop);
+  static const bool nores_on = !(getenv("FOCR_H3_NORES") && getenv("FOCR_H3_NORES")[0] == '0');
   if (mask)
-    hipLaunchKernelGGL((conv3x3_halo_kernel<PLANES, TP, true>), grid, 256, LDS, stream, x, wf, bias, residual, y, stats, g,
-                       alpha, relu, mask);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<PLANES, TP, true, true>), grid, 256, LDS, stream, x, wf, bias, residual, y, stats,
+                       g, alpha, relu, mask);
+  else if (!residual && nores_on)
+    hipLaunchKernelGGL((conv3x3_halo_kernel<PLANES, TP, false, false>), grid, 256, LDS, stream, x, wf, bias, residual, y, stats,
+                       g, alpha, relu, mask);
   else
-    hipLaunchKernelGGL((conv3x3_halo_kernel<PLANES, TP, false>), grid, 256, LDS, stream, x, wf, bias, residual, y, stats, g,
-                       alpha, relu, mask);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<PLANES, TP, false, true>), grid, 256, LDS, stream, x, wf, bias, residual, y, stats,
+                       g, alpha, relu, mask);
   return 1;
 }
 template <int PLANES>

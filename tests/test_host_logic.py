@@ -420,8 +420,8 @@ def test_halo_kernel_register_budget(tmp_path):
     """conv3x3_halo_kernel sits at the 256-VGPR limit of two waves per SIMD; a few more live registers and EVERY instantiation
     spills (round 6: a run-time `if (mask)` around eight epilogue registers took the private segment from 20-100 to 336-420
     bytes and the 64 -> 64 layer from 43 to 55 us -- found only in the end-of-round profile).  Compile the file for gfx950 and
-    hold the unmasked instantiations (the ones the SR network and every forward pass use) to the budget they have had since
-    round 3; the masked data-gradient variants may spill more, bounded too."""
+    hold the unmasked instantiations (the ones the SR network and every forward pass use) to NO scratch at all -- what they
+    have had since the residual operand left the main loop's live ranges; the masked data-gradient variants to a few registers."""
     import re
     import shutil
     import subprocess
@@ -436,8 +436,10 @@ def test_halo_kernel_register_budget(tmp_path):
     text = out.read_text()
     rows = re.findall(r"\.name:\s+(\S*conv3x3_halo_kernel\S*)\n(?:.*\n){0,14}?\s+\.private_segment_fixed_size:\s+(\d+)"
                       r"(?:.*\n){0,14}?\s+\.vgpr_count:\s+(\d+)", text)
-    assert len(rows) == 12, [r[0] for r in rows]               # {1, 2 planes} x {8, 16, 32 px rows} x {plain, masked}
+    assert len(rows) == 18, [r[0] for r in rows]     # {1, 2 planes} x {8, 16, 32 px rows} x {no residual, residual, residual + mask}
     for name, private, vgprs in rows:
-        masked = "ELb1EE" in name
+        masked = "ELb1ELb1EE" in name
         assert int(vgprs) <= 256, (name, vgprs)
-        assert int(private) <= (288 if masked else 128), (name, private)
+        # since the residual is requested after the contraction (round 6) no instantiation needs scratch, bar a few
+        # registers of two masked ones
+        assert int(private) <= (64 if masked else 0), (name, private)
