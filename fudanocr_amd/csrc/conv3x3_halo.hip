@@ -217,6 +217,8 @@ __device__ unsigned long long* h3_trace_buf;
 // RES: the launch has a residual operand.  Launches without one -- most of the SR network's -- take the instantiation
 // that does not carry its eight float4 per lane at all (161-179 VGPRs): 64 -> 64 at B = 128 42.6 -> 37.4 us,
 // c3 -1.6 %, c5 -2.2 %, c1 -2.5 % (profiles/r06_halo_nores_ab.txt).
+// (three blocks per CU for the single-product, no-residual instantiation -- 161 VGPRs, 50.7 KB of LDS, waves_per_eu(2, 3) --
+// measured: no change, profiles/r06_halo_occ3_ab.txt)
 template <int PLANES, int TP = H3_TP, bool MASK = false, bool RES = true>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_kernel(const float* __restrict__ X, const __bf16* __restrict__ Wf,
                                                               const float* __restrict__ bias,
