@@ -39,7 +39,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak; the bf16x3 split issue
 FLOP_PER_IMG = {"c3": 18.131e9, "c1": 5.366e9 + 2.820e9, "c2": 15.311e9, "c5": 94.667e9,
                 "tfl": 15.311e9 + 3 * 26.8e9, "sfl": 15.311e9 + 3 * 26.8e9}
 DEFAULT_BATCH = {"c3": 128, "c1": 128, "c2": 64, "c5": 32, "tfl": 128, "sfl": 128}
-PMC_ARTEFACT = os.path.join(ROOT, "profiles", "r06f_pmc_traffic.json")
+PMC_ARTEFACT = os.path.join(ROOT, "profiles", "r06g_pmc_traffic.json")
 
 
 def _cpu_model():
