@@ -347,11 +347,16 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   };
   auto stage_halo = [&](int s) {
     constexpr int NPASS = (HR * HP * 16 + 255) / 256;           // 13 (12 for the narrow shapes)
-    // two batches (7 + 6 loads per thread): one batch of 13 is SLOWER (staging phase 6.8 -> 7.4 us in the block trace,
-    // launch 40.8 -> 42.0 us, 31 spilled VGPRs in the split-product variant) -- the phase is bandwidth-, not
-    // round-trip-bound
-    stage_batch(s, std::integral_constant<int, 0>{}, std::integral_constant<int, 7>{});
-    stage_batch(s, std::integral_constant<int, 7>{}, std::integral_constant<int, NPASS>{});
+    // round 3: two batches (7 + 6 loads per thread), one batch of 13 was SLOWER (staging phase 6.8 -> 7.4 us in the block
+    // trace, launch 40.8 -> 42.0 us) -- with 31 spilled VGPRs in the split-product variant
+    // (round 6, the kernel no longer spills: split-product launches take all 13 loads in one batch -- 512 -> 512 at B = 128
+    // 421 -> 414 us, tfl -0.8 %; single-product launches are FASTER with 7 + 6: 174 vs 187 us, profiles/r06_halo_one_batch_ab.txt)
+    if (PLANES == 2) {
+      stage_batch(s, std::integral_constant<int, 0>{}, std::integral_constant<int, NPASS>{});
+    } else {
+      stage_batch(s, std::integral_constant<int, 0>{}, std::integral_constant<int, 7>{});
+      stage_batch(s, std::integral_constant<int, 7>{}, std::integral_constant<int, NPASS>{});
+    }
   };
 
   // per-lane LDS byte addresses: A fragment of pixel (wave + kh, li + kw), channel chunk 2 * kk + lh (the tap row kh and
