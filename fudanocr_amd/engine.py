@@ -142,6 +142,9 @@ class _Boundary(torch.autograd.Function):
         return g, None
 
 
+_HR_SIDE = os.environ.get("FOCR_HR_SIDE", "1") != "0"      # the focus losses' HR branch on the side stream, under the SR forward
+
+
 class TrainStep:
     """model: SR net (TBSRN/TSRN); crit: CTCFocusLoss.  One call = one optimisation step.
 
@@ -546,6 +549,10 @@ class TrainStep:
                     flip_ev.record(side)
         try:
             with K.use_context(c):
+                if _HR_SIDE and on_gpu and self.wgrad_side_stream and encoded is not None and hasattr(self.crit, "prefetch_hr"):
+                    if c.side_stream_obj is None:
+                        c.side_stream_obj = torch.cuda.Stream()
+                    self.crit.prefetch_hr(images_hr, encoded, c.side_stream_obj)
                 sr = self.model(images_lr)
                 loss, mse, _, ctc = self.crit(sr, images_hr, label_strs, encoded)
             if on_gpu:
